@@ -1,0 +1,192 @@
+/*
+ * jtx_mi.h -- C-ABI of the MI355X-native path-tracing core for JTX-PathTracer.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * has no FFI of its own -- the path is reached by direct C++ calls -- so each entry point below
+ * names the reference interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ * All functions return 0 on success, non-zero on failure (jtx_mi_last_error() has the text) and
+ * never throw.  The library has NO CPU fallback: every compute entry point needs a gfx950 device.
+ *
+ * Buffer orientation (reference quirk Q9: camera.cpp:103, camera.hpp:127-139): row 0 of the
+ * acc/img buffers is the BOTTOM scan-line, exactly as Camera::img_ / acc_ in the reference
+ * (RGB8Image::save flips rows, image.cpp:14-22).
+ */
+#ifndef JTX_MI_H
+#define JTX_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JTX_MI_VERSION 1
+
+/* LinearBVHNode, src/bvh.hpp:7-15 (32 B) */
+typedef struct {
+    float    pmin[3];
+    float    pmax[3];
+    int32_t  offset;      /* leaf: primitivesOffset; interior: secondChildOffset */
+    uint16_t num_prims;   /* > 0 => leaf */
+    uint8_t  axis;
+    uint8_t  pad;
+} jtx_mi_bvh_node;
+
+/* Triangle{index, meshIndex}, src/mesh.hpp:202-204 */
+typedef struct { int32_t index; int32_t mesh_index; } jtx_mi_tri_ref;
+
+/* Material, src/material.hpp:5-23.  Texture ids: -1 = none (reference quirk Q4). */
+typedef struct {
+    int32_t type;          /* 0 DIFFUSE, 1 DIELECTRIC, 2 CONDUCTOR, 3 METALLIC_ROUGHNESS */
+    float   albedo[3];
+    float   ior[3];
+    float   k[3];
+    float   alpha_x, alpha_y;   /* METALLIC_ROUGHNESS: alpha_x = metallic, alpha_y = roughness (loader.cpp:136-137) */
+    float   emission[3];        /* carried, unused by integrateMIS (integrator.cpp:189-190) */
+    int32_t albedo_tex;
+    int32_t mr_tex;
+} jtx_mi_material;
+
+/* Light, src/lights/lights.hpp:24-34 */
+typedef struct {
+    int32_t type;          /* 0 POINT, 1 DISTANT */
+    float   position[3];   /* DISTANT: direction the light travels */
+    float   intensity[3];
+    float   scale;
+    float   scene_radius;  /* overwritten by scene_create for DISTANT (scene.cpp:128-134) */
+} jtx_mi_light;
+
+/* TextureImage, src/image.hpp:99-226: float texels, nearest lookup, wrap */
+typedef struct {
+    int32_t width, height, channels;
+    const float *texels;
+} jtx_mi_texture;
+
+/* Mesh, src/mesh.hpp:10-69 */
+typedef struct {
+    int32_t        num_triangles;
+    int32_t        num_vertices;
+    const int32_t *indices;       /* 3 per triangle */
+    const float   *vertices;      /* 3 per vertex */
+    const float   *normals;       /* 3 per vertex */
+    const float   *uvs;           /* 2 per vertex, or NULL => uv (0,0) (reference quirk Q3) */
+    int32_t        material;      /* index into materials (replaces Material*) */
+    float          transform[16]; /* row-major Mesh::transform, baked into the device copy at create */
+} jtx_mi_mesh;
+
+/* Scene, src/scene.hpp:24-91 */
+typedef struct {
+    int32_t                num_meshes;
+    const jtx_mi_mesh     *meshes;
+    int32_t                num_tri_refs;
+    const jtx_mi_tri_ref  *tri_refs;      /* Scene::triangles */
+    int32_t                num_materials;
+    const jtx_mi_material *materials;
+    int32_t                num_lights;
+    const jtx_mi_light    *lights;
+    int32_t                num_textures;
+    const jtx_mi_texture  *textures;
+    float                  sky_color[3];
+    int32_t                max_prims_in_node;  /* Scene::buildBVH(maxPrimsInNode), default 1 */
+} jtx_mi_scene_desc;
+
+/* Camera ctor args + CameraProperties, src/camera.hpp:44-54, src/scene.hpp:15-22 */
+typedef struct {
+    float   center[3], target[3], up[3];
+    float   yfov, defocus_angle, focus_distance;
+    int32_t width, height;
+    int32_t x_pixel_samples, y_pixel_samples;
+    int32_t max_depth;
+} jtx_mi_camera_desc;
+
+typedef struct {
+    int32_t sample_begin;     /* first stratum to render; 0 clears the accumulation buffer */
+    int32_t sample_end;       /* one past the last stratum; <= 0 => xs*ys */
+    int32_t tile_rank;        /* multi-GPU pixel-tile sharding: this process owns 32x32 tiles k with */
+    int32_t tile_world;       /*   k % tile_world == tile_rank (0/0 or 0/1 => whole frame) */
+    int32_t integrator;       /* 0 auto, 1 pixel-persistent megakernel, 2 queued wavefront */
+    int32_t count_rays;       /* != 0: accumulate jtx_mi_counters on the device (slower) */
+    int32_t samples_per_tick; /* progress callback granularity for jtx_mi_render; <= 0 => all */
+    int32_t reserved;
+} jtx_mi_render_opts;
+
+/* ray / traffic counters */
+typedef struct {
+    uint64_t n_camera, n_closest, n_any;
+    uint64_t n_nodes_closest, n_tri_closest, n_accept;
+    uint64_t n_nodes_any, n_tri_any, n_shade;
+} jtx_mi_counters;
+
+typedef struct {
+    int32_t num_nodes, num_prims, max_depth, lds_resident;
+    float   scene_radius;
+    uint64_t device_bytes;
+} jtx_mi_scene_info;
+
+typedef struct jtx_mi_scene jtx_mi_scene;
+
+/* return non-zero to abort (replaces Camera::terminateRender / stopRender_, camera.hpp:77) */
+typedef int (*jtx_mi_progress_cb)(int32_t current_sample, int32_t total_samples, void *user);
+
+const char *jtx_mi_last_error(void);
+int         jtx_mi_version(void);
+int         jtx_mi_device_count(int32_t *count);
+int         jtx_mi_set_device(int32_t device);
+
+/* Host-only: Scene::buildBVH (scene.cpp:96-135) = buildTree (bvh.cpp:9-133) + flattenBVH (bvh.cpp:135-149).
+ * nodes_out needs room for 2*num_tri_refs nodes, refs_out for num_tri_refs.  No GPU needed. */
+int jtx_mi_bvh_build(const jtx_mi_scene_desc *desc, jtx_mi_bvh_node *nodes_out, int32_t *num_nodes_out,
+                     jtx_mi_tri_ref *refs_out, int32_t *max_depth_out);
+
+/* Scene::buildBVH + upload: builds the BVH on the host, bakes transforms, lays nodes / triangles /
+ * shading records out for the kernels and copies them to the current device. */
+int  jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out);
+void jtx_mi_scene_destroy(jtx_mi_scene *scene);                      /* Scene::destroy */
+int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
+int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
+
+/* StaticCamera::render(const Scene&) (camera.cpp:45-128), blocking.  acc_rgb: W*H*3 float sums
+ * (AccumulationBuffer), img_rgb: W*H*3 u8 (RGB8Image); both HOST buffers owned by the caller. */
+int jtx_mi_render(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
+                  float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user);
+
+/* Same, DEVICE buffers, asynchronous on `stream` (a hipStream_t, NULL = the library's own stream).
+ * d_acc_rgb must stay valid until the stream is synchronised.  Used by bench.py / multi-GPU. */
+int jtx_mi_render_device(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
+                         void *d_acc_rgb, void *d_img_rgb, void *stream);
+int jtx_mi_sync(jtx_mi_scene *scene);
+/* GPU time of the integrator kernel(s) of the last render call(s) since the previous query,
+ * from HIP events recorded on the launch stream: sum in ms and number of launches. */
+int jtx_mi_kernel_time(jtx_mi_scene *scene, float *ms_total, int32_t *launches);
+int jtx_mi_get_counters(jtx_mi_scene *scene, jtx_mi_counters *out);  /* of the last count_rays render */
+
+/* Fine-grained entry points for parity tests (HOST buffers; blocking). */
+/* Scene::closestHit (scene.cpp:10-55): prim = index into the BVH-ordered refs, -1 on miss */
+int jtx_mi_closest_hit_batch(jtx_mi_scene *scene, int32_t n, const float *o, const float *d, float tmin, float tmax,
+                             int32_t *hit, float *t, int32_t *prim, float *b1, float *b2,
+                             float *point, float *normal, float *uv);
+/* Scene::anyHit (scene.cpp:57-94) */
+int jtx_mi_any_hit_batch(jtx_mi_scene *scene, int32_t n, const float *o, const float *d, const float *tmin,
+                         const float *tmax, int32_t *hit);
+/* sampleBxdf / evalBxdf / pdfBxdf (bsdf/bxdf.cpp:9,79,130) for one material over n inputs */
+int jtx_mi_bxdf_sample_batch(jtx_mi_scene *scene, int32_t material, int32_t n, const float *normal, const float *uv,
+                             const float *wo, const float *uc, const float *u2,
+                             int32_t *ok, float *f, float *wi, float *pdf);
+int jtx_mi_bxdf_eval_batch(jtx_mi_scene *scene, int32_t material, int32_t n, const float *normal, const float *uv,
+                           const float *wo, const float *wi, float *f);
+int jtx_mi_bxdf_pdf_batch(jtx_mi_scene *scene, int32_t material, int32_t n, const float *normal, const float *uv,
+                          const float *wo, const float *wi, float *pdf);
+/* Camera::getRay (camera.hpp:127-139) seeded as camera.cpp:101 */
+int jtx_mi_camera_rays(const jtx_mi_camera_desc *cam, int32_t n, const int32_t *row, const int32_t *col,
+                       const int32_t *sample, float *o, float *d);
+/* integrateMIS (integrator.cpp:171-216) + the <=1 clamp (camera.cpp:110-112) per listed (row,col,sample) */
+int jtx_mi_radiance_samples(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, int32_t n, const int32_t *row,
+                            const int32_t *col, const int32_t *sample, float *rgb);
+/* RNG (util/rand.hpp:42-107) streams and the deterministic sin/cos, for known-answer tests */
+int jtx_mi_rng_stream(uint32_t x, uint32_t y, uint32_t n, int32_t count, uint32_t *out_u32, float *out_f32);
+int jtx_mi_sincos_batch(const float *x, int32_t n, float *out_sin, float *out_cos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JTX_MI_H */

@@ -1,0 +1,280 @@
+"""Python mirror of the reference's Scene / StaticCamera interface over the C-ABI (include/jtx_mi.h).
+
+Names and argument meaning follow the reference (src/scene.hpp:24-91, src/camera.hpp:20-188):
+`Scene.buildBVH / rebuildBVH / destroy / closestHit / anyHit / bounds / getSceneRadius`,
+`StaticCamera(width, height, cameraProperties, xPixelSamples, yPixelSamples, maxDepth)`,
+`StaticCamera.render(scene)`, members `img_`, `currentSample_`, `getSpp()`, `terminateRender()`.
+Everything that computes runs in the HIP library; nothing here falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import JtxMiError, check
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Scene:
+    """Scene (src/scene.hpp:24-91) backed by a device-resident jtx_mi_scene."""
+
+    def __init__(self, data):
+        self.data = data                    # scenes.SceneData
+        self.name = data.name
+        self._h = None
+        self._lib = capi.load()
+
+    # -- Scene::buildBVH(maxPrimsInNode) scene.cpp:96-135: host SAH build + device upload
+    def buildBVH(self, maxPrimsInNode=1):
+        if self._h is not None:
+            return
+        self.data.max_prims_in_node = maxPrimsInNode
+        desc = self.data.to_desc()
+        h = C.c_void_p()
+        check(self._lib.jtx_mi_scene_create(C.byref(desc), C.byref(h)))
+        self._h = h
+
+    def destroyBVH(self):
+        if self._h is not None:
+            self._lib.jtx_mi_scene_destroy(self._h)
+            self._h = None
+
+    def rebuildBVH(self, maxPrimsInNode=1):
+        self.destroyBVH()
+        self.buildBVH(maxPrimsInNode)
+
+    def destroy(self):
+        self.destroyBVH()
+
+    def __del__(self):
+        try:
+            self.destroyBVH()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise JtxMiError("Scene.buildBVH() has not been called")
+        return self._h
+
+    def info(self):
+        i = capi.SceneInfo()
+        check(self._lib.jtx_mi_scene_get_info(self.handle, C.byref(i)))
+        return dict(num_nodes=i.num_nodes, num_prims=i.num_prims, max_depth=i.max_depth,
+                    lds_resident=bool(i.lds_resident), scene_radius=float(i.scene_radius),
+                    device_bytes=int(i.device_bytes))
+
+    def bvh(self):
+        i = self.info()
+        nodes = (capi.BvhNode * max(1, i["num_nodes"]))()
+        refs = (capi.TriRef * max(1, i["num_prims"]))()
+        check(self._lib.jtx_mi_scene_get_bvh(self.handle, nodes, refs))
+        return nodes_to_numpy(nodes, i["num_nodes"]), refs_to_numpy(refs, i["num_prims"])
+
+    def bounds(self):
+        """AABB of the root node (scene.hpp:71-74)."""
+        n, _ = self.bvh()
+        return (n["pmin"][0], n["pmax"][0]) if len(n) else (None, None)
+
+    def getSceneRadius(self):
+        return self.info()["scene_radius"]
+
+    def numPrimitives(self):
+        return self.data.num_triangles
+
+    # -- Scene::closestHit scene.cpp:10-55, batched
+    def closestHit(self, o, d, tmin=0.001, tmax=float("inf")):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        out = dict(hit=np.zeros(n, np.int32), t=np.zeros(n, np.float32), prim=np.zeros(n, np.int32),
+                   b1=np.zeros(n, np.float32), b2=np.zeros(n, np.float32), point=np.zeros((n, 3), np.float32),
+                   normal=np.zeros((n, 3), np.float32), uv=np.zeros((n, 2), np.float32))
+        check(self._lib.jtx_mi_closest_hit_batch(self.handle, n, _fp(o), _fp(d), tmin, tmax, _ip(out["hit"]), _fp(out["t"]),
+                                                 _ip(out["prim"]), _fp(out["b1"]), _fp(out["b2"]), _fp(out["point"]),
+                                                 _fp(out["normal"]), _fp(out["uv"])))
+        return out
+
+    # -- Scene::anyHit scene.cpp:57-94, batched
+    def anyHit(self, o, d, tmin, tmax):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float32), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
+        hit = np.zeros(n, np.int32)
+        check(self._lib.jtx_mi_any_hit_batch(self.handle, n, _fp(o), _fp(d), _fp(tmin), _fp(tmax), _ip(hit)))
+        return hit
+
+    # -- sampleBxdf / evalBxdf / pdfBxdf bsdf/bxdf.cpp:9,79,130, batched per material
+    def sampleBxdf(self, material, normal, wo, uc, u2, uv=None):
+        normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        wo = np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        uc = np.ascontiguousarray(uc, np.float32).reshape(-1)
+        u2 = np.ascontiguousarray(u2, np.float32).reshape(-1, 2)
+        n = len(normal)
+        uvp = _fp(np.ascontiguousarray(uv, np.float32)) if uv is not None else None
+        ok = np.zeros(n, np.int32); f = np.zeros((n, 3), np.float32); wi = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32)
+        check(self._lib.jtx_mi_bxdf_sample_batch(self.handle, material, n, _fp(normal), uvp, _fp(wo), _fp(uc), _fp(u2),
+                                                 _ip(ok), _fp(f), _fp(wi), _fp(pdf)))
+        return dict(ok=ok, f=f, wi=wi, pdf=pdf)
+
+    def evalBxdf(self, material, normal, wo, wi, uv=None):
+        normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        wo = np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3)
+        n = len(normal)
+        uvp = _fp(np.ascontiguousarray(uv, np.float32)) if uv is not None else None
+        f = np.zeros((n, 3), np.float32)
+        check(self._lib.jtx_mi_bxdf_eval_batch(self.handle, material, n, _fp(normal), uvp, _fp(wo), _fp(wi), _fp(f)))
+        return f
+
+    def pdfBxdf(self, material, normal, wo, wi, uv=None):
+        normal = np.ascontiguousarray(normal, np.float32).reshape(-1, 3)
+        wo = np.ascontiguousarray(wo, np.float32).reshape(-1, 3)
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1, 3)
+        n = len(normal)
+        uvp = _fp(np.ascontiguousarray(uv, np.float32)) if uv is not None else None
+        pdf = np.zeros(n, np.float32)
+        check(self._lib.jtx_mi_bxdf_pdf_batch(self.handle, material, n, _fp(normal), uvp, _fp(wo), _fp(wi), _fp(pdf)))
+        return pdf
+
+
+NODE_DTYPE = np.dtype([("pmin", np.float32, 3), ("pmax", np.float32, 3), ("offset", np.int32),
+                       ("num_prims", np.uint16), ("axis", np.uint8), ("pad", np.uint8)])
+REF_DTYPE = np.dtype([("index", np.int32), ("mesh_index", np.int32)])
+
+
+def nodes_to_numpy(nodes, n):
+    return np.frombuffer(bytes(memoryview(nodes))[: n * 32], NODE_DTYPE).copy()
+
+
+def refs_to_numpy(refs, n):
+    return np.frombuffer(bytes(memoryview(refs))[: n * 8], REF_DTYPE).copy()
+
+
+def bvh_build_host(data):
+    """Host-only Scene::buildBVH through the C-ABI (needs no GPU)."""
+    lib = capi.load()
+    desc = data.to_desc()
+    n = max(1, data.num_triangles)
+    nodes = (capi.BvhNode * (2 * n + 1))()
+    refs = (capi.TriRef * n)()
+    nn, md = C.c_int32(), C.c_int32()
+    check(lib.jtx_mi_bvh_build(C.byref(desc), nodes, C.byref(nn), refs, C.byref(md)))
+    return nodes_to_numpy(nodes, nn.value), refs_to_numpy(refs, data.num_triangles), md.value
+
+
+class StaticCamera:
+    """StaticCamera (src/camera.hpp:179-188) -- one blocking render per call."""
+
+    def __init__(self, width, height, cameraProperties, xPixelSamples, yPixelSamples, maxDepth, threadCount=0):
+        self.width_, self.height_ = int(width), int(height)
+        self.properties_ = dict(cameraProperties)
+        self.xPixelSamples_, self.yPixelSamples_ = int(xPixelSamples), int(yPixelSamples)
+        self.maxDepth_ = int(maxDepth)
+        self.samplesPerPass_ = 1
+        self.currentSample_ = 0
+        self.img_ = np.zeros((self.height_, self.width_, 3), np.uint8)      # RGB8Image, row 0 = bottom
+        self.acc_ = np.zeros((self.height_, self.width_, 3), np.float32)    # AccumulationBuffer
+        self.stopRender_ = False
+        self.counters = None
+        self._lib = capi.load()
+
+    def getSpp(self):
+        return self.xPixelSamples_ * self.yPixelSamples_
+
+    def terminateRender(self):
+        self.stopRender_ = True
+
+    def resize(self, w, h):
+        self.width_, self.height_ = int(w), int(h)
+        self.img_ = np.zeros((h, w, 3), np.uint8)
+        self.acc_ = np.zeros((h, w, 3), np.float32)
+
+    def clear(self):
+        self.img_[...] = 0
+
+    def desc(self):
+        c = capi.CameraDesc()
+        p = self.properties_
+        c.center = capi.c_float3(*p["center"]); c.target = capi.c_float3(*p["target"]); c.up = capi.c_float3(*p["up"])
+        c.yfov, c.defocus_angle, c.focus_distance = p["yfov"], p["defocus_angle"], p["focus_distance"]
+        c.width, c.height = self.width_, self.height_
+        c.x_pixel_samples, c.y_pixel_samples, c.max_depth = self.xPixelSamples_, self.yPixelSamples_, self.maxDepth_
+        return c
+
+    def render(self, scene, count_rays=False, progress=None, tile_rank=0, tile_world=1, sample_begin=0, sample_end=0):
+        """StaticCamera::render(const Scene&) (camera.cpp:45-128)."""
+        self.stopRender_ = False
+        self.currentSample_ = 0
+        o = capi.RenderOpts()
+        o.count_rays = 1 if count_rays else 0
+        o.tile_rank, o.tile_world = tile_rank, tile_world
+        o.sample_begin, o.sample_end = sample_begin, sample_end
+        o.samples_per_tick = self.samplesPerPass_ if progress is not None else 0
+
+        def _cb(cur, total, _user):
+            self.currentSample_ = cur
+            if progress is not None:
+                progress(cur, total)
+            return 1 if self.stopRender_ else 0
+
+        cb = capi.PROGRESS_CB(_cb)
+        cam = self.desc()
+        check(self._lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), _fp(self.acc_),
+                                      self.img_.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None))
+        if progress is None:
+            self.currentSample_ = sample_end if sample_end > 0 else self.getSpp()
+        if count_rays:
+            c = capi.Counters()
+            check(self._lib.jtx_mi_get_counters(scene.handle, C.byref(c)))
+            self.counters = c.as_dict()
+        return self.img_
+
+    def save(self, path):
+        """RGB8Image::save flips rows (image.cpp:14-22); writes a binary PPM (no PNG encoder here)."""
+        with open(path, "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (self.width_, self.height_))
+            f.write(self.img_[::-1].tobytes())
+
+
+def camera_rays(cam_desc, row, col, sample):
+    lib = capi.load()
+    row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32); sample = np.ascontiguousarray(sample, np.int32)
+    n = len(row)
+    o = np.zeros((n, 3), np.float32); d = np.zeros((n, 3), np.float32)
+    check(lib.jtx_mi_camera_rays(C.byref(cam_desc), n, _ip(row), _ip(col), _ip(sample), _fp(o), _fp(d)))
+    return o, d
+
+
+def radiance_samples(scene, cam_desc, row, col, sample):
+    lib = capi.load()
+    row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32); sample = np.ascontiguousarray(sample, np.int32)
+    n = len(row)
+    rgb = np.zeros((n, 3), np.float32)
+    check(lib.jtx_mi_radiance_samples(scene.handle, C.byref(cam_desc), n, _ip(row), _ip(col), _ip(sample), _fp(rgb)))
+    return rgb
+
+
+def rng_stream(x, y, n, count):
+    lib = capi.load()
+    u = np.zeros(count, np.uint32); f = np.zeros(count, np.float32)
+    check(lib.jtx_mi_rng_stream(x, y, n, count, u.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(f)))
+    return u, f
+
+
+def sincos(x):
+    lib = capi.load()
+    x = np.ascontiguousarray(x, np.float32)
+    s = np.zeros_like(x); c = np.zeros_like(x)
+    check(lib.jtx_mi_sincos_batch(_fp(x), len(x), _fp(s), _fp(c)))
+    return s, c

@@ -1,0 +1,171 @@
+// jtx_bvh_build.cpp -- host-side BVH construction for the MI355X core.
+//
+// Produces exactly the tree Scene::buildBVH builds in the reference (scene.cpp:96-135): recursive
+// binned SAH with 12 buckets (bvh.cpp:9-133), cost 0.5 + sum(count*SA)/SA(parent), mid split by
+// nth_element for two primitives, degenerate centroid bounds -> leaf, and the depth-first
+// LinearBVHNode order of flattenBVH (bvh.cpp:135-149) with the first child implicit at i+1.
+// Unlike the reference it never materialises a pointer tree: buildTree's recursion order IS the
+// flattened (pre-order) order and an interior box equals the bounds of its primitives (min/max are
+// exact), so nodes are emitted straight into the linear array.
+#include "jtx_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace jtxh {
+
+namespace {
+
+struct Bounds {
+    float lo[3], hi[3];
+    Bounds() {                                                   // AABB() aabb.hpp:11-16
+        for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<float>::max(); hi[i] = std::numeric_limits<float>::lowest(); }
+    }
+    void grow(const float p[3]) { for (int i = 0; i < 3; ++i) { lo[i] = p[i] < lo[i] ? p[i] : lo[i]; hi[i] = p[i] > hi[i] ? p[i] : hi[i]; } }
+    void grow(const Bounds &b) { for (int i = 0; i < 3; ++i) { lo[i] = b.lo[i] < lo[i] ? b.lo[i] : lo[i]; hi[i] = b.hi[i] > hi[i] ? b.hi[i] : hi[i]; } }
+    float area() const {                                         // aabb.hpp:87-90
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2 * (dx * dy + dx * dz + dy * dz);
+    }
+    int longestAxis() const {                                    // aabb.hpp:51-56
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx > dy && dx > dz) return 0;
+        if (dy > dz) return 1;
+        return 2;
+    }
+    float offset(const float p[3], int a) const {                // aabb.hpp:58-64
+        float o = p[a] - lo[a];
+        if (hi[a] > lo[a]) o /= hi[a] - lo[a];
+        return o;
+    }
+};
+
+struct Prim {
+    int index, mesh;
+    Bounds b;
+    float centroid(int a) const { return 0.5f * b.lo[a] + 0.5f * b.hi[a]; }   // mesh.hpp:207-209
+};
+
+constexpr int kBuckets = 12;
+
+struct Builder {
+    std::vector<jtx_mi_bvh_node> &nodes;
+    std::vector<Prim> &ordered;
+    int orderedCount = 0;
+    int maxPrims;
+    int maxDepth = 0;
+
+    int emitLeaf(int slot, Prim *p, size_t n, const Bounds &bounds) {
+        jtx_mi_bvh_node &ln = nodes[slot];
+        ln.offset = orderedCount;
+        ln.num_prims = (uint16_t) n;
+        if (n > 65535) throw std::runtime_error("BVH leaf with more than 65535 primitives (uint16 numPrimitives, bvh.hpp:13)");
+        for (size_t i = 0; i < n; ++i) ordered[orderedCount + i] = p[i];
+        orderedCount += (int) n;
+        (void) bounds;
+        return slot;
+    }
+
+    int bucketOf(const Bounds &cb, const Prim &q, int dim) const {
+        float c[3] = {q.centroid(0), q.centroid(1), q.centroid(2)};
+        int b = (int) (kBuckets * cb.offset(c, dim));
+        if (b == kBuckets) b = kBuckets - 1;
+        return b;
+    }
+
+    int build(Prim *p, size_t n, int depth) {
+        const int slot = (int) nodes.size();
+        nodes.push_back(jtx_mi_bvh_node{});
+        if (depth > maxDepth) maxDepth = depth;
+
+        Bounds bounds;
+        for (size_t i = 0; i < n; ++i) bounds.grow(p[i].b);
+        for (int a = 0; a < 3; ++a) { nodes[slot].pmin[a] = bounds.lo[a]; nodes[slot].pmax[a] = bounds.hi[a]; }
+
+        if (bounds.area() == 0 || n == 1) return emitLeaf(slot, p, n, bounds);          // bvh.cpp:18-28
+
+        Bounds cb;
+        for (size_t i = 0; i < n; ++i) { float c[3] = {p[i].centroid(0), p[i].centroid(1), p[i].centroid(2)}; cb.grow(c); }
+        const int dim = cb.longestAxis();
+        if (cb.lo[dim] == cb.hi[dim]) return emitLeaf(slot, p, n, bounds);              // bvh.cpp:36-46
+
+        size_t mid = n / 2;
+        if (n == 2) {                                                                   // bvh.cpp:50-57
+            std::nth_element(p, p + mid, p + n, [dim](const Prim &a, const Prim &b) { return a.centroid(dim) < b.centroid(dim); });
+        } else {
+            int count[kBuckets] = {};
+            Bounds bb[kBuckets];
+            for (size_t i = 0; i < n; ++i) { const int b = bucketOf(cb, p[i], dim); count[b]++; bb[b].grow(p[i].b); }
+            float cost[kBuckets - 1] = {};
+            { int below = 0; Bounds acc;                                                // bvh.cpp:74-81
+              for (int i = 0; i < kBuckets - 1; ++i) { below += count[i]; acc.grow(bb[i]); cost[i] += below * acc.area(); } }
+            { int above = 0; Bounds acc;                                                // bvh.cpp:84-90
+              for (int i = kBuckets - 1; i > 0; --i) { above += count[i]; acc.grow(bb[i]); cost[i - 1] += above * acc.area(); } }
+            int best = -1; float bestCost = std::numeric_limits<float>::infinity();
+            for (int i = 0; i < kBuckets - 1; ++i) if (cost[i] < bestCost) { bestCost = cost[i]; best = i; }
+            const float leafCost = (float) n;
+            bestCost = 0.5f + bestCost / bounds.area();
+            if ((int) n > maxPrims || bestCost < leafCost) {                            // bvh.cpp:105-112
+                Prim *m = std::partition(p, p + n, [&](const Prim &q) { return bucketOf(cb, q, dim) <= best; });
+                mid = (size_t) (m - p);
+            } else {
+                return emitLeaf(slot, p, n, bounds);
+            }
+        }
+        nodes[slot].axis = (uint8_t) dim;
+        nodes[slot].num_prims = 0;
+        build(p, mid, depth + 1);                                   // first child lands at slot + 1
+        const int second = build(p + mid, n - mid, depth + 1);
+        nodes[slot].offset = second;                                // secondChildOffset (bvh.cpp:146)
+        return slot;
+    }
+};
+
+inline void xformPoint(const float m[16], const float *v, float out[3]) {   // Transform::applyToPoint (DESIGN.md math spec)
+    for (int r = 0; r < 3; ++r) out[r] = m[4 * r + 0] * v[0] + m[4 * r + 1] * v[1] + m[4 * r + 2] * v[2] + m[4 * r + 3];
+}
+
+} // namespace
+
+void meshVertices(const jtx_mi_mesh &m, int tri, float v0[3], float v1[3], float v2[3]) {   // Mesh::getVertices mesh.hpp:71-77
+    const int32_t *i = m.indices + 3 * (size_t) tri;
+    xformPoint(m.transform, m.vertices + 3 * (size_t) i[0], v0);
+    xformPoint(m.transform, m.vertices + 3 * (size_t) i[1], v1);
+    xformPoint(m.transform, m.vertices + 3 * (size_t) i[2], v2);
+}
+
+void buildBVH(const jtx_mi_scene_desc &d, BvhResult &out) {
+    const size_t n = (size_t) d.num_tri_refs;
+    std::vector<Prim> work(n), ordered(n);
+    for (size_t i = 0; i < n; ++i) {
+        const jtx_mi_tri_ref &r = d.tri_refs[i];
+        if (r.mesh_index < 0 || r.mesh_index >= d.num_meshes) throw std::runtime_error("tri_ref.mesh_index out of range");
+        const jtx_mi_mesh &m = d.meshes[r.mesh_index];
+        if (r.index < 0 || r.index >= m.num_triangles) throw std::runtime_error("tri_ref.index out of range");
+        for (int k = 0; k < 3; ++k) {
+            const int32_t vi = m.indices[3 * (size_t) r.index + k];
+            if (vi < 0 || vi >= m.num_vertices) throw std::runtime_error("mesh index out of range");
+        }
+        float v0[3], v1[3], v2[3];
+        meshVertices(m, r.index, v0, v1, v2);
+        work[i].index = r.index; work[i].mesh = r.mesh_index;
+        work[i].b = Bounds(); work[i].b.grow(v0); work[i].b.grow(v1); work[i].b.grow(v2);   // tBounds mesh.hpp:79-84
+    }
+    out.nodes.clear();
+    out.nodes.reserve(2 * n + 1);
+    Builder b{out.nodes, ordered};
+    b.maxPrims = d.max_prims_in_node > 0 ? d.max_prims_in_node : 1;
+    if (n) b.build(work.data(), n, 0);
+    out.max_depth = b.maxDepth;
+    out.refs.resize(n);
+    for (size_t i = 0; i < n; ++i) out.refs[i] = jtx_mi_tri_ref{ordered[i].index, ordered[i].mesh};
+    out.scene_radius = 0;
+    if (!out.nodes.empty()) {                                        // getSceneRadius scene.hpp:81-84
+        const jtx_mi_bvh_node &r = out.nodes[0];
+        const float dx = r.pmax[0] - r.pmin[0], dy = r.pmax[1] - r.pmin[1], dz = r.pmax[2] - r.pmin[2];
+        out.scene_radius = std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
+    }
+}
+
+} // namespace jtxh

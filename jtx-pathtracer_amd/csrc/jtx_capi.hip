@@ -1,0 +1,572 @@
+// jtx_capi.hip -- implementation of the C-ABI declared in include/jtx_mi.h.
+//
+// Host responsibilities (all that is left of Scene / StaticCamera on the CPU): build the BVH, bake
+// mesh transforms, lay the scene out for the kernels, derive the camera basis (Camera::init,
+// camera.cpp:7-31), launch, and move the film.  There is deliberately no CPU rendering path.
+#include "jtx_host.hpp"
+#include "jtx_launch.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+using namespace jtx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg) { g_err = msg; return 1; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    void alloc(size_t count) { release(); n = count; if (count) HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); }
+    void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
+    ~DevBuf() { release(); }
+};
+
+constexpr size_t kLdsSceneBudget = 40 * 1024;   // nodes+tris staged in LDS when they fit this
+
+} // namespace
+
+struct jtx_mi_scene {
+    jtxh::BvhResult bvh;
+    DevBuf<float4> nodes, tris, shade;
+    DevBuf<DMaterial> materials;
+    DevBuf<DLight> lights;
+    DevBuf<DTexture> textures;
+    DevBuf<float> texels;
+    DevBuf<unsigned long long> counters;
+    DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
+    DevBuf<unsigned char> film_img;
+    DevScene dev{};
+    hipStream_t stream = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;
+    size_t device_bytes = 0;
+    int device = 0;
+    std::mutex mu;
+
+    ~jtx_mi_scene() {
+        for (auto &e : pending) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+        for (auto &e : free_events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+        if (stream) (void) hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+inline void xformNormal(const float m[16], const float *v, float out[3]) {     // Transform::applyToNormal: upper 3x3
+    for (int r = 0; r < 3; ++r) out[r] = m[4 * r + 0] * v[0] + m[4 * r + 1] * v[1] + m[4 * r + 2] * v[2];
+}
+
+inline float srgbToLinear(float v) {                                            // color.hpp:13-23
+    return v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
+}
+
+void validate(const jtx_mi_scene_desc &d) {
+    if (d.num_meshes < 0 || d.num_tri_refs < 0 || d.num_materials < 0 || d.num_lights < 0 || d.num_textures < 0)
+        throw std::runtime_error("negative count in scene description");
+    for (int i = 0; i < d.num_meshes; ++i) {
+        const jtx_mi_mesh &m = d.meshes[i];
+        if (!m.indices || !m.vertices || !m.normals) throw std::runtime_error("mesh with null indices/vertices/normals");
+        if (m.material < 0 || m.material >= d.num_materials) throw std::runtime_error("mesh.material out of range");
+    }
+    for (int i = 0; i < d.num_materials; ++i) {
+        const jtx_mi_material &m = d.materials[i];
+        if (m.type < 0 || m.type > 3) throw std::runtime_error("material.type out of range");
+        if (m.albedo_tex < -1 || m.albedo_tex >= d.num_textures || m.mr_tex < -1 || m.mr_tex >= d.num_textures)
+            throw std::runtime_error("material texture id out of range (-1 = none)");
+    }
+    for (int i = 0; i < d.num_textures; ++i) {
+        const jtx_mi_texture &t = d.textures[i];
+        if (t.width <= 0 || t.height <= 0 || t.channels < 3 || !t.texels) throw std::runtime_error("texture needs w,h > 0, >= 3 channels and texels");
+    }
+    for (int i = 0; i < d.num_lights; ++i)
+        if (d.lights[i].type < 0 || d.lights[i].type > 1) throw std::runtime_error("light.type out of range");
+}
+
+// Flatten the scene into the kernel layout documented in jtx_scene_dev.hpp.
+void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
+    const jtxh::BvhResult &b = s.bvh;
+    const size_t nn = b.nodes.size(), np = b.refs.size();
+    std::vector<float4> nodes(2 * nn), tris(3 * np), shade(4 * np);
+    for (size_t i = 0; i < nn; ++i) {
+        const jtx_mi_bvh_node &n = b.nodes[i];
+        const int meta = (int) n.num_prims | ((int) n.axis << 16);
+        float fo, fm;
+        std::memcpy(&fo, &n.offset, 4); std::memcpy(&fm, &meta, 4);
+        nodes[2 * i + 0] = make_float4(n.pmin[0], n.pmin[1], n.pmin[2], n.pmax[0]);
+        nodes[2 * i + 1] = make_float4(n.pmax[1], n.pmax[2], fo, fm);
+    }
+    for (size_t i = 0; i < np; ++i) {
+        const jtx_mi_mesh &m = d.meshes[b.refs[i].mesh_index];
+        const int tri = b.refs[i].index;
+        float v0[3], v1[3], v2[3];
+        jtxh::meshVertices(m, tri, v0, v1, v2);
+        const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};      // v0v1, mesh.hpp:109
+        const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};      // v0v2, mesh.hpp:110
+        tris[3 * i + 0] = make_float4(v0[0], v0[1], v0[2], e1[0]);
+        tris[3 * i + 1] = make_float4(e1[1], e1[2], e2[0], e2[1]);
+        tris[3 * i + 2] = make_float4(e2[2], 0.f, 0.f, 0.f);
+        const int32_t *ix = m.indices + 3 * (size_t) tri;
+        float n0[3], n1[3], n2[3];
+        xformNormal(m.transform, m.normals + 3 * (size_t) ix[0], n0);           // getNormals mesh.hpp:92-97
+        xformNormal(m.transform, m.normals + 3 * (size_t) ix[1], n1);
+        xformNormal(m.transform, m.normals + 3 * (size_t) ix[2], n2);
+        float uv[6] = {0, 0, 0, 0, 0, 0};                                       // no uvs => (0,0) (Q3)
+        if (m.uvs) for (int k = 0; k < 3; ++k) { uv[2 * k] = m.uvs[2 * (size_t) ix[k]]; uv[2 * k + 1] = m.uvs[2 * (size_t) ix[k] + 1]; }
+        float fmat; const int mat = m.material; std::memcpy(&fmat, &mat, 4);
+        shade[4 * i + 0] = make_float4(n0[0], n0[1], n0[2], n1[0]);
+        shade[4 * i + 1] = make_float4(n1[1], n1[2], n2[0], n2[1]);
+        shade[4 * i + 2] = make_float4(n2[2], uv[0], uv[1], uv[2]);
+        shade[4 * i + 3] = make_float4(uv[3], uv[4], uv[5], fmat);
+    }
+    s.nodes.upload(nodes); s.tris.upload(tris); s.shade.upload(shade);
+
+    std::vector<DMaterial> mats(d.num_materials);
+    std::vector<char> usedAsAlbedo(d.num_textures, 0);
+    for (int i = 0; i < d.num_materials; ++i) {
+        const jtx_mi_material &m = d.materials[i];
+        DMaterial &o = mats[i];
+        std::memset(&o, 0, sizeof o);
+        o.type = m.type;
+        for (int k = 0; k < 3; ++k) { o.albedo[k] = m.albedo[k]; o.ior[k] = m.ior[k]; o.k[k] = m.k[k]; }
+        o.alpha_x = m.alpha_x; o.alpha_y = m.alpha_y;
+        o.albedo_tex = m.albedo_tex; o.mr_tex = m.mr_tex;
+        if (m.albedo_tex >= 0) usedAsAlbedo[m.albedo_tex] = 1;
+    }
+    s.materials.upload(mats);
+
+    std::vector<DLight> lights(d.num_lights);
+    for (int i = 0; i < d.num_lights; ++i) {
+        const jtx_mi_light &l = d.lights[i];
+        DLight &o = lights[i];
+        std::memset(&o, 0, sizeof o);
+        o.type = l.type; o.scale = l.scale;
+        for (int k = 0; k < 3; ++k) { o.position[k] = l.position[k]; o.intensity[k] = l.intensity[k]; }
+        o.scene_radius = l.type == 1 ? b.scene_radius : l.scene_radius;         // scene.cpp:128-134
+    }
+    s.lights.upload(lights);
+
+    std::vector<DTexture> tex(d.num_textures);
+    std::vector<float> texels;
+    for (int i = 0; i < d.num_textures; ++i) {
+        const jtx_mi_texture &t = d.textures[i];
+        const size_t count = (size_t) t.width * t.height * t.channels;
+        tex[i].w = t.width; tex[i].h = t.height; tex[i].c = t.channels; tex[i].pad = 0;
+        tex[i].raw_off = (long long) texels.size();
+        texels.insert(texels.end(), t.texels, t.texels + count);
+        tex[i].linear_off = tex[i].raw_off;
+        if (usedAsAlbedo[i]) {
+            tex[i].linear_off = (long long) texels.size();
+            for (size_t k = 0; k < count; ++k) texels.push_back(srgbToLinear(t.texels[k]));
+        }
+    }
+    s.textures.upload(tex); s.texels.upload(texels);
+
+    DevScene &ds = s.dev;
+    ds.nodes = s.nodes.p; ds.tris = s.tris.p; ds.shade = s.shade.p;
+    ds.materials = s.materials.p; ds.lights = s.lights.p; ds.textures = s.textures.p; ds.texels = s.texels.p;
+    ds.num_nodes = (int) nn; ds.num_prims = (int) np; ds.num_lights = d.num_lights; ds.num_materials = d.num_materials;
+    ds.stack_depth = b.max_depth > 0 ? b.max_depth : 1;
+    ds.lds_scene = (nn > 0 && nn * 32 + np * 48 <= kLdsSceneBudget) ? 1 : 0;
+    for (int k = 0; k < 3; ++k) ds.sky[k] = d.sky_color[k];
+    s.device_bytes = (nodes.size() + tris.size() + shade.size()) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
+                     lights.size() * sizeof(DLight) + tex.size() * sizeof(DTexture) + texels.size() * sizeof(float);
+}
+
+// Camera::init (camera.cpp:7-31)
+DCam deriveCamera(const jtx_mi_camera_desc &c) {
+    auto sub = [](const float a[3], const float b[3], float o[3]) { for (int i = 0; i < 3; ++i) o[i] = a[i] - b[i]; };
+    auto cross = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+    auto norm = [](float v[3]) { const float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); for (int i = 0; i < 3; ++i) v[i] = v[i] / l; };
+    const float PI = 3.14159265358979323846f;
+    DCam k{};
+    const float aspect = (float) c.width / (float) c.height;
+    const float h = std::tan((c.yfov * PI / 180.0f) / 2);
+    const float vh = 2 * h * c.focus_distance;
+    const float vw = vh * aspect;
+    float w[3], u[3], v[3];
+    sub(c.center, c.target, w); norm(w);
+    cross(c.up, w, u); norm(u);
+    cross(w, u, v);
+    float vu[3], vv[3];
+    for (int i = 0; i < 3; ++i) { vu[i] = vw * u[i]; vv[i] = vh * v[i]; }
+    for (int i = 0; i < 3; ++i) { k.du[i] = vu[i] / (float) c.width; k.dv[i] = vv[i] / (float) c.height; }
+    for (int i = 0; i < 3; ++i) {
+        const float ul = c.center[i] - (c.focus_distance * w[i]) - vu[i] / 2 - vv[i] / 2;
+        k.vp00[i] = ul + 0.5f * (k.du[i] + k.dv[i]);
+    }
+    const float dr = c.focus_distance * std::tan((c.defocus_angle / 2) * PI / 180.0f);
+    for (int i = 0; i < 3; ++i) { k.defocus_u[i] = dr * u[i]; k.defocus_v[i] = dr * v[i]; k.center[i] = c.center[i]; }
+    k.defocus_angle = c.defocus_angle;
+    k.xs = c.x_pixel_samples; k.ys = c.y_pixel_samples;
+    return k;
+}
+
+void checkCamera(const jtx_mi_camera_desc &c) {
+    if (c.width <= 0 || c.height <= 0) throw std::runtime_error("camera width/height must be > 0");
+    if (c.x_pixel_samples <= 0 || c.y_pixel_samples <= 0) throw std::runtime_error("camera pixel samples must be > 0");
+    if (c.max_depth < 0) throw std::runtime_error("camera max_depth must be >= 0");
+}
+
+std::pair<hipEvent_t, hipEvent_t> takeEvents(jtx_mi_scene &s) {
+    if (!s.free_events.empty()) { auto e = s.free_events.back(); s.free_events.pop_back(); return e; }
+    std::pair<hipEvent_t, hipEvent_t> e;
+    HIPCHK(hipEventCreate(&e.first)); HIPCHK(hipEventCreate(&e.second));
+    return e;
+}
+
+// One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
+void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
+                  float *d_acc, unsigned char *d_img, hipStream_t stream) {
+    RenderParams p{};
+    p.scene = s.dev;
+    p.cam = deriveCamera(cam);
+    p.width = cam.width; p.height = cam.height; p.max_depth = cam.max_depth;
+    p.sample_begin = sb; p.sample_end = se;
+    const int world = o.tile_world > 1 ? o.tile_world : 1;
+    const int rank = o.tile_world > 1 ? o.tile_rank : 0;
+    if (rank < 0 || rank >= world) throw std::runtime_error("tile_rank must be in [0, tile_world)");
+    p.tile_rank = rank; p.tile_world = world;
+    p.tiles_x = (cam.width + 31) / 32;
+    const int tiles = p.tiles_x * ((cam.height + 31) / 32);
+    const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
+    p.acc = d_acc; p.img = d_img;
+    const bool count = o.count_rays != 0;
+    if (count) {
+        if (!s.counters.p) s.counters.alloc(9);
+        if (sb == 0 || true) HIPCHK(hipMemsetAsync(s.counters.p, 0, 9 * sizeof(unsigned long long), stream));
+    }
+    p.counters = s.counters.p;
+    if (o.integrator != 0 && o.integrator != 1) throw std::runtime_error("integrator: 0 (auto) or 1 (pixel-persistent) are available");
+    auto ev = takeEvents(s);
+    HIPCHK(hipEventRecord(ev.first, stream));
+    HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
+    HIPCHK(hipEventRecord(ev.second, stream));
+    s.pending.push_back(ev);
+}
+
+} // namespace
+
+extern "C" {
+
+const char *jtx_mi_last_error(void) { return g_err.c_str(); }
+int jtx_mi_version(void) { return JTX_MI_VERSION; }
+
+int jtx_mi_device_count(int32_t *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n; return 0;
+}
+int jtx_mi_set_device(int32_t device) {
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int jtx_mi_bvh_build(const jtx_mi_scene_desc *desc, jtx_mi_bvh_node *nodes_out, int32_t *num_nodes_out,
+                     jtx_mi_tri_ref *refs_out, int32_t *max_depth_out) {
+    try {
+        if (!desc) throw std::runtime_error("null scene description");
+        validate(*desc);
+        jtxh::BvhResult r;
+        jtxh::buildBVH(*desc, r);
+        if (nodes_out) std::memcpy(nodes_out, r.nodes.data(), r.nodes.size() * sizeof(jtx_mi_bvh_node));
+        if (refs_out) std::memcpy(refs_out, r.refs.data(), r.refs.size() * sizeof(jtx_mi_tri_ref));
+        if (num_nodes_out) *num_nodes_out = (int32_t) r.nodes.size();
+        if (max_depth_out) *max_depth_out = r.max_depth;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
+    jtx_mi_scene *s = nullptr;
+    try {
+        if (!desc || !out) throw std::runtime_error("null argument");
+        *out = nullptr;
+        validate(*desc);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            throw std::runtime_error("no HIP device: the jtx_mi core has no CPU fallback");
+        s = new jtx_mi_scene();
+        HIPCHK(hipGetDevice(&s->device));
+        jtxh::buildBVH(*desc, s->bvh);
+        if (s->bvh.max_depth > 120) throw std::runtime_error("BVH deeper than 120 levels: LDS traversal stack would not fit");
+        flatten(*desc, *s);
+        HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        *out = s;
+        return 0;
+    } catch (const std::exception &e) { delete s; return fail(e.what()); }
+}
+
+void jtx_mi_scene_destroy(jtx_mi_scene *scene) {
+    if (!scene) return;
+    if (scene->stream) (void) hipStreamSynchronize(scene->stream);
+    delete scene;
+}
+
+int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
+    if (!s || !out) return fail("null argument");
+    out->num_nodes = s->dev.num_nodes; out->num_prims = s->dev.num_prims; out->max_depth = s->bvh.max_depth;
+    out->lds_resident = s->dev.lds_scene; out->scene_radius = s->bvh.scene_radius; out->device_bytes = s->device_bytes;
+    return 0;
+}
+int jtx_mi_scene_get_bvh(const jtx_mi_scene *s, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out) {
+    if (!s) return fail("null scene");
+    if (nodes_out) std::memcpy(nodes_out, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(jtx_mi_bvh_node));
+    if (refs_out) std::memcpy(refs_out, s->bvh.refs.data(), s->bvh.refs.size() * sizeof(jtx_mi_tri_ref));
+    return 0;
+}
+
+int jtx_mi_render_device(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
+                         void *d_acc_rgb, void *d_img_rgb, void *stream) {
+    try {
+        if (!s || !cam || !d_acc_rgb) throw std::runtime_error("null argument");
+        checkCamera(*cam);
+        jtx_mi_render_opts o{}; if (opts) o = *opts;
+        const int spp = cam->x_pixel_samples * cam->y_pixel_samples;
+        const int sb = o.sample_begin > 0 ? o.sample_begin : 0;
+        const int se = (o.sample_end > 0 && o.sample_end < spp) ? o.sample_end : spp;
+        if (sb >= se) throw std::runtime_error("empty sample range");
+        std::lock_guard<std::mutex> lk(s->mu);
+        hipStream_t st = stream ? (hipStream_t) stream : s->stream;
+        if (sb == 0 && (o.tile_world > 1))      // non-owned pixels must read as exactly 0 for the reduce
+            HIPCHK(hipMemsetAsync(d_acc_rgb, 0, sizeof(float) * 3 * (size_t) cam->width * cam->height, st));
+        launchRender(*s, *cam, o, sb, se, (float *) d_acc_rgb, (unsigned char *) d_img_rgb, st);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_sync(jtx_mi_scene *s) {
+    if (!s) return fail("null scene");
+    hipError_t e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(std::string("sync: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int jtx_mi_kernel_time(jtx_mi_scene *s, float *ms_total, int32_t *launches) {
+    try {
+        if (!s) throw std::runtime_error("null scene");
+        std::lock_guard<std::mutex> lk(s->mu);
+        float total = 0; int n = 0;
+        for (auto &e : s->pending) {
+            HIPCHK(hipEventSynchronize(e.second));
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+            total += ms; ++n;
+            s->free_events.push_back(e);
+        }
+        s->pending.clear();
+        if (ms_total) *ms_total = total;
+        if (launches) *launches = n;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
+    try {
+        if (!s || !out) throw std::runtime_error("null argument");
+        if (!s->counters.p) throw std::runtime_error("no counted render has run (opts.count_rays)");
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipDeviceSynchronize());
+        unsigned long long h[9];
+        HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
+        out->n_camera = h[0]; out->n_closest = h[1]; out->n_any = h[2]; out->n_nodes_closest = h[3]; out->n_tri_closest = h[4];
+        out->n_accept = h[5]; out->n_nodes_any = h[6]; out->n_tri_any = h[7]; out->n_shade = h[8];
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
+                  float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user) {
+    try {
+        if (!s || !cam || !acc_rgb) throw std::runtime_error("null argument");
+        checkCamera(*cam);
+        jtx_mi_render_opts o{}; if (opts) o = *opts;
+        const int spp = cam->x_pixel_samples * cam->y_pixel_samples;
+        const int sb = o.sample_begin > 0 ? o.sample_begin : 0;
+        const int se = (o.sample_end > 0 && o.sample_end < spp) ? o.sample_end : spp;
+        if (sb >= se) throw std::runtime_error("empty sample range");
+        const size_t npix = (size_t) cam->width * cam->height;
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (s->film_acc.n != 3 * npix) { s->film_acc.alloc(3 * npix); s->film_img.alloc(3 * npix); }
+        if (sb == 0) HIPCHK(hipMemsetAsync(s->film_acc.p, 0, sizeof(float) * 3 * npix, s->stream));
+        else HIPCHK(hipMemcpyAsync(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(s->film_img.p, 0, 3 * npix, s->stream));
+        const int tick = (cb && o.samples_per_tick > 0) ? o.samples_per_tick : (se - sb);
+        jtx_mi_counters total{}; const bool count = o.count_rays != 0;
+        for (int b = sb; b < se; b += tick) {
+            const int e = b + tick < se ? b + tick : se;
+            launchRender(*s, *cam, o, b, e, s->film_acc.p, img_rgb ? s->film_img.p : nullptr, s->stream);
+            HIPCHK(hipMemcpyAsync(acc_rgb, s->film_acc.p, sizeof(float) * 3 * npix, hipMemcpyDeviceToHost, s->stream));
+            if (img_rgb) HIPCHK(hipMemcpyAsync(img_rgb, s->film_img.p, 3 * npix, hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+            if (count) {
+                unsigned long long h[9];
+                HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
+                total.n_camera += h[0]; total.n_closest += h[1]; total.n_any += h[2]; total.n_nodes_closest += h[3];
+                total.n_tri_closest += h[4]; total.n_accept += h[5]; total.n_nodes_any += h[6]; total.n_tri_any += h[7];
+                total.n_shade += h[8];
+            }
+            if (cb) {
+                lk.unlock();
+                const int stop = cb(e, spp, user);                      // currentSample_ advance, camera.cpp:68-74
+                lk.lock();
+                if (stop) break;
+            }
+        }
+        if (count) {   // leave the frame totals on the device for jtx_mi_get_counters
+            unsigned long long h[9] = {total.n_camera, total.n_closest, total.n_any, total.n_nodes_closest, total.n_tri_closest,
+                                       total.n_accept, total.n_nodes_any, total.n_tri_any, total.n_shade};
+            HIPCHK(hipMemcpy(s->counters.p, h, sizeof h, hipMemcpyHostToDevice));
+        }
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+} // extern "C"
+
+// ---- fine-grained parity entry points: host buffers in, host buffers out ----
+namespace {
+template <class T> struct Tmp {
+    T *p = nullptr; size_t n = 0;
+    Tmp(size_t count) : n(count) { if (count) HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); }
+    Tmp(const T *h, size_t count) : n(count) {
+        if (count) { HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); HIPCHK(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice)); }
+    }
+    void down(T *h) { if (h && n) HIPCHK(hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost)); }
+    ~Tmp() { if (p) (void) hipFree(p); }
+};
+}
+
+
+extern "C" {
+
+int jtx_mi_closest_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const float *d, float tmin, float tmax,
+                             int32_t *hit, float *t, int32_t *prim, float *b1, float *b2, float *point, float *normal,
+                             float *uv) {
+    try {
+        if (!s || n < 0 || (n && (!o || !d))) throw std::runtime_error("bad argument");
+        if (n == 0) return 0;
+        Tmp<float> dO(o, 3 * (size_t) n), dD(d, 3 * (size_t) n), dT(n), dB1(n), dB2(n), dP(3 * (size_t) n), dN(3 * (size_t) n), dUV(2 * (size_t) n);
+        Tmp<int> dHit(n), dPrim(n);
+        HIPCHK(jtx_launch_closest_batch(s->dev, n, dO.p, dD.p, tmin, tmax, dHit.p, dT.p, dPrim.p, dB1.p, dB2.p, dP.p, dN.p, dUV.p, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        dHit.down(hit); dT.down(t); dPrim.down(prim); dB1.down(b1); dB2.down(b2); dP.down(point); dN.down(normal); dUV.down(uv);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_any_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const float *d, const float *tmin, const float *tmax,
+                         int32_t *hit) {
+    try {
+        if (!s || n < 0 || (n && (!o || !d || !tmin || !tmax || !hit))) throw std::runtime_error("bad argument");
+        if (n == 0) return 0;
+        Tmp<float> dO(o, 3 * (size_t) n), dD(d, 3 * (size_t) n), dA(tmin, n), dB(tmax, n);
+        Tmp<int> dHit(n);
+        HIPCHK(jtx_launch_any_batch(s->dev, n, dO.p, dD.p, dA.p, dB.p, dHit.p, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        dHit.down(hit);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+static int bxdfBatch(jtx_mi_scene *s, int mode, int32_t material, int32_t n, const float *normal, const float *uv, const float *wo,
+                     const float *wi_in, const float *uc, const float *u2, int32_t *ok, float *f, float *wi_out, float *pdf) {
+    try {
+        if (!s || n < 0 || (n && (!normal || !wo))) throw std::runtime_error("bad argument");
+        if (material < 0 || material >= s->dev.num_materials) throw std::runtime_error("material out of range");
+        if (n == 0) return 0;
+        const size_t N = (size_t) n;
+        Tmp<float> dN(normal, 3 * N), dUV(uv, uv ? 2 * N : 0), dWo(wo, 3 * N), dWi(wi_in, wi_in ? 3 * N : 0), dUc(uc, uc ? N : 0),
+            dU2(u2, u2 ? 2 * N : 0), dF(3 * N), dWiOut(3 * N), dPdf(N);
+        Tmp<int> dOk(N);
+        HIPCHK(jtx_launch_bxdf_batch(s->dev, mode, material, n, dN.p, dUV.p, dWo.p, dWi.p, dUc.p, dU2.p, dOk.p, dF.p, dWiOut.p, dPdf.p, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if (ok) dOk.down(ok);
+        dF.down(f); dWiOut.down(wi_out); dPdf.down(pdf);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+int jtx_mi_bxdf_sample_batch(jtx_mi_scene *s, int32_t material, int32_t n, const float *normal, const float *uv, const float *wo,
+                             const float *uc, const float *u2, int32_t *ok, float *f, float *wi, float *pdf) {
+    if (n > 0 && (!uc || !u2)) return fail("bad argument");
+    return bxdfBatch(s, 0, material, n, normal, uv, wo, nullptr, uc, u2, ok, f, wi, pdf);
+}
+int jtx_mi_bxdf_eval_batch(jtx_mi_scene *s, int32_t material, int32_t n, const float *normal, const float *uv, const float *wo,
+                           const float *wi, float *f) {
+    if (n > 0 && !wi) return fail("bad argument");
+    return bxdfBatch(s, 1, material, n, normal, uv, wo, wi, nullptr, nullptr, nullptr, f, nullptr, nullptr);
+}
+int jtx_mi_bxdf_pdf_batch(jtx_mi_scene *s, int32_t material, int32_t n, const float *normal, const float *uv, const float *wo,
+                          const float *wi, float *pdf) {
+    if (n > 0 && !wi) return fail("bad argument");
+    return bxdfBatch(s, 1, material, n, normal, uv, wo, wi, nullptr, nullptr, nullptr, nullptr, nullptr, pdf);
+}
+
+int jtx_mi_camera_rays(const jtx_mi_camera_desc *cam, int32_t n, const int32_t *row, const int32_t *col, const int32_t *sample,
+                       float *o, float *d) {
+    try {
+        if (!cam || n < 0 || (n && (!row || !col || !sample))) throw std::runtime_error("bad argument");
+        checkCamera(*cam);
+        if (n == 0) return 0;
+        Tmp<int> dR(row, n), dC(col, n), dS(sample, n);
+        Tmp<float> dO(3 * (size_t) n), dD(3 * (size_t) n);
+        HIPCHK(jtx_launch_camera_rays(deriveCamera(*cam), n, dR.p, dC.p, dS.p, dO.p, dD.p, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        dO.down(o); dD.down(d);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_radiance_samples(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, int32_t n, const int32_t *row, const int32_t *col,
+                            const int32_t *sample, float *rgb) {
+    try {
+        if (!s || !cam || n < 0 || (n && (!row || !col || !sample || !rgb))) throw std::runtime_error("bad argument");
+        checkCamera(*cam);
+        if (n == 0) return 0;
+        Tmp<int> dR(row, n), dC(col, n), dS(sample, n);
+        Tmp<float> dRGB(3 * (size_t) n);
+        HIPCHK(jtx_launch_radiance_samples(s->dev, deriveCamera(*cam), cam->max_depth, n, dR.p, dC.p, dS.p, dRGB.p, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        dRGB.down(rgb);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_rng_stream(uint32_t x, uint32_t y, uint32_t n, int32_t count, uint32_t *out_u32, float *out_f32) {
+    try {
+        if (count < 0) throw std::runtime_error("bad argument");
+        if (count == 0) return 0;
+        Tmp<uint32_t> dU(count); Tmp<float> dF(count);
+        HIPCHK(jtx_launch_rng_stream(x, y, n, count, dU.p, dF.p, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        dU.down(out_u32); dF.down(out_f32);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_sincos_batch(const float *x, int32_t n, float *out_sin, float *out_cos) {
+    try {
+        if (n < 0 || (n && !x)) throw std::runtime_error("bad argument");
+        if (n == 0) return 0;
+        Tmp<float> dX(x, n), dS(n), dC(n);
+        HIPCHK(jtx_launch_sincos(dX.p, n, dS.p, dC.p, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        dS.down(out_sin); dC.down(out_cos);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+} // extern "C"

@@ -1,0 +1,335 @@
+// jtx_kernels.hip -- gfx950 kernels of the path-tracing core and their launchers.
+//
+//  k_render_pixels   : pixel-persistent integrator.  One lane owns one pixel and runs all of its
+//                      strata in the reference's sample order, so the float accumulation order of
+//                      AccumulationBuffer::updatePixel (image.hpp:82-86) is preserved with no
+//                      atomics and no resolve pass; a lane whose path ends starts its next stratum
+//                      at once (in-lane path regeneration), which keeps all 64 lanes of a wave busy
+//                      although path lengths differ.  One wave = one 8x8 pixel block.
+//  k_*_batch         : per-ray / per-sample entry points used by the parity tests.
+//
+// Compiled with -ffp-contract=off: results must equal the CPU oracle bit for bit.
+#include "jtx_scene_dev.hpp"
+#include "jtx_launch.hpp"
+
+namespace jtx {
+
+constexpr int BLOCK = 256;
+
+// ---- LDS carve: [stack: stack_depth x BLOCK ints][nodes][tris] (all 16-B aligned) ----
+JD void stageScene(const DevScene &sc, float4 *lds_nodes, float4 *lds_tris) {
+    const int nn = 2 * sc.num_nodes, nt = 3 * sc.num_prims;
+    for (int i = threadIdx.x; i < nn; i += BLOCK) lds_nodes[i] = sc.nodes[i];
+    for (int i = threadIdx.x; i < nt; i += BLOCK) lds_tris[i] = sc.tris[i];
+    __syncthreads();
+}
+
+JD void waveAddCounters(unsigned long long *g, const Counters9 &c) {
+    const unsigned v[9] = {c.n_camera, c.n_closest, c.n_any, c.n_nodes_closest, c.n_tri_closest, c.n_accept,
+                           c.n_nodes_any, c.n_tri_any, c.n_shade};
+    for (int i = 0; i < 9; ++i) {
+        unsigned long long s = v[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[i], s);
+    }
+}
+
+// One bounce of integrateMIS (integrator.cpp:171-216) for the lane's current path.  Returns true
+// when the path is finished (radiance final).
+struct PathState {
+    f3 o, d, beta, radiance;
+    Rng rng;
+    int depth;
+};
+
+template <bool COUNT, class Src>
+JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int maxDepth, PathState &ps, Counters9 &cnt) {
+    HitRec h;
+    const bool hit = traverse<false, COUNT>(src, sc.num_nodes, stk, stride, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
+    if (!hit) {                                                       // integrator.cpp:183-187
+        ps.radiance = ps.radiance + ps.beta * a3(sc.sky);
+        return true;
+    }
+    if (ps.depth++ == maxDepth) return true;                           // integrator.cpp:191
+    const Surface sf = makeSurface(sc.shade, h, ps.o, ps.d);
+    const DMaterial &mat = sc.materials[sf.material];
+    ShadeCtx ctx; ctx.materials = sc.materials; ctx.textures = sc.textures; ctx.texels = sc.texels;
+    const f3 wo = -ps.d;
+    if (sc.num_lights > 0) {                                          // sampleLights integrator.cpp:134-169
+        const uint32_t idx = ps.rng.sampleRange(sc.num_lights - 1);
+        const DLight &light = sc.lights[idx];
+        (void) ps.rng.f(); (void) ps.rng.f();
+        LightSample ls;
+        if (lightSample(light, sf.point, ls)) {
+            const f3 sOrigin = sf.point + sf.normal * RAY_EPSILON;
+            const float lDist = len(sf.point - ls.p);
+            HitRec dummy;
+            const bool occluded = traverse<true, COUNT>(src, sc.num_nodes, stk, stride, sOrigin, ls.wi, 0.0f,
+                                                        lDist - RAY_EPSILON, dummy, cnt);
+            if (!occluded) {
+                f3 f; float pb;
+                evalPdfBxdf(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
+                f = f * absdot(ls.wi, sf.normal);
+                const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
+                const float misWeight = powerHeuristic(1.0f, pl, 1.0f, pb);   // applied to delta lights too (Q10)
+                ps.radiance = ps.radiance + ps.beta * (misWeight * f * ls.radiance / pl);
+            }
+        }
+    }
+    const float u = ps.rng.f();
+    f2 u2; u2.x = ps.rng.f(); u2.y = ps.rng.f();
+    BSample bs;
+    if (COUNT) cnt.n_shade++;
+    if (!sampleBxdf(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) return true;
+    if (bs.pdf > 0.0f) ps.beta = ps.beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);
+    ps.o = sf.point + bs.wi * RAY_EPSILON;                             // integrator.cpp:212
+    ps.d = bs.wi;
+    return false;
+}
+
+JD void startPath(const DCam &cam, uint32_t row, uint32_t col, uint32_t s, PathState &ps) {
+    ps.rng.seed(row, col, s + 1u);                                     // camera.cpp:101
+    cameraRay(cam, col, row, s, ps.rng, ps.o, ps.d);
+    ps.beta = mk3(1.0f); ps.radiance = mk3(0.0f); ps.depth = 0;
+}
+
+JD unsigned char toByte(float v) {                                     // image.hpp:9-16,47-52
+    const float g = v > 0.0f ? sqrtf(v) : 0.0f;
+    const float c = clampf(g, 0.0f, 0.999f);
+    return (unsigned char) (int) (255.999f * c);
+}
+
+template <bool COUNT, bool LDS_SCENE>
+__global__ void __launch_bounds__(BLOCK) k_render_pixels(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const DevScene &sc = p.scene;
+    int *stack = smem;
+    float4 *lds_nodes = (float4 *) (smem + sc.stack_depth * BLOCK);
+    float4 *lds_tris = lds_nodes + 2 * sc.num_nodes;
+    if (LDS_SCENE) stageScene(sc, lds_nodes, lds_tris);
+
+    // work mapping: block = 4 waves = 4 consecutive 8x8 sub-blocks of one owned 32x32 tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int owned = blockIdx.x >> 2;                                 // index into this rank's tiles
+    const int tile = p.tile_rank + owned * p.tile_world;               // global 32x32 tile id, row-major (camera.cpp:55-64)
+    const int sub = ((blockIdx.x & 3) << 2) | wave;                    // 0..15 sub-block inside the tile
+    const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
+    const int row = trow * 32 + (sub >> 2) * 8 + (lane >> 3);
+    const int col = tcol * 32 + (sub & 3) * 8 + (lane & 7);
+    const bool inside = row < p.height && col < p.width;
+
+    Counters9 cnt = {};
+    int *stk = stack + threadIdx.x;
+    if (inside) {
+        const size_t pix = (size_t) row * p.width + col;
+        f3 acc = mk3(0.0f);
+        if (p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
+        int s = p.sample_begin;
+        PathState ps;
+        bool alive = s < p.sample_end;
+        if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
+        while (alive) {
+            bool done;
+            if (LDS_SCENE) { LdsSrc src; src.nodes = lds_nodes; src.tris = lds_tris;
+                             done = pathBounce<COUNT>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
+            else           { GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
+                             done = pathBounce<COUNT>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
+            if (done) {
+                f3 c = ps.radiance;                                    // camera.cpp:110-112
+                if (c.x > 1.0f) c.x = 1.0f;
+                if (c.y > 1.0f) c.y = 1.0f;
+                if (c.z > 1.0f) c.z = 1.0f;
+                acc = acc + c;                                         // image.hpp:82-86
+                ++s;
+                if (s < p.sample_end) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
+                else alive = false;
+            }
+        }
+        p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
+        if (p.img) {
+            const float inv = (float) p.sample_end;                    // currSample + 1 of the last pass (camera.cpp:115)
+            p.img[3 * pix] = toByte(acc.x / inv);
+            p.img[3 * pix + 1] = toByte(acc.y / inv);
+            p.img[3 * pix + 2] = toByte(acc.z / inv);
+        }
+    }
+    if (COUNT) waveAddCounters(p.counters, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// parity-test kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_closest_batch(DevScene sc, int n, const float *o, const float *d, float tmin,
+                                                         float tmax, int *hit, float *t, int *prim, float *b1, float *b2,
+                                                         float *point, float *normal, float *uv) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Counters9 cnt = {};
+    HitRec h; h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f;
+    GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
+    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    const bool r = traverse<false, false>(src, sc.num_nodes, smem + threadIdx.x, BLOCK, ro, rd, tmin, tmax, h, cnt);
+    hit[i] = r ? 1 : 0;
+    Surface sf; sf.point = sf.normal = mk3(0.0f); sf.uv = mk2(0.0f, 0.0f);
+    if (r) sf = makeSurface(sc.shade, h, ro, rd); else { h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f; }
+    t[i] = h.t; prim[i] = h.prim; b1[i] = h.b1; b2[i] = h.b2;
+    point[3 * i] = sf.point.x; point[3 * i + 1] = sf.point.y; point[3 * i + 2] = sf.point.z;
+    normal[3 * i] = sf.normal.x; normal[3 * i + 1] = sf.normal.y; normal[3 * i + 2] = sf.normal.z;
+    uv[2 * i] = sf.uv.x; uv[2 * i + 1] = sf.uv.y;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_any_batch(DevScene sc, int n, const float *o, const float *d, const float *tmin,
+                                                     const float *tmax, int *hit) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Counters9 cnt = {};
+    HitRec h;
+    GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
+    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    hit[i] = traverse<true, false>(src, sc.num_nodes, smem + threadIdx.x, BLOCK, ro, rd, tmin[i], tmax[i], h, cnt) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_bxdf_batch(DevScene sc, int mode, int material, int n, const float *normal,
+                                                      const float *uv, const float *wo, const float *wi_in, const float *uc,
+                                                      const float *u2, int *ok, float *f, float *wi_out, float *pdf) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    ShadeCtx ctx; ctx.materials = sc.materials; ctx.textures = sc.textures; ctx.texels = sc.texels;
+    const DMaterial &m = sc.materials[material];
+    const f3 nrm = mk3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+    const f2 tuv = uv ? mk2(uv[2 * i], uv[2 * i + 1]) : mk2(0.0f, 0.0f);
+    const f3 w_o = mk3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
+    if (mode == 0) {
+        BSample bs; bs.f = bs.wi = mk3(0.0f); bs.pdf = 0.0f;
+        const bool r = sampleBxdf(ctx, m, nrm, tuv, w_o, uc[i], mk2(u2[2 * i], u2[2 * i + 1]), bs);
+        if (!r) { bs.f = bs.wi = mk3(0.0f); bs.pdf = 0.0f; }
+        ok[i] = r ? 1 : 0;
+        f[3 * i] = bs.f.x; f[3 * i + 1] = bs.f.y; f[3 * i + 2] = bs.f.z;
+        wi_out[3 * i] = bs.wi.x; wi_out[3 * i + 1] = bs.wi.y; wi_out[3 * i + 2] = bs.wi.z;
+        pdf[i] = bs.pdf;
+    } else {
+        const f3 w_i = mk3(wi_in[3 * i], wi_in[3 * i + 1], wi_in[3 * i + 2]);
+        f3 fv; float pv;
+        evalPdfBxdf(ctx, m, nrm, tuv, w_o, w_i, fv, pv);
+        if (f) { f[3 * i] = fv.x; f[3 * i + 1] = fv.y; f[3 * i + 2] = fv.z; }
+        if (pdf) pdf[i] = pv;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_camera_rays(DCam cam, int n, const int *row, const int *col, const int *sample,
+                                                       float *o, float *d) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Rng rng; rng.seed(row[i], col[i], sample[i] + 1);
+    f3 ro, rd; cameraRay(cam, col[i], row[i], sample[i], rng, ro, rd);
+    o[3 * i] = ro.x; o[3 * i + 1] = ro.y; o[3 * i + 2] = ro.z;
+    d[3 * i] = rd.x; d[3 * i + 1] = rd.y; d[3 * i + 2] = rd.z;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_radiance_samples(DevScene sc, DCam cam, int maxDepth, int n, const int *row,
+                                                            const int *col, const int *sample, float *rgb) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Counters9 cnt = {};
+    PathState ps;
+    startPath(cam, row[i], col[i], sample[i], ps);
+    GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
+    while (!pathBounce<false>(sc, src, smem + threadIdx.x, BLOCK, maxDepth, ps, cnt)) {}
+    f3 c = ps.radiance;
+    if (c.x > 1.0f) c.x = 1.0f;
+    if (c.y > 1.0f) c.y = 1.0f;
+    if (c.z > 1.0f) c.z = 1.0f;
+    rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+}
+
+__global__ void k_rng_stream(uint32_t x, uint32_t y, uint32_t n, int count, uint32_t *out_u32, float *out_f32) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng a, b; a.seed(x, y, n); b.seed(x, y, n);
+    for (int i = 0; i < count; ++i) { out_u32[i] = a.advance(); out_f32[i] = b.f(); }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_sincos(const float *x, int n, float *s, float *c) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float ss, cc; det_sincos(x[i], ss, cc);
+    s[i] = ss; c[i] = cc;
+}
+
+} // namespace jtx
+
+// ------------------------------------------------------------------------------------------------
+// launchers (host)
+// ------------------------------------------------------------------------------------------------
+using namespace jtx;
+
+static size_t ldsBytes(const DevScene &sc, bool withScene) {
+    size_t b = (size_t) sc.stack_depth * BLOCK * sizeof(int);
+    if (withScene) b += ((size_t) 2 * sc.num_nodes + (size_t) 3 * sc.num_prims) * sizeof(float4);
+    return b;
+}
+
+hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream) {
+    if (num_owned_tiles <= 0) return hipSuccess;
+    const dim3 grid((unsigned) num_owned_tiles * 4u), block(BLOCK);
+    const bool lds = p.scene.lds_scene != 0;
+    const size_t shmem = ldsBytes(p.scene, lds);
+    if (lds) {
+        if (count) hipLaunchKernelGGL((k_render_pixels<true, true>), grid, block, shmem, stream, p);
+        else       hipLaunchKernelGGL((k_render_pixels<false, true>), grid, block, shmem, stream, p);
+    } else {
+        if (count) hipLaunchKernelGGL((k_render_pixels<true, false>), grid, block, shmem, stream, p);
+        else       hipLaunchKernelGGL((k_render_pixels<false, false>), grid, block, shmem, stream, p);
+    }
+    return hipGetLastError();
+}
+
+static inline unsigned blocksFor(int n) { return (unsigned) ((n + BLOCK - 1) / BLOCK); }
+
+hipError_t jtx_launch_closest_batch(const DevScene &sc, int n, const float *o, const float *d, float tmin, float tmax,
+                                    int *hit, float *t, int *prim, float *b1, float *b2, float *point, float *normal,
+                                    float *uv, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_closest_batch, dim3(blocksFor(n)), dim3(BLOCK), ldsBytes(sc, false), stream, sc, n, o, d, tmin, tmax,
+                       hit, t, prim, b1, b2, point, normal, uv);
+    return hipGetLastError();
+}
+hipError_t jtx_launch_any_batch(const DevScene &sc, int n, const float *o, const float *d, const float *tmin,
+                                const float *tmax, int *hit, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_any_batch, dim3(blocksFor(n)), dim3(BLOCK), ldsBytes(sc, false), stream, sc, n, o, d, tmin, tmax, hit);
+    return hipGetLastError();
+}
+hipError_t jtx_launch_bxdf_batch(const DevScene &sc, int mode, int material, int n, const float *normal, const float *uv,
+                                 const float *wo, const float *wi_in, const float *uc, const float *u2, int *ok, float *f,
+                                 float *wi_out, float *pdf, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bxdf_batch, dim3(blocksFor(n)), dim3(BLOCK), 0, stream, sc, mode, material, n, normal, uv, wo, wi_in,
+                       uc, u2, ok, f, wi_out, pdf);
+    return hipGetLastError();
+}
+hipError_t jtx_launch_camera_rays(const DCam &cam, int n, const int *row, const int *col, const int *sample, float *o,
+                                  float *d, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_camera_rays, dim3(blocksFor(n)), dim3(BLOCK), 0, stream, cam, n, row, col, sample, o, d);
+    return hipGetLastError();
+}
+hipError_t jtx_launch_radiance_samples(const DevScene &sc, const DCam &cam, int maxDepth, int n, const int *row,
+                                       const int *col, const int *sample, float *rgb, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_radiance_samples, dim3(blocksFor(n)), dim3(BLOCK), ldsBytes(sc, false), stream, sc, cam, maxDepth, n,
+                       row, col, sample, rgb);
+    return hipGetLastError();
+}
+hipError_t jtx_launch_rng_stream(uint32_t x, uint32_t y, uint32_t n, int count, uint32_t *out_u32, float *out_f32,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(k_rng_stream, dim3(1), dim3(64), 0, stream, x, y, n, count, out_u32, out_f32);
+    return hipGetLastError();
+}
+hipError_t jtx_launch_sincos(const float *x, int n, float *s, float *c, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sincos, dim3(blocksFor(n)), dim3(BLOCK), 0, stream, x, n, s, c);
+    return hipGetLastError();
+}

@@ -1,0 +1,36 @@
+// jtx_launch.hpp -- kernel parameter blocks and launcher prototypes shared by jtx_kernels.hip and
+// the C-ABI implementation (jtx_capi.hip).
+#pragma once
+#include "jtx_scene_dev.hpp"
+
+namespace jtx {
+
+struct RenderParams {
+    DevScene scene;
+    DCam     cam;
+    int width, height, max_depth;
+    int sample_begin, sample_end;
+    int tile_rank, tile_world, tiles_x;
+    float *acc;                    // W*H*3 float sums (AccumulationBuffer)
+    unsigned char *img;            // W*H*3 u8 (RGB8Image) or null
+    unsigned long long *counters;  // 9 x u64 or null
+};
+
+} // namespace jtx
+
+hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
+hipError_t jtx_launch_closest_batch(const jtx::DevScene &sc, int n, const float *o, const float *d, float tmin, float tmax,
+                                    int *hit, float *t, int *prim, float *b1, float *b2, float *point, float *normal,
+                                    float *uv, hipStream_t stream);
+hipError_t jtx_launch_any_batch(const jtx::DevScene &sc, int n, const float *o, const float *d, const float *tmin,
+                                const float *tmax, int *hit, hipStream_t stream);
+hipError_t jtx_launch_bxdf_batch(const jtx::DevScene &sc, int mode, int material, int n, const float *normal, const float *uv,
+                                 const float *wo, const float *wi_in, const float *uc, const float *u2, int *ok, float *f,
+                                 float *wi_out, float *pdf, hipStream_t stream);
+hipError_t jtx_launch_camera_rays(const jtx::DCam &cam, int n, const int *row, const int *col, const int *sample, float *o,
+                                  float *d, hipStream_t stream);
+hipError_t jtx_launch_radiance_samples(const jtx::DevScene &sc, const jtx::DCam &cam, int maxDepth, int n, const int *row,
+                                       const int *col, const int *sample, float *rgb, hipStream_t stream);
+hipError_t jtx_launch_rng_stream(uint32_t x, uint32_t y, uint32_t n, int count, uint32_t *out_u32, float *out_f32,
+                                 hipStream_t stream);
+hipError_t jtx_launch_sincos(const float *x, int n, float *s, float *c, hipStream_t stream);

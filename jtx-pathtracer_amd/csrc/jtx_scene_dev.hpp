@@ -1,0 +1,208 @@
+// jtx_scene_dev.hpp -- device scene layout and the BVH traversal / ray-triangle stage.
+//
+// HBM layout (built once per scene by jtx_mi_scene_create, see DESIGN.md "Data layout"):
+//   nodes : 2 x float4 per node  [pmin.xyz pmax.x] [pmax.yz asfloat(offset) asfloat(num_prims | axis<<16)]
+//           -- the reference's 32-B LinearBVHNode (bvh.hpp:7-15) re-packed so one node = two 16-B lanes
+//              of one dwordx4 pair (a 128-B gfx950 cache line holds 4 nodes; the implicit first child
+//              cur+1 shares the parent's line 3 times out of 4).
+//   tris  : 3 x float4 per primitive IN BVH ORDER [v0.xyz e1.x] [e1.yz e2.xy] [e2.z - - -]
+//           -- Mesh::transform baked, e1 = v1-v0, e2 = v2-v0 precomputed in fp32 exactly as
+//              mesh.hpp:109-110 computes them per test, so the per-test index gather + three
+//              matrix multiplies of mesh.hpp:71-77 disappear.
+//   shade : 4 x float4 per primitive [n0.xyz n1.x] [n1.yz n2.xy] [n2.z uv0.xy uv1.x] [uv1.y uv2.xy asfloat(material)]
+//           -- read once per accepted path vertex (the reference interpolates at every accept,
+//              mesh.hpp:133-145; only the last one survives, so deferring is equivalent).
+// When nodes+tris fit the LDS budget they are staged into LDS once per workgroup (LdsSrc).
+#pragma once
+#include "jtx_bxdf.hpp"
+
+namespace jtx {
+
+struct DLight { int type; float position[3]; float intensity[3]; float scale; float scene_radius; int pad[3]; };
+
+struct DevScene {
+    const float4    *nodes;
+    const float4    *tris;
+    const float4    *shade;
+    const DMaterial *materials;
+    const DLight    *lights;
+    const DTexture  *textures;
+    const float     *texels;
+    int num_nodes, num_prims, num_lights, num_materials;
+    int stack_depth;       // LDS stack entries per lane = BVH leaf depth (+1), known from the build
+    int lds_scene;         // != 0: nodes+tris are staged in LDS
+    float sky[3];
+};
+
+struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode only)
+    unsigned n_camera, n_closest, n_any, n_nodes_closest, n_tri_closest, n_accept, n_nodes_any, n_tri_any, n_shade;
+};
+
+struct GlobalSrc {
+    const float4 *nodes, *tris;
+    JD float4 node(int i, int h) const { return nodes[2 * i + h]; }
+    JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
+};
+struct LdsSrc {           // pointers into the workgroup's LDS copy
+    const float4 *nodes, *tris;
+    JD float4 node(int i, int h) const { return nodes[2 * i + h]; }
+    JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
+};
+
+struct HitRec { float t; int prim; float b1, b2; };
+
+// Scene::closestHit (scene.cpp:10-55) / Scene::anyHit (scene.cpp:57-94) with AABB::hit
+// (aabb.hpp:66-81) and Mesh::tClosestHit / tAnyHit (mesh.hpp:106-192) inlined.
+//  * 1/d is computed once per ray: aabb.hpp:71 recomputes the same quotient at every node.
+//  * The per-axis early-out of aabb.hpp:78 is folded into one test after the third axis: t0 only
+//    grows and t1 only shrinks (a NaN candidate is never selected by either ternary), so
+//    "t0 > t1 after some axis" <=> "t0 > t1 after the last axis".
+//  * |det| < 1e-8 is a double compare in the reference (mesh.hpp:114); for a float |det| it is
+//    equivalent to |det| <= 1e-8f because 1e-8f < 1e-8 < nextafter(1e-8f).
+//  * stack: one LDS column per lane (stk[level * stride]), depth bounded by the BVH build.
+template <bool ANY, bool COUNT, class Src>
+JD bool traverse(const Src &src, int num_nodes, int *stk, int stride, f3 o, f3 d, float tmin, float tmax,
+                 HitRec &rec, Counters9 &cnt) {
+    if (num_nodes == 0) return false;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const int negmask = (ix < 0.0f ? 1 : 0) | (iy < 0.0f ? 2 : 0) | (iz < 0.0f ? 4 : 0);
+    int sp = 0, cur = 0;
+    bool hitAnything = false;
+    if (COUNT) { if (ANY) cnt.n_any++; else cnt.n_closest++; }
+    while (true) {
+        const float4 na = src.node(cur, 0);
+        const float4 nb = src.node(cur, 1);
+        if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
+        float t0 = tmin, t1 = tmax;
+        {
+            float tn = (na.x - o.x) * ix, tf = (na.w - o.x) * ix;
+            float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
+            t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
+        }
+        {
+            float tn = (na.y - o.y) * iy, tf = (nb.x - o.y) * iy;
+            float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
+            t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
+        }
+        {
+            float tn = (na.z - o.z) * iz, tf = (nb.y - o.z) * iz;
+            float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
+            t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
+        }
+        bool descend = false;
+        if (!(t0 > t1)) {
+            const int meta = __float_as_int(nb.w);
+            const int off = __float_as_int(nb.z);
+            const int nprims = meta & 0xffff;
+            if (nprims > 0) {
+                for (int i = 0; i < nprims; ++i) {
+                    const int prim = off + i;
+                    const float4 q0 = src.tri(prim, 0), q1 = src.tri(prim, 1), q2 = src.tri(prim, 2);
+                    if (COUNT) { if (ANY) cnt.n_tri_any++; else cnt.n_tri_closest++; }
+                    const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+                    const f3 pvec = cross(d, e2);
+                    const float det = dot(e1, pvec);
+                    if (fabsf(det) <= 1e-8f) continue;
+                    const float invDet = 1.0f / det;
+                    const f3 tvec = o - v0;
+                    const float b1 = dot(tvec, pvec) * invDet;
+                    if (b1 < 0.0f || b1 > 1.0f) continue;
+                    const f3 qvec = cross(tvec, e1);
+                    const float b2 = dot(d, qvec) * invDet;
+                    if (b2 < 0.0f || b1 + b2 > 1.0f) continue;
+                    const float root = dot(e2, qvec) * invDet;
+                    if (!(tmin < root && root < tmax)) continue;
+                    if (ANY) return true;
+                    hitAnything = true;
+                    tmax = root;
+                    rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+                    if (COUNT) cnt.n_accept++;
+                }
+            } else {
+                const int axis = (meta >> 16) & 0xff;
+                const bool neg = (negmask >> axis) & 1;
+                stk[sp * stride] = neg ? cur + 1 : off;
+                sp++;
+                cur = neg ? off : cur + 1;
+                descend = true;
+            }
+        }
+        if (!descend) {
+            if (sp == 0) break;
+            --sp;
+            cur = stk[sp * stride];
+        }
+    }
+    return hitAnything;
+}
+
+struct Surface { f3 point, normal; f2 uv; int material; };
+
+// The accept branch of Mesh::tClosestHit (mesh.hpp:129-145) + setFaceNormal (material.hpp:36-39)
+JD Surface makeSurface(const float4 *shade, const HitRec &h, f3 o, f3 d) {
+    const float4 s0 = shade[4 * h.prim + 0], s1 = shade[4 * h.prim + 1], s2 = shade[4 * h.prim + 2], s3 = shade[4 * h.prim + 3];
+    const f3 n0 = mk3(s0.x, s0.y, s0.z), n1 = mk3(s0.w, s1.x, s1.y), n2 = mk3(s1.z, s1.w, s2.x);
+    Surface r;
+    r.point = o + h.t * d;
+    const float b0 = (1.0f - h.b1 - h.b2);
+    const f3 n = b0 * n0 + h.b1 * n1 + h.b2 * n2;
+    r.normal = dot(d, n) < 0.0f ? n : -n;
+    r.uv = mk2(s2.y * b0 + s2.w * h.b1 + s3.y * h.b2, s2.z * b0 + s3.x * h.b1 + s3.z * h.b2);
+    r.material = __float_as_int(s3.w);
+    return r;
+}
+
+// Light::sample (lights.hpp:36-54)
+struct LightSample { f3 p, radiance, wi; float pdf; };
+JD bool lightSample(const DLight &l, f3 p, LightSample &ls) {
+    const f3 pos = a3(l.position), I = a3(l.intensity);
+    if (l.type == 0) {
+        ls.p = pos;
+        ls.wi = normalize(pos - p);
+        ls.radiance = l.scale * I / lenSqr(pos - p);
+        ls.pdf = 1.0f;
+        return true;
+    }
+    if (l.type == 1) {
+        ls.p = p - pos * 2.0f * l.scene_radius;
+        ls.wi = -pos;
+        ls.radiance = l.scale * I;
+        ls.pdf = 1.0f;
+        return true;
+    }
+    return false;
+}
+
+JD float powerHeuristic(float nf, float fPdf, float ng, float gPdf) {   // integrator.cpp:6-10
+    const float f = nf * fPdf, g = ng * gPdf;
+    return f * f / (f * f + g * g);
+}
+
+// Camera state derived on the host by Camera::init (camera.cpp:7-31)
+struct DCam {
+    float center[3], vp00[3], du[3], dv[3], defocus_u[3], defocus_v[3];
+    float defocus_angle;
+    int xs, ys;
+};
+
+// Camera::getRay (camera.hpp:127-139), called as getRay(col,row,stratum) (camera.cpp:103)
+JD void cameraRay(const DCam &k, uint32_t col, uint32_t row, uint32_t stratum, Rng &rng, f3 &o, f3 &d) {
+    const uint32_t x = stratum % (uint32_t) k.xs, y = stratum / (uint32_t) k.xs;
+    const float dx = rng.f(), dy = rng.f();
+    const float offx = ((float) x + dx) / (float) k.xs, offy = ((float) y + dy) / (float) k.ys;
+    const f3 sample = a3(k.vp00) + ((float) col + offx) * a3(k.du) + ((float) row + offy) * a3(k.dv);
+    f3 origin = a3(k.center);
+    if (!(k.defocus_angle <= 0.0f)) {
+        float px, py;
+        while (true) {                                       // RNG::sampleUnitDisc rand.hpp:179-184
+            px = -1.0f + (1.0f - -1.0f) * rng.f();
+            py = -1.0f + (1.0f - -1.0f) * rng.f();
+            if (px * px + py * py + 0.0f * 0.0f < 1.0f) break;
+        }
+        origin = a3(k.center) + (px * a3(k.defocus_u)) + (py * a3(k.defocus_v));
+    }
+    (void) rng.f();                                          // ray time
+    o = origin; d = sample - origin;
+}
+
+} // namespace jtx

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import jtx_pathtracer_amd as jtx
+        import ctypes as C
+        lib = jtx._capi.load()
+        n = C.c_int32(0)
+        return lib.jtx_mi_device_count(C.byref(n)) == 0 and n.value > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The product library on a GPU box.  GPU tests FAIL (not skip) when the HIP library is missing."""
+    import jtx_pathtracer_amd as jtx
+    jtx._capi.load()            # raises if libjtx_mi.so is absent: no silent fallback
+    if not _has_gpu():
+        pytest.fail("no HIP device visible: -m gpu tests need an MI355X")
+    return jtx
+
+
+@pytest.fixture(scope="session")
+def cornell_pair(gpu):
+    import oracle_lib as ol
+    data = gpu.scenes.cornell()
+    sc = gpu.Scene(data)
+    sc.buildBVH()
+    return data, sc, ol.OracleScene(data)
+
+
+@pytest.fixture(scope="session")
+def mixed_pair(gpu):
+    import oracle_lib as ol
+    data = gpu.scenes.mixed(sphere_res=(24, 12))
+    sc = gpu.Scene(data)
+    sc.buildBVH()
+    return data, sc, ol.OracleScene(data)

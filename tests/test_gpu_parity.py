@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle, bit for bit.
+
+Tolerance: NONE.  All arithmetic on the path is IEEE fp32 with one rounding per operation on both
+sides (device code is built -ffp-contract=off, sin/cos are the deterministic polynomials of
+DESIGN.md), so radiance, accumulation buffer, RGB8 image and ray counters must be identical.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_same_f32(a, b, what):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, what
+    # NaNs compare by bit pattern class: both NaN is fine
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        bad = np.argwhere(~same)
+        i = tuple(bad[0])
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} floats differ; first at {i}: gpu={a[i]!r} oracle={b[i]!r}")
+
+
+def test_rng_streams(gpu):
+    for seed in [(0, 0, 1), (1, 2, 3), (511, 17, 16), (1079, 1919, 64), (4000000000, 7, 9)]:
+        gu, gf = gpu.api.rng_stream(*seed, 64)
+        ou, of = ol.rng_stream(*seed, 64)
+        assert (gu == ou).all()
+        assert_same_f32(gf, of, "rng floats")
+
+
+def test_sincos_bitexact(gpu):
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.uniform(-0.8, 2 * np.pi + 0.1, 200000), rs.uniform(-16, 16, 50000),
+                        np.array([0.0, -0.0, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, 1e-8, -1e-8])]).astype(np.float32)
+    gs, gc = gpu.api.sincos(x)
+    os_, oc = ol.sincos(x)
+    assert_same_f32(gs, os_, "sin")
+    assert_same_f32(gc, oc, "cos")
+
+
+def _grid_samples(w, h, spp, n, seed):
+    rs = np.random.RandomState(seed)
+    return rs.randint(0, h, n).astype(np.int32), rs.randint(0, w, n).astype(np.int32), rs.randint(0, spp, n).astype(np.int32)
+
+
+@pytest.mark.parametrize("defocus", [0.0, 2.5])
+def test_camera_rays(gpu, defocus):
+    data = gpu.scenes.cornell()
+    data.camera["defocus_angle"] = defocus
+    data.camera["focus_distance"] = 1.0 if defocus == 0 else 800.0
+    cam = data.camera_desc(640, 360, 8, 4, 5)
+    row, col, smp = _grid_samples(640, 360, 32, 20000, 1)
+    go, gd = gpu.api.camera_rays(cam, row, col, smp)
+    oo, od = ol.camera_rays(cam, row, col, smp)
+    assert_same_f32(go, oo, "ray origin")
+    assert_same_f32(gd, od, "ray dir")
+
+
+def _rays_for(data, osc, n, seed):
+    """camera rays + secondary-like rays from hit points + axis-parallel / grazing rays."""
+    cam = data.camera_desc(256, 256, 2, 2, 4)
+    row, col, smp = _grid_samples(256, 256, 4, n, seed)
+    o, d = ol.camera_rays(cam, row, col, smp)
+    h = osc.closestHit(o, d)
+    rs = np.random.RandomState(seed + 1)
+    dirs = rs.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    o2 = np.where(h["hit"][:, None] > 0, h["point"] + 1e-3 * dirs, o).astype(np.float32)
+    axis = np.zeros((64, 3), np.float32)
+    axis[np.arange(64), np.arange(64) % 3] = np.where(np.arange(64) % 2, 1.0, -1.0)
+    o3 = np.tile(np.array([[278.0, 273.0, 200.0]], np.float32), (64, 1))
+    return (np.concatenate([o, o2, o3]), np.concatenate([d, dirs, axis]))
+
+
+@pytest.mark.parametrize("pair", ["cornell_pair", "mixed_pair"])
+def test_closest_hit(pair, request):
+    data, sc, osc = request.getfixturevalue(pair)
+    o, d = _rays_for(data, osc, 30000, 3)
+    g = sc.closestHit(o, d)
+    r = osc.closestHit(o, d)
+    assert (g["hit"] == r["hit"]).all()
+    assert (g["prim"] == r["prim"]).all()
+    for k in ("t", "b1", "b2", "point", "normal", "uv"):
+        assert_same_f32(g[k], r[k], k)
+    assert g["hit"].mean() > 0.5
+
+
+@pytest.mark.parametrize("pair", ["cornell_pair", "mixed_pair"])
+def test_any_hit(pair, request):
+    data, sc, osc = request.getfixturevalue(pair)
+    o, d = _rays_for(data, osc, 30000, 5)
+    rs = np.random.RandomState(9)
+    tmax = rs.uniform(1.0, 900.0, len(o)).astype(np.float32)
+    g = sc.anyHit(o, d, 0.0, tmax)
+    r = osc.anyHit(o, d, 0.0, tmax)
+    assert (g == r).all()
+    assert 0.05 < g.mean() < 0.95
+
+
+def _bxdf_inputs(n, seed):
+    rs = np.random.RandomState(seed)
+    nrm = rs.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+    nrm[: n // 4] *= rs.uniform(0.9, 1.1, (n // 4, 1)).astype(np.float32)      # non-unit normals (quirk Q6)
+    wo = rs.normal(size=(n, 3)).astype(np.float32)
+    wo[n // 2:] /= np.linalg.norm(wo[n // 2:], axis=1, keepdims=True).astype(np.float32)   # half unit, half not (Q5)
+    wi = rs.normal(size=(n, 3)).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True).astype(np.float32)
+    # grazing: wo nearly perpendicular to the normal
+    g = slice(0, n // 10)
+    wo[g] = np.cross(nrm[g], wi[g]) + 1e-4 * nrm[g]
+    uc = rs.uniform(0, 1, n).astype(np.float32)
+    u2 = rs.uniform(0, 1, (n, 2)).astype(np.float32)
+    uv = rs.uniform(-2, 3, (n, 2)).astype(np.float32)
+    return nrm, wo, wi, uc, u2, uv
+
+
+def test_bxdf_all_materials(mixed_pair):
+    data, sc, osc = mixed_pair
+    nrm, wo, wi, uc, u2, uv = _bxdf_inputs(20000, 11)
+    assert len(data.materials) >= 11
+    for m in range(len(data.materials)):
+        gs = sc.sampleBxdf(m, nrm, wo, uc, u2, uv)
+        rs_ = osc.sampleBxdf(m, nrm, wo, uc, u2, uv)
+        assert (gs["ok"] == rs_["ok"]).all(), f"material {m} sample ok"
+        for k in ("f", "wi", "pdf"):
+            assert_same_f32(gs[k], rs_[k], f"material {m} sample {k}")
+        assert_same_f32(sc.evalBxdf(m, nrm, wo, wi, uv), osc.evalBxdf(m, nrm, wo, wi, uv), f"material {m} eval")
+        assert_same_f32(sc.pdfBxdf(m, nrm, wo, wi, uv), osc.pdfBxdf(m, nrm, wo, wi, uv), f"material {m} pdf")
+        if data.materials[m]["type"] != 1 or data.materials[m]["alpha_x"] > 0:
+            assert gs["ok"].mean() > 0.3, f"material {m}: too few successful samples"
+
+
+@pytest.mark.parametrize("pair,depth", [("cornell_pair", 4), ("cornell_pair", 8), ("mixed_pair", 8)])
+def test_radiance_samples(pair, depth, request):
+    data, sc, osc = request.getfixturevalue(pair)
+    cam = data.camera_desc(320, 200, 4, 4, depth)
+    row, col, smp = _grid_samples(320, 200, 16, 40000, 21)
+    g = gpu_rgb = request.getfixturevalue("gpu").api.radiance_samples(sc, cam, row, col, smp)
+    r = osc.radiance_samples(cam, row, col, smp)
+    assert_same_f32(g, r, "radiance")
+    assert gpu_rgb.max() > 0.1
+
+
+def _render_both(gpu, data, sc, osc, w, h, xs, ys, depth, **kw):
+    cam_g = gpu.StaticCamera(w, h, data.camera, xs, ys, depth)
+    cam_g.render(sc, count_rays=True, **kw)
+    acc, img, cnt = osc.render(data.camera_desc(w, h, xs, ys, depth))
+    return cam_g, acc, img, cnt
+
+
+def test_render_config1_cornell_512(gpu, cornell_pair):
+    """BASELINE config 1: Cornell 512x512, 16 spp (4x4), depth 4 -- whole frame, bit-exact."""
+    data, sc, osc = cornell_pair
+    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 512, 512, 4, 4, 4)
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
+    assert cam_g.counters == cnt
+    assert cnt["n_camera"] == 512 * 512 * 16
+
+
+def test_render_mixed_small(gpu, mixed_pair):
+    data, sc, osc = mixed_pair
+    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 200, 120, 2, 2, 8)
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
+    assert cam_g.counters == cnt
+
+
+def test_render_ragged_sizes(gpu, cornell_pair):
+    """widths/heights that are not multiples of the 8x8 wave block or the 32x32 tile; 1x1 image."""
+    data, sc, osc = cornell_pair
+    for (w, h) in [(1, 1), (33, 7), (70, 45)]:
+        cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, w, h, 2, 1, 3)
+        assert_same_f32(cam_g.acc_, acc, f"acc {w}x{h}")
+        assert (cam_g.img_ == img).all()
+        assert cam_g.counters == cnt
+
+
+def test_render_resume_and_progress(gpu, cornell_pair):
+    """rendering strata [0,3) then [3,8) equals [0,8); the progress callback sees every pass."""
+    data, sc, osc = cornell_pair
+    full = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4); full.render(sc)
+    part = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4)
+    part.render(sc, sample_begin=0, sample_end=3)
+    part.render(sc, sample_begin=3, sample_end=8)
+    assert_same_f32(part.acc_, full.acc_, "resumed acc")
+    assert (part.img_ == full.img_).all()
+    seen = []
+    prog = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4)
+    prog.render(sc, progress=lambda c, t: seen.append((c, t)))
+    assert seen == [(i, 8) for i in range(1, 9)]
+    assert_same_f32(prog.acc_, full.acc_, "progressive acc")
+    # cancellation: terminateRender() stops after the current pass
+    stop = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4)
+    stop.render(sc, progress=lambda c, t: stop.terminateRender() if c == 2 else None)
+    assert stop.currentSample_ == 2
+
+
+def test_render_tile_sharding(gpu, cornell_pair):
+    """pixel-tile shards of 3 ranks are disjoint, zero elsewhere, and sum to the 1-GPU frame exactly."""
+    data, sc, osc = cornell_pair
+    full = gpu.StaticCamera(200, 100, data.camera, 2, 2, 4); full.render(sc)
+    total = np.zeros_like(full.acc_)
+    cover = np.zeros(full.acc_.shape[:2], np.int32)
+    for r in range(3):
+        c = gpu.StaticCamera(200, 100, data.camera, 2, 2, 4)
+        c.render(sc, tile_rank=r, tile_world=3)
+        total += c.acc_
+        cover += (gpu.distributed.tile_owner_mask(200, 100, r, 3)).astype(np.int32)
+        assert (c.acc_[~gpu.distributed.tile_owner_mask(200, 100, r, 3)] == 0).all()
+    assert (cover == 1).all()
+    assert_same_f32(total, full.acc_, "sum of shards")
+
+
+def test_empty_and_degenerate_scenes(gpu):
+    """no triangles at all (every ray misses -> sky), and a scene without lights."""
+    s = gpu.scenes.SceneData("empty")
+    s.materials = [gpu.scenes.material()]
+    s.sky = (0.25, 0.5, 0.75)
+    sc = gpu.Scene(s); sc.buildBVH()
+    cam = gpu.StaticCamera(16, 8, s.camera, 1, 1, 3); cam.render(sc)
+    assert_same_f32(cam.acc_, np.broadcast_to(np.array(s.sky, np.float32), (8, 16, 3)), "sky only")
+    q = gpu.scenes.quad_scene()
+    sq = gpu.Scene(q); sq.buildBVH()
+    oq = ol.OracleScene(q)
+    cg = gpu.StaticCamera(64, 64, q.camera, 2, 2, 4); cg.render(sq)
+    acc, img, _ = oq.render(q.camera_desc(64, 64, 2, 2, 4))
+    assert_same_f32(cg.acc_, acc, "quad scene acc")
+    assert (cg.img_ == img).all()
+
+
+def test_errors_are_reported(gpu):
+    s = gpu.scenes.cornell()
+    s.meshes[0]["material"] = 99
+    with pytest.raises(gpu.JtxMiError):
+        gpu.Scene(s).buildBVH()
