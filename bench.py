@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the JTX path-tracing hot path on MI355X (BASELINE.json metric).
+
+A "step" is one whole frame of the workload: BASELINE config 2, Cornell box 1920x1080, 64 spp (8x8
+strata), maxDepth 8, through jtx_mi_render_device (scene already resident in HBM).  With N > 1
+ranks the frame's 32x32 pixel tiles are interleaved over the ranks and one RCCL reduce per frame
+sums the disjoint shards onto rank 0 (strong scaling: the frame is fixed).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  ray = one Scene::closestHit or Scene::anyHit call.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene factory name, width, height, xs, ys, max_depth)
+    "cornell_1920x1080_64spp_d8": ("cornell", 1920, 1080, 8, 8, 8),
+    "cornell_512x512_16spp_d4": ("cornell", 512, 512, 4, 4, 4),
+    "atrium_1920x1080_64spp_d8": ("atrium", 1920, 1080, 8, 8, 8),
+    "mixed_1920x1080_128spp_d8": ("mixed", 1920, 1080, 16, 8, 8),
+}
+
+
+def algorithmic_bytes(c):
+    """bytes the reference's data structures imply per ray / shade / sample."""
+    b_closest = 32 * c["n_nodes_closest"] + 56 * c["n_tri_closest"] + 60 * c["n_accept"] + 64 * c["n_closest"]
+    b_any = 32 * c["n_nodes_any"] + 56 * c["n_tri_any"] + 64 * c["n_any"]
+    b_shade = 176 * c["n_shade"]
+    b_cam = 27 * c["n_camera"]
+    return b_closest + b_any + b_shade + b_cam
+
+
+def cpu_baseline(data, width, height, xs, ys, depth, budget_s=12.0):
+    """The CPU oracle (kind "port": a restatement of the reference's algorithm, reference flags
+    -O3 -ffast-math, one barrier per sample pass as StaticCamera::render) timed on this host's cores
+    over a bounded number of strata of the SAME frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    import jtx_pathtracer_amd as jtx
+    capi = jtx._capi
+    fast = os.path.join(ROOT, "oracle", "_build", "libjtx_oracle_fast.so")
+    if not os.path.exists(fast):
+        ol.build(fast=True)
+    lib = C.CDLL(fast)
+    lib.ora_scene_create.restype = C.c_void_p
+    lib.ora_scene_create.argtypes = [C.POINTER(capi.SceneDesc)]
+    lib.ora_render.restype = None
+    lib.ora_render.argtypes = [C.c_void_p, C.POINTER(capi.CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(capi.Counters)]
+    lib.ora_scene_destroy.argtypes = [C.c_void_p]
+    import numpy as np
+    desc = data.to_desc()
+    h = C.c_void_p(lib.ora_scene_create(C.byref(desc)))
+    cam = data.camera_desc(width, height, xs, ys, depth)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    acc = np.zeros((height, width, 3), np.float32)
+    img = np.zeros((height, width, 3), np.uint8)
+
+    def run(s0, s1):
+        cnt = capi.Counters()
+        t = time.perf_counter()
+        lib.ora_render(h, C.byref(cam), cores, s0, s1, 1, acc.ctypes.data_as(C.POINTER(C.c_float)),
+                       img.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(cnt))
+        dt = time.perf_counter() - t
+        return dt, cnt.n_closest + cnt.n_any
+
+    dt1, rays1 = run(0, 1)                                # calibration stratum (also warms the caches)
+    spp = xs * ys
+    n = int(max(1, min(spp - 1, budget_s / max(dt1, 1e-3))))
+    dt, rays = run(1, 1 + n)
+    lib.ora_scene_destroy(h)
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"strata 1..{n} of {spp} of the same {width}x{height} frame ({rays} rays, {dt:.2f} s), "
+                      "oracle built -O3 -ffast-math, one barrier per sample pass"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_1920x1080_64spp_d8", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--atrium-tris", type=int, default=262144)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import jtx_pathtracer_amd as jtx
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (see the docstring)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    jtx._capi.check(jtx._capi.load().jtx_mi_set_device(local_rank))
+
+    factory, W, H, xs, ys, depth = WORKLOADS[args.workload]
+    data = getattr(jtx.scenes, factory)(args.atrium_tris) if factory == "atrium" else getattr(jtx.scenes, factory)()
+    t0 = time.perf_counter()
+    scene = jtx.Scene(data)
+    scene.buildBVH()
+    t_upload = time.perf_counter() - t0
+    cam = data.camera_desc(W, H, xs, ys, depth)
+    acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+    # a non-default torch stream: the kernel launch, the HIP events around it and the RCCL reduce are
+    # all ordered on it (stream 0 would mean "the library's own stream" to jtx_mi_render_device)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    lib = jtx._capi.load()
+
+    def step(count=False):
+        jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count)
+        jtx.distributed.reduce_frame(acc, img, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # counted pass: deterministic ray / node / triangle tallies of this rank's shard (untimed)
+    step(count=True)
+    fence()
+    cnt = jtx._capi.Counters()
+    jtx._capi.check(lib.jtx_mi_get_counters(scene.handle, C.byref(cnt)))
+    mine = cnt.as_dict()
+    keys = sorted(mine)
+    tot = torch.tensor([mine[k] for k in keys], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot)
+    total = dict(zip(keys, [int(v) for v in tot.tolist()]))
+    rays_frame = total["n_closest"] + total["n_any"]
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ms = C.c_float(); nl = C.c_int32()
+    jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))   # drop warm-up events
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t
+    jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
+    kernel_ms = ms.value / max(1, nl.value)
+
+    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        value = rays_frame * args.steps / elapsed / 1e6
+        my_bytes = algorithmic_bytes(mine)               # rank 0's launch
+        achieved = my_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("workload") == args.workload and world == 1:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene_triangles": data.num_triangles, "width": W, "height": H,
+                       "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
+                       "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
+                       "parallelism": f"pixel-tile shard x{world} + 1 reduce/frame" if world > 1 else "1 gpu",
+                       "scene_upload_ms": round(t_upload * 1e3, 2),
+                       "integrator": "pixel-persistent", "lds_resident_bvh": scene.info()["lds_resident"]},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                         "kernel": "k_render_pixels", "kernel_ms": round(kernel_ms, 3),
+                         "algorithmic_bytes_per_launch": my_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(data, W, H, xs, ys, depth)
+            except Exception as e:                        # report, never hide
+                out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
