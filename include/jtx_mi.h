@@ -104,10 +104,10 @@ typedef struct {
     int32_t sample_end;       /* one past the last stratum; <= 0 => xs*ys */
     int32_t tile_rank;        /* multi-GPU pixel-tile sharding: this process owns 32x32 tiles k with */
     int32_t tile_world;       /*   k % tile_world == tile_rank (0/0 or 0/1 => whole frame) */
-    int32_t integrator;       /* 0 auto, 1 pixel-persistent megakernel, 2 queued wavefront */
+    int32_t integrator;       /* 0 auto (= 2; env JTX_INTEGRATOR overrides), 1 pixel-persistent kernel, 2 wavefront */
     int32_t count_rays;       /* != 0: accumulate jtx_mi_counters on the device (slower) */
     int32_t samples_per_tick; /* progress callback granularity for jtx_mi_render; <= 0 => all */
-    int32_t reserved;
+    int32_t reserved;         /* bit 0: time every wavefront kernel with its own HIP events (jtx_mi_kernel_time_by_kind) */
 } jtx_mi_render_opts;
 
 /* ray / traffic counters */
@@ -158,6 +158,9 @@ int jtx_mi_sync(jtx_mi_scene *scene);
 /* GPU time of the integrator kernel(s) of the last render call(s) since the previous query,
  * from HIP events recorded on the launch stream: sum in ms and number of launches. */
 int jtx_mi_kernel_time(jtx_mi_scene *scene, float *ms_total, int32_t *launches);
+/* Wavefront renders with opts.reserved bit 0: summed GPU ms and launch count per kernel kind since the last
+ * query: [0] generate, [1] trace closest, [2] shade, [3] trace any (shadow), [4] resolve. */
+int jtx_mi_kernel_time_by_kind(jtx_mi_scene *scene, float *ms5, int32_t *n5);
 int jtx_mi_get_counters(jtx_mi_scene *scene, jtx_mi_counters *out);  /* of the last count_rays render */
 
 /* Fine-grained entry points for parity tests (HOST buffers; blocking). */

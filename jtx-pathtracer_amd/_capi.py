@@ -101,6 +101,7 @@ SYMBOLS = {
     "jtx_mi_render_device": (C.c_int, [_scene, P(CameraDesc), P(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]),
     "jtx_mi_sync": (C.c_int, [_scene]),
     "jtx_mi_kernel_time": (C.c_int, [_scene, _f, _i]),
+    "jtx_mi_kernel_time_by_kind": (C.c_int, [_scene, _f, _i]),
     "jtx_mi_get_counters": (C.c_int, [_scene, P(Counters)]),
     "jtx_mi_closest_hit_batch": (C.c_int, [_scene, C.c_int32, _f, _f, C.c_float, C.c_float, _i, _f, _i, _f, _f, _f, _f, _f]),
     "jtx_mi_any_hit_batch": (C.c_int, [_scene, C.c_int32, _f, _f, _f, _f, _i]),

@@ -212,7 +212,8 @@ class StaticCamera:
         c.x_pixel_samples, c.y_pixel_samples, c.max_depth = self.xPixelSamples_, self.yPixelSamples_, self.maxDepth_
         return c
 
-    def render(self, scene, count_rays=False, progress=None, tile_rank=0, tile_world=1, sample_begin=0, sample_end=0):
+    def render(self, scene, count_rays=False, progress=None, tile_rank=0, tile_world=1, sample_begin=0, sample_end=0,
+               integrator=0):
         """StaticCamera::render(const Scene&) (camera.cpp:45-128)."""
         self.stopRender_ = False
         self.currentSample_ = 0
@@ -220,6 +221,7 @@ class StaticCamera:
         o.count_rays = 1 if count_rays else 0
         o.tile_rank, o.tile_world = tile_rank, tile_world
         o.sample_begin, o.sample_end = sample_begin, sample_end
+        o.integrator = integrator
         o.samples_per_tick = self.samplesPerPass_ if progress is not None else 0
 
         def _cb(cur, total, _user):

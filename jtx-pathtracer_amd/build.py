@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libjtx_mi.so")
-SOURCES = ["jtx_kernels.hip", "jtx_capi.hip", "jtx_bvh_build.cpp"]
+SOURCES = ["jtx_kernels.hip", "jtx_wavefront.hip", "jtx_capi.hip", "jtx_bvh_build.cpp"]
 HEADERS = ["jtx_device_math.hpp", "jtx_bxdf.hpp", "jtx_scene_dev.hpp", "jtx_launch.hpp", "jtx_host.hpp",
            os.path.join("..", "..", "include", "jtx_mi.h")]
 # -ffp-contract=off: device results must equal the strict-fp32 CPU oracle bit for bit.
@@ -33,7 +33,7 @@ def build_all(force=False, verbose=False):
     """Compile every HIP source into jtx-pathtracer_amd/libjtx_mi.so.  Returns the library path."""
     if not force and lib_is_built():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + SOURCES
+    cmd = [_hipcc()] + FLAGS + os.environ.get("JTX_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

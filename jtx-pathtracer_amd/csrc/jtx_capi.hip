@@ -7,6 +7,7 @@
 #include "jtx_launch.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -48,6 +49,15 @@ struct jtx_mi_scene {
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;
     DevScene dev{};
+    // wavefront integrator state (sized for pixels * strata-per-batch slots)
+    DevBuf<float> wf_floats;         // all float SoA arrays, carved
+    DevBuf<float4> wf_hit;
+    DevBuf<int> wf_ints;             // flags, depth, rng
+    DevBuf<unsigned> wf_heads;       // one work-queue head per launch
+    size_t wf_slots = 0, wf_nheads = 0;
+    int num_cus = 256;
+    float ms_by_kind[5] = {0, 0, 0, 0, 0};   // generate, trace-closest, shade, trace-any, resolve (profiled renders)
+    int   n_by_kind[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;
     size_t device_bytes = 0;
@@ -103,8 +113,8 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         const int meta = (int) n.num_prims | ((int) n.axis << 16);
         float fo, fm;
         std::memcpy(&fo, &n.offset, 4); std::memcpy(&fm, &meta, 4);
-        nodes[2 * i + 0] = make_float4(n.pmin[0], n.pmin[1], n.pmin[2], n.pmax[0]);
-        nodes[2 * i + 1] = make_float4(n.pmax[1], n.pmax[2], fo, fm);
+        nodes[2 * i + 0] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);   // (near, far) pairs per axis
+        nodes[2 * i + 1] = make_float4(n.pmin[2], n.pmax[2], fo, fm);
     }
     for (size_t i = 0; i < np; ++i) {
         const jtx_mi_mesh &m = d.meshes[b.refs[i].mesh_index];
@@ -226,6 +236,93 @@ std::pair<hipEvent_t, hipEvent_t> takeEvents(jtx_mi_scene &s) {
     return e;
 }
 
+// ---- wavefront integrator orchestration ----
+// strata per batch: the batch's slot arrays (~132 B/slot) should stay near the 256 MiB Infinity Cache
+int wfStrataPerBatch(int pixels, int nstrata) {
+    const char *e = getenv("JTX_WF_BATCH");
+    int b = e ? atoi(e) : 0;
+    if (b <= 0) { b = (int) (((size_t) 16 << 20) / (size_t) (pixels > 0 ? pixels : 1)); if (b < 1) b = 1; }
+    if (b > nstrata) b = nstrata;
+    return b;
+}
+
+void wfEnsureBuffers(jtx_mi_scene &s, size_t slots, size_t nheads) {
+    if (s.wf_slots < slots) {
+        s.wf_floats.alloc(25 * slots); s.wf_hit.alloc(slots); s.wf_ints.alloc(4 * slots);
+        s.wf_slots = slots;
+    }
+    if (s.wf_nheads < nheads) { s.wf_heads.alloc(nheads); s.wf_nheads = nheads; }
+}
+
+struct KindTimer {          // optional per-kernel HIP events (opts.reserved & 1)
+    jtx_mi_scene &s; bool on; hipStream_t st;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> evs;
+    void begin(int kind) { if (!on) return; std::pair<hipEvent_t, hipEvent_t> e; HIPCHK(hipEventCreate(&e.first)); HIPCHK(hipEventCreate(&e.second));
+                           HIPCHK(hipEventRecord(e.first, st)); evs.push_back({kind, e}); }
+    void end() { if (!on) return; HIPCHK(hipEventRecord(evs.back().second.second, st)); }
+    void collect() {
+        if (!on) return;
+        for (auto &k : evs) {
+            HIPCHK(hipEventSynchronize(k.second.second));
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, k.second.first, k.second.second));
+            s.ms_by_kind[k.first] += ms; s.n_by_kind[k.first]++;
+            (void) hipEventDestroy(k.second.first); (void) hipEventDestroy(k.second.second);
+        }
+        evs.clear();
+    }
+};
+
+void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
+                     float *d_acc, unsigned char *d_img, hipStream_t stream, int rank, int world) {
+    WfParams p{};
+    p.scene = s.dev;
+    p.cam = deriveCamera(cam);
+    p.width = cam.width; p.height = cam.height; p.max_depth = cam.max_depth;
+    p.tile_rank = rank; p.tile_world = world;
+    p.tiles_x = (cam.width + 31) / 32;
+    const int tiles = p.tiles_x * ((cam.height + 31) / 32);
+    const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
+    if (owned == 0) return;
+    p.pixels = owned * 1024;
+    const int nstrata = se - sb;
+    const int B = wfStrataPerBatch(p.pixels, nstrata);
+    p.num_slots = p.pixels * B;
+    const int batches = (nstrata + B - 1) / B;
+    const int D = cam.max_depth;
+    wfEnsureBuffers(s, (size_t) p.num_slots, 0);
+    const size_t N = s.wf_slots;
+    float *f = s.wf_floats.p;
+    WfBuffers &b = p.b;
+    b.rox = f + 0 * N; b.roy = f + 1 * N; b.roz = f + 2 * N; b.rdx = f + 3 * N; b.rdy = f + 4 * N; b.rdz = f + 5 * N;
+    b.betax = f + 6 * N; b.betay = f + 7 * N; b.betaz = f + 8 * N; b.radx = f + 9 * N; b.rady = f + 10 * N; b.radz = f + 11 * N;
+    b.sox = f + 12 * N; b.soy = f + 13 * N; b.soz = f + 14 * N; b.sdx = f + 15 * N; b.sdy = f + 16 * N; b.sdz = f + 17 * N;
+    b.stmax = f + 18 * N; b.pendx = f + 19 * N; b.pendy = f + 20 * N; b.pendz = f + 21 * N;
+    b.hit = s.wf_hit.p;
+    b.flags = s.wf_ints.p; b.depth = s.wf_ints.p + N; b.rng = (unsigned *) (s.wf_ints.p + 2 * N); b.sflags = s.wf_ints.p + 3 * N;
+    p.acc = d_acc; p.img = d_img;
+    const bool count = o.count_rays != 0;
+    if (count) {
+        if (!s.counters.p) s.counters.alloc(32);
+        HIPCHK(hipMemsetAsync(s.counters.p, 0, 32 * sizeof(unsigned long long), stream));
+    }
+    p.counters = count ? s.counters.p : nullptr;
+    const int grid = s.num_cus * 8;
+    KindTimer kt{s, (o.reserved & 1) != 0, stream, {}};
+    const bool hasLights = s.dev.num_lights > 0;
+    for (int bi = 0; bi < batches; ++bi) {
+        const int s0 = sb + bi * B;
+        const int ns = (s0 + B <= se) ? B : se - s0;
+        kt.begin(0); HIPCHK(jtx_wf_generate(p, s0, ns, stream)); kt.end();
+        for (int r = 0; r <= D; ++r) {
+            kt.begin(1); HIPCHK(jtx_wf_trace(p, 0, grid, count, stream)); kt.end();
+            kt.begin(2); HIPCHK(jtx_wf_shade(p, grid, count, stream)); kt.end();
+            if (hasLights && r < D) { kt.begin(3); HIPCHK(jtx_wf_trace(p, 1, grid, count, stream)); kt.end(); }
+        }
+        kt.begin(4); HIPCHK(jtx_wf_resolve(p, s0, ns, (s0 + ns == se) ? 1 : 0, stream)); kt.end();
+    }
+    kt.collect();
+}
+
 // One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
                   float *d_acc, unsigned char *d_img, hipStream_t stream) {
@@ -244,14 +341,17 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     p.acc = d_acc; p.img = d_img;
     const bool count = o.count_rays != 0;
     if (count) {
-        if (!s.counters.p) s.counters.alloc(9);
-        if (sb == 0 || true) HIPCHK(hipMemsetAsync(s.counters.p, 0, 9 * sizeof(unsigned long long), stream));
+        if (!s.counters.p) s.counters.alloc(32);
+        HIPCHK(hipMemsetAsync(s.counters.p, 0, 32 * sizeof(unsigned long long), stream));
     }
     p.counters = s.counters.p;
-    if (o.integrator != 0 && o.integrator != 1) throw std::runtime_error("integrator: 0 (auto) or 1 (pixel-persistent) are available");
+    if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (wavefront)");
+    int integ = o.integrator;
+    if (integ == 0) { const char *e = getenv("JTX_INTEGRATOR"); integ = e ? atoi(e) : 0; if (integ < 1 || integ > 2) integ = 2; }
     auto ev = takeEvents(s);
     HIPCHK(hipEventRecord(ev.first, stream));
-    HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
+    if (integ == 1) HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
+    else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
     HIPCHK(hipEventRecord(ev.second, stream));
     s.pending.push_back(ev);
 }
@@ -305,6 +405,7 @@ int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
         if (s->bvh.max_depth > 120) throw std::runtime_error("BVH deeper than 120 levels: LDS traversal stack would not fit");
         flatten(*desc, *s);
         HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, s->device)); s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
         *out = s;
         return 0;
     } catch (const std::exception &e) { delete s; return fail(e.what()); }
@@ -372,6 +473,21 @@ int jtx_mi_kernel_time(jtx_mi_scene *s, float *ms_total, int32_t *launches) {
         if (launches) *launches = n;
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+#ifdef JTX_PROFILE_PHASES
+int jtx_mi_debug_phases(jtx_mi_scene *s, unsigned long long *out6) {   // diagnostic builds only
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out6, s->counters.p + 16, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+
+int jtx_mi_kernel_time_by_kind(jtx_mi_scene *s, float *ms5, int32_t *n5) {
+    if (!s || !ms5 || !n5) return fail("null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (int i = 0; i < 5; ++i) { ms5[i] = s->ms_by_kind[i]; n5[i] = s->n_by_kind[i]; s->ms_by_kind[i] = 0; s->n_by_kind[i] = 0; }
+    return 0;
 }
 
 int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {

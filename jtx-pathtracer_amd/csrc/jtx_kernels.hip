@@ -40,12 +40,25 @@ struct PathState {
     f3 o, d, beta, radiance;
     Rng rng;
     int depth;
+#ifdef JTX_PROFILE_PHASES
+    long long ph[6];
+#endif
 };
+
+#ifdef JTX_PROFILE_PHASES
+#define PH_DECL long long ph_t = clock64();
+#define PH(i) { long long n_ = clock64(); ps.ph[i] += n_ - ph_t; ph_t = n_; }
+#else
+#define PH_DECL
+#define PH(i)
+#endif
 
 template <bool COUNT, class Src>
 JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int maxDepth, PathState &ps, Counters9 &cnt) {
     HitRec h;
+    PH_DECL
     const bool hit = traverse<false, COUNT>(src, sc.num_nodes, stk, stride, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
+    PH(0)
     if (!hit) {                                                       // integrator.cpp:183-187
         ps.radiance = ps.radiance + ps.beta * a3(sc.sky);
         return true;
@@ -64,8 +77,10 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int
             const f3 sOrigin = sf.point + sf.normal * RAY_EPSILON;
             const float lDist = len(sf.point - ls.p);
             HitRec dummy;
+            PH(1)
             const bool occluded = traverse<true, COUNT>(src, sc.num_nodes, stk, stride, sOrigin, ls.wi, 0.0f,
                                                         lDist - RAY_EPSILON, dummy, cnt);
+            PH(2)
             if (!occluded) {
                 f3 f; float pb;
                 evalPdfBxdf(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
@@ -76,6 +91,7 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int
             }
         }
     }
+    PH(3)
     const float u = ps.rng.f();
     f2 u2; u2.x = ps.rng.f(); u2.y = ps.rng.f();
     BSample bs;
@@ -84,6 +100,7 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int
     if (bs.pdf > 0.0f) ps.beta = ps.beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);
     ps.o = sf.point + bs.wi * RAY_EPSILON;                             // integrator.cpp:212
     ps.d = bs.wi;
+    PH(4)
     return false;
 }
 
@@ -126,6 +143,10 @@ __global__ void __launch_bounds__(BLOCK) k_render_pixels(RenderParams p) {
         if (p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
         int s = p.sample_begin;
         PathState ps;
+#ifdef JTX_PROFILE_PHASES
+        for (int i = 0; i < 6; ++i) ps.ph[i] = 0;
+        long long k0 = clock64();
+#endif
         bool alive = s < p.sample_end;
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
@@ -145,6 +166,12 @@ __global__ void __launch_bounds__(BLOCK) k_render_pixels(RenderParams p) {
                 else alive = false;
             }
         }
+#ifdef JTX_PROFILE_PHASES
+        if (p.counters && lane == 0) {     // diagnostic build: per-phase wave cycles of lane 0's view
+            for (int i = 0; i < 5; ++i) atomicAdd(&p.counters[16 + i], (unsigned long long) ps.ph[i]);
+            atomicAdd(&p.counters[16 + 5], (unsigned long long) (clock64() - k0));
+        }
+#endif
         p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
         if (p.img) {
             const float inv = (float) p.sample_end;                    // currSample + 1 of the last pass (camera.cpp:115)

@@ -16,7 +16,40 @@ struct RenderParams {
     unsigned long long *counters;  // 9 x u64 or null
 };
 
+// ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
+enum { WF_LIVE = 1 };                                   // flags[]: extension ray pending / hit ready
+enum { WF_SH_PENDING = 1, WF_SH_UNOCCLUDED = 2 };       // sflags[]: shadow ray to trace / traced and unoccluded
+
+struct WfBuffers {
+    int   *flags;                                   // WF_LIVE
+    int   *sflags;                                  // WF_SH_*
+    float *rox, *roy, *roz, *rdx, *rdy, *rdz;       // extension ray (Ray, integrator.cpp:212)
+    float4 *hit;                                    // {t, b1, b2, asfloat(prim or -1)}
+    float *betax, *betay, *betaz;                   // path throughput
+    float *radx, *rady, *radz;                      // path radiance
+    unsigned *rng; int *depth;
+    float *sox, *soy, *soz, *sdx, *sdy, *sdz, *stmax;   // shadow ray (integrator.cpp:146-150)
+    float *pendx, *pendy, *pendz;                   // what the shadow ray adds when unoccluded
+};
+
+struct WfParams {
+    DevScene scene;
+    DCam     cam;
+    WfBuffers b;
+    int width, height, max_depth;
+    int tile_rank, tile_world, tiles_x;
+    int pixels;                    // owned 32x32 tiles * 1024 (padded)
+    int num_slots;                 // pixels * strata per batch
+    float *acc; unsigned char *img;
+    unsigned long long *counters;
+};
+
 } // namespace jtx
+
+hipError_t jtx_wf_generate(const jtx::WfParams &p, int s0, int nstrata, hipStream_t st);
+hipError_t jtx_wf_trace(const jtx::WfParams &p, int any, int grid, bool count, hipStream_t st);
+hipError_t jtx_wf_shade(const jtx::WfParams &p, int grid, bool count, hipStream_t st);
+hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write_img, hipStream_t st);
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_closest_batch(const jtx::DevScene &sc, int n, const float *o, const float *d, float tmin, float tmax,

@@ -1,7 +1,7 @@
 // jtx_scene_dev.hpp -- device scene layout and the BVH traversal / ray-triangle stage.
 //
 // HBM layout (built once per scene by jtx_mi_scene_create, see DESIGN.md "Data layout"):
-//   nodes : 2 x float4 per node  [pmin.xyz pmax.x] [pmax.yz asfloat(offset) asfloat(num_prims | axis<<16)]
+//   nodes : 2 x float4 per node  [min.x max.x min.y max.y] [min.z max.z asfloat(offset) asfloat(num_prims | axis<<16)]
 //           -- the reference's 32-B LinearBVHNode (bvh.hpp:7-15) re-packed so one node = two 16-B lanes
 //              of one dwordx4 pair (a 128-B gfx950 cache line holds 4 nodes; the implicit first child
 //              cur+1 shares the parent's line 3 times out of 4).
@@ -51,89 +51,146 @@ struct LdsSrc {           // pointers into the workgroup's LDS copy
 
 struct HitRec { float t; int prim; float b1, b2; };
 
-// Scene::closestHit (scene.cpp:10-55) / Scene::anyHit (scene.cpp:57-94) with AABB::hit
-// (aabb.hpp:66-81) and Mesh::tClosestHit / tAnyHit (mesh.hpp:106-192) inlined.
+// Moller-Trumbore, Mesh::tClosestHit / tAnyHit (mesh.hpp:106-127, 168-192) on the pre-baked record.
+//  |det| < 1e-8 is a double compare in the reference (mesh.hpp:114); for a float |det| it is
+//  equivalent to |det| <= 1e-8f because 1e-8f < 1e-8 < nextafter(1e-8f).
+template <class Src>
+JD bool triTest(const Src &src, int prim, f3 o, f3 d, float tmin, float tmax, float &b1, float &b2, float &root) {
+    const float4 q0 = src.tri(prim, 0), q1 = src.tri(prim, 1), q2 = src.tri(prim, 2);
+    const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
+    const f3 pvec = cross(d, e2);
+    const float det = dot(e1, pvec);
+    if (fabsf(det) <= 1e-8f) return false;
+    const float invDet = 1.0f / det;
+    const f3 tvec = o - v0;
+    b1 = dot(tvec, pvec) * invDet;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    const f3 qvec = cross(tvec, e1);
+    b2 = dot(d, qvec) * invDet;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
+    root = dot(e2, qvec) * invDet;
+    return tmin < root && root < tmax;
+}
+
+// AABB::hit (aabb.hpp:66-81) exactly as written, for rays the fast form below cannot take.
 //  * 1/d is computed once per ray: aabb.hpp:71 recomputes the same quotient at every node.
 //  * The per-axis early-out of aabb.hpp:78 is folded into one test after the third axis: t0 only
 //    grows and t1 only shrinks (a NaN candidate is never selected by either ternary), so
 //    "t0 > t1 after some axis" <=> "t0 > t1 after the last axis".
-//  * |det| < 1e-8 is a double compare in the reference (mesh.hpp:114); for a float |det| it is
-//    equivalent to |det| <= 1e-8f because 1e-8f < 1e-8 < nextafter(1e-8f).
+JD bool slabExact(const float4 na, const float4 nb, f3 o, f3 inv, float t0, float t1) {
+    {
+        float tn = (na.x - o.x) * inv.x, tf = (na.y - o.x) * inv.x;
+        float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
+        t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
+    }
+    {
+        float tn = (na.z - o.y) * inv.y, tf = (na.w - o.y) * inv.y;
+        float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
+        t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
+    }
+    {
+        float tn = (nb.x - o.z) * inv.z, tf = (nb.y - o.z) * inv.z;
+        float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
+        t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
+    }
+    return !(t0 > t1);
+}
+
+// The same test for a REGULAR ray: every 1/d finite and non-zero, origin finite, interval not NaN.
+// Then tNear/tFar are never NaN (no 0*inf, no inf-inf), so the reference's compare-and-swap is
+// min/max of the pair and its running t0/t1 ternaries are max/min chains (associative up to the sign
+// of zero, which only ever feeds the comparison t0 > t1).  17 VALU instead of ~40.
+JD bool slabRegular(const float4 na, const float4 nb, f3 o, f3 inv, float tmin, float tmax) {
+    const float ax = (na.x - o.x) * inv.x, bx = (na.y - o.x) * inv.x;
+    const float ay = (na.z - o.y) * inv.y, by = (na.w - o.y) * inv.y;
+    const float az = (nb.x - o.z) * inv.z, bz = (nb.y - o.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return t0 <= t1;
+}
+
+JD bool finiteNonZero(float x) { return fabsf(x) < __builtin_inff() && x != 0.0f; }
+
+// Scene::closestHit (scene.cpp:10-55) / Scene::anyHit (scene.cpp:57-94).
+// "while-while" form: every lane first walks interior nodes until it stands on a leaf whose box it
+// hits (or its stack runs dry), then the wave tests leaf triangles together -- the visit ORDER per
+// ray, the near-child-first rule (dirIsNeg[axis], scene.cpp:40-46) and the shrinking t.max are
+// exactly the reference's; only the interleaving between lanes differs.
 //  * stack: one LDS column per lane (stk[level * stride]), depth bounded by the BVH build.
+#ifndef JTX_LEAF_VOTE
+#define JTX_LEAF_VOTE 20      // lanes parked on a leaf that end the interior phase of a wave
+#endif
+
+template <bool ANY, bool COUNT, bool REGULAR, class Src>
+JD bool traverseT(const Src &src, int *stk, int stride, f3 o, f3 d, f3 inv, int negmask, float tmin, float tmax,
+                  HitRec &rec, Counters9 &cnt) {
+    int sp = 0, cur = 0;
+    bool hitAnything = false;
+    if (COUNT) { if (ANY) cnt.n_any++; else cnt.n_closest++; }
+    // Per lane: WALK (cur = node to visit), PARKED on a leaf (leafN > 0) or DONE (cur < 0).
+    // The wave alternates two phases.  Interior phase: every walking lane visits one node per
+    // iteration; it ends when no lane walks any more or when JTX_LEAF_VOTE lanes are parked.  Leaf
+    // phase: the parked lanes test their leaf's triangles together, then pop.  A parked lane simply
+    // waits, so each ray still sees exactly the reference's visit order and shrinking t.max.
+    int leafOff = 0, leafN = 0;
+    while (true) {
+        while (true) {
+            if (leafN == 0 && cur >= 0) {
+                const float4 na = src.node(cur, 0);
+                const float4 nb = src.node(cur, 1);
+                if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
+                const bool boxHit = REGULAR ? slabRegular(na, nb, o, inv, tmin, tmax) : slabExact(na, nb, o, inv, tmin, tmax);
+                if (boxHit) {
+                    const int meta = __float_as_int(nb.w);
+                    const int off = __float_as_int(nb.z);
+                    if ((meta & 0xffff) != 0) { leafOff = off; leafN = meta & 0xffff; }
+                    else {
+                        const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
+                        stk[sp * stride] = neg ? cur + 1 : off;
+                        sp++;
+                        cur = neg ? off : cur + 1;
+                    }
+                } else {
+                    if (sp == 0) cur = -1;
+                    else { --sp; cur = stk[sp * stride]; }
+                }
+            }
+            const unsigned long long walking = __ballot(leafN == 0 && cur >= 0);
+            const unsigned long long parked = __ballot(leafN > 0);
+            if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE) break;
+        }
+        if (__ballot(leafN > 0) == 0ull) break;            // wave-uniform: every lane is DONE
+        if (leafN > 0) {
+            for (int i = 0; i < leafN; ++i) {
+                const int prim = leafOff + i;
+                if (COUNT) { if (ANY) cnt.n_tri_any++; else cnt.n_tri_closest++; }
+                float b1, b2, root;
+                if (!triTest(src, prim, o, d, tmin, tmax, b1, b2, root)) continue;
+                hitAnything = true;
+                if (ANY) break;
+                tmax = root;
+                rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+                if (COUNT) cnt.n_accept++;
+            }
+            leafN = 0;
+            if ((ANY && hitAnything) || sp == 0) cur = -1;
+            else { --sp; cur = stk[sp * stride]; }
+        }
+    }
+    return hitAnything;
+}
+
 template <bool ANY, bool COUNT, class Src>
 JD bool traverse(const Src &src, int num_nodes, int *stk, int stride, f3 o, f3 d, float tmin, float tmax,
                  HitRec &rec, Counters9 &cnt) {
     if (num_nodes == 0) return false;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-    const int negmask = (ix < 0.0f ? 1 : 0) | (iy < 0.0f ? 2 : 0) | (iz < 0.0f ? 4 : 0);
-    int sp = 0, cur = 0;
-    bool hitAnything = false;
-    if (COUNT) { if (ANY) cnt.n_any++; else cnt.n_closest++; }
-    while (true) {
-        const float4 na = src.node(cur, 0);
-        const float4 nb = src.node(cur, 1);
-        if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
-        float t0 = tmin, t1 = tmax;
-        {
-            float tn = (na.x - o.x) * ix, tf = (na.w - o.x) * ix;
-            float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
-            t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
-        }
-        {
-            float tn = (na.y - o.y) * iy, tf = (nb.x - o.y) * iy;
-            float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
-            t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
-        }
-        {
-            float tn = (na.z - o.z) * iz, tf = (nb.y - o.z) * iz;
-            float lo = tn > tf ? tf : tn, hi = tn > tf ? tn : tf;
-            t0 = lo > t0 ? lo : t0; t1 = hi < t1 ? hi : t1;
-        }
-        bool descend = false;
-        if (!(t0 > t1)) {
-            const int meta = __float_as_int(nb.w);
-            const int off = __float_as_int(nb.z);
-            const int nprims = meta & 0xffff;
-            if (nprims > 0) {
-                for (int i = 0; i < nprims; ++i) {
-                    const int prim = off + i;
-                    const float4 q0 = src.tri(prim, 0), q1 = src.tri(prim, 1), q2 = src.tri(prim, 2);
-                    if (COUNT) { if (ANY) cnt.n_tri_any++; else cnt.n_tri_closest++; }
-                    const f3 v0 = mk3(q0.x, q0.y, q0.z), e1 = mk3(q0.w, q1.x, q1.y), e2 = mk3(q1.z, q1.w, q2.x);
-                    const f3 pvec = cross(d, e2);
-                    const float det = dot(e1, pvec);
-                    if (fabsf(det) <= 1e-8f) continue;
-                    const float invDet = 1.0f / det;
-                    const f3 tvec = o - v0;
-                    const float b1 = dot(tvec, pvec) * invDet;
-                    if (b1 < 0.0f || b1 > 1.0f) continue;
-                    const f3 qvec = cross(tvec, e1);
-                    const float b2 = dot(d, qvec) * invDet;
-                    if (b2 < 0.0f || b1 + b2 > 1.0f) continue;
-                    const float root = dot(e2, qvec) * invDet;
-                    if (!(tmin < root && root < tmax)) continue;
-                    if (ANY) return true;
-                    hitAnything = true;
-                    tmax = root;
-                    rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
-                    if (COUNT) cnt.n_accept++;
-                }
-            } else {
-                const int axis = (meta >> 16) & 0xff;
-                const bool neg = (negmask >> axis) & 1;
-                stk[sp * stride] = neg ? cur + 1 : off;
-                sp++;
-                cur = neg ? off : cur + 1;
-                descend = true;
-            }
-        }
-        if (!descend) {
-            if (sp == 0) break;
-            --sp;
-            cur = stk[sp * stride];
-        }
-    }
-    return hitAnything;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+    const bool regular = finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
+                         fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
+                         tmin == tmin && tmax == tmax;
+    if (__builtin_expect(regular, 1)) return traverseT<ANY, COUNT, true>(src, stk, stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
+    return traverseT<ANY, COUNT, false>(src, stk, stride, o, d, inv, negmask, tmin, tmax, rec, cnt);   // axis-parallel & co.
 }
 
 struct Surface { f3 point, normal; f2 uv; int material; };

@@ -32,7 +32,7 @@ def owned_tiles(width, height, rank, world):
 
 
 def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count_rays=False,
-                 sample_begin=0, sample_end=0):
+                 sample_begin=0, sample_end=0, integrator=0, profile_kernels=False):
     """Launch this rank's share of the frame into device tensors `acc` (H*W*3 f32) / `img` (H*W*3 u8).
 
     Asynchronous on `stream` (an int hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).
@@ -42,6 +42,8 @@ def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count
     o.tile_rank, o.tile_world = rank, world
     o.count_rays = 1 if count_rays else 0
     o.sample_begin, o.sample_end = sample_begin, sample_end
+    o.integrator = integrator
+    o.reserved = 1 if profile_kernels else 0
     capi.check(lib.jtx_mi_render_device(scene.handle, C.byref(cam_desc), C.byref(o),
                                         C.c_void_p(acc.data_ptr()),
                                         C.c_void_p(img.data_ptr()) if img is not None else None,

@@ -156,29 +156,32 @@ def _render_both(gpu, data, sc, osc, w, h, xs, ys, depth, **kw):
     return cam_g, acc, img, cnt
 
 
-def test_render_config1_cornell_512(gpu, cornell_pair):
-    """BASELINE config 1: Cornell 512x512, 16 spp (4x4), depth 4 -- whole frame, bit-exact."""
+@pytest.mark.parametrize("integrator", [1, 2])
+def test_render_config1_cornell_512(gpu, cornell_pair, integrator):
+    """BASELINE config 1: Cornell 512x512, 16 spp (4x4), depth 4 -- whole frame, bit-exact, both integrators."""
     data, sc, osc = cornell_pair
-    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 512, 512, 4, 4, 4)
+    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 512, 512, 4, 4, 4, integrator=integrator)
     assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
     assert (cam_g.img_ == img).all()
     assert cam_g.counters == cnt
     assert cnt["n_camera"] == 512 * 512 * 16
 
 
-def test_render_mixed_small(gpu, mixed_pair):
+@pytest.mark.parametrize("integrator", [1, 2])
+def test_render_mixed_small(gpu, mixed_pair, integrator):
     data, sc, osc = mixed_pair
-    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 200, 120, 2, 2, 8)
+    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 200, 120, 2, 2, 8, integrator=integrator)
     assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
     assert (cam_g.img_ == img).all()
     assert cam_g.counters == cnt
 
 
-def test_render_ragged_sizes(gpu, cornell_pair):
+@pytest.mark.parametrize("integrator", [1, 2])
+def test_render_ragged_sizes(gpu, cornell_pair, integrator):
     """widths/heights that are not multiples of the 8x8 wave block or the 32x32 tile; 1x1 image."""
     data, sc, osc = cornell_pair
     for (w, h) in [(1, 1), (33, 7), (70, 45)]:
-        cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, w, h, 2, 1, 3)
+        cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, w, h, 2, 1, 3, integrator=integrator)
         assert_same_f32(cam_g.acc_, acc, f"acc {w}x{h}")
         assert (cam_g.img_ == img).all()
         assert cam_g.counters == cnt
@@ -204,15 +207,16 @@ def test_render_resume_and_progress(gpu, cornell_pair):
     assert stop.currentSample_ == 2
 
 
-def test_render_tile_sharding(gpu, cornell_pair):
+@pytest.mark.parametrize("integrator", [1, 2])
+def test_render_tile_sharding(gpu, cornell_pair, integrator):
     """pixel-tile shards of 3 ranks are disjoint, zero elsewhere, and sum to the 1-GPU frame exactly."""
     data, sc, osc = cornell_pair
-    full = gpu.StaticCamera(200, 100, data.camera, 2, 2, 4); full.render(sc)
+    full = gpu.StaticCamera(200, 100, data.camera, 2, 2, 4); full.render(sc, integrator=integrator)
     total = np.zeros_like(full.acc_)
     cover = np.zeros(full.acc_.shape[:2], np.int32)
     for r in range(3):
         c = gpu.StaticCamera(200, 100, data.camera, 2, 2, 4)
-        c.render(sc, tile_rank=r, tile_world=3)
+        c.render(sc, tile_rank=r, tile_world=3, integrator=integrator)
         total += c.acc_
         cover += (gpu.distributed.tile_owner_mask(200, 100, r, 3)).astype(np.int32)
         assert (c.acc_[~gpu.distributed.tile_owner_mask(200, 100, r, 3)] == 0).all()

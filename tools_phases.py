@@ -1,0 +1,15 @@
+# diagnostic: per-phase wave-cycle shares (needs a build with -DJTX_PROFILE_PHASES)
+import ctypes as C, sys
+sys.path.insert(0, "/root/repo")
+import jtx_pathtracer_amd as jtx
+lib = jtx._capi.load()
+data = jtx.scenes.cornell(); sc = jtx.Scene(data); sc.buildBVH()
+cam = jtx.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+cam.render(sc, count_rays=True)
+f = lib.jtx_mi_debug_phases; f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+out = (C.c_uint64 * 6)()
+assert f(sc.handle, out) == 0
+v = list(out); tot = v[5]
+names = ["closest traversal", "surface+light sample", "shadow traversal", "eval/pdf + accumulate", "bsdf sample", "TOTAL(kernel loop)"]
+for n, x in zip(names, v): print(f"{n:28s} {x:16d} {100.0*x/tot:6.2f}%")
+print("unaccounted (regen, clamp, loop)", 100.0*(tot-sum(v[:5]))/tot)
