@@ -330,22 +330,28 @@ JD void mrParams(const ShadeCtx &c, const DMaterial &m, f2 uv, float &metallic, 
     if (m.mr_tex != -1) { f3 mr = getTexel(c.textures[m.mr_tex], c.texels, false, uv); roughness = mr.y; metallic = mr.z; }
 }
 
+// MASK = bit set of Material::Type values the scene actually contains (scene_create knows them): the
+// kernels are instantiated for "diffuse only" and "anything", so an all-Lambert scene such as the
+// Cornell box does not carry the GGX / Fresnel code (registers, I-cache) it can never reach.
+constexpr int MAT_ALL = 15, MAT_DIFFUSE_ONLY = 1;
+
 // sampleBxdf (bxdf.cpp:9-77)
+template <int MASK = MAT_ALL>
 JD bool sampleBxdf(const ShadeCtx &c, const DMaterial &m, f3 normal, f2 uv, f3 wo, float uc, f2 u, BSample &out) {
     Frame fr = Frame::fromZ(normal);
     f3 wol = fr.toLocal(wo);
     if (wol.z == 0.0f) return false;
     bool ok = false;
-    if (m.type == 3) {
+    if ((MASK & 8) && m.type == 3) {
         float metallic, roughness; mrParams(c, m, uv, metallic, roughness);
         MR b; b.mf.ax = b.mf.ay = roughness * roughness; b.albedo = albedoOf(c, m, uv); b.metallic = metallic;
         ok = mrSample(b, wol, uc, u, out);
-    } else if (m.type == 0) {
+    } else if ((MASK & 1) && m.type == 0) {
         ok = diffuseSample(albedoOf(c, m, uv), wol, u, out);
-    } else if (m.type == 2) {
+    } else if ((MASK & 4) && m.type == 2) {
         GGX g; g.ax = m.alpha_x; g.ay = m.alpha_y;
         ok = conductorSample(g, a3(m.ior), a3(m.k), wol, u, out);
-    } else if (m.type == 1) {
+    } else if ((MASK & 2) && m.type == 1) {
         GGX g; g.ax = m.alpha_x; g.ay = m.alpha_y;
         ok = dielectricSample(g, m.ior[0], wol, uc, u, out);
     }
@@ -355,25 +361,26 @@ JD bool sampleBxdf(const ShadeCtx &c, const DMaterial &m, f3 normal, f2 uv, f3 w
     return true;
 }
 // evalBxdf (bxdf.cpp:79-128) and pdfBxdf (bxdf.cpp:130-166) share the frame and the local vectors.
+template <int MASK = MAT_ALL>
 JD void evalPdfBxdf(const ShadeCtx &c, const DMaterial &m, f3 normal, f2 uv, f3 wo, f3 wi, f3 &f, float &pdf) {
     Frame fr = Frame::fromZ(normal);
     f3 wol = fr.toLocal(wo), wil = fr.toLocal(wi);
     f = mk3(0.0f); pdf = 0.0f;
     if (wol.z == 0.0f || wil.z == 0.0f) return;
-    if (m.type == 3) {
+    if ((MASK & 8) && m.type == 3) {
         float metallic, roughness; mrParams(c, m, uv, metallic, roughness);
         MR b; b.mf.ax = b.mf.ay = roughness * roughness; b.albedo = albedoOf(c, m, uv); b.metallic = metallic;
         f = mrEval(b, wol, wil);
         b.albedo = a3(m.albedo);                       // pdfBxdf uses the constant albedo (bxdf.cpp:146)
         pdf = mrPdf(b, wol, wil);
-    } else if (m.type == 0) {
+    } else if ((MASK & 1) && m.type == 0) {
         f = diffuseEval(albedoOf(c, m, uv), wol, wil);
         pdf = diffusePdf(wol, wil);
-    } else if (m.type == 2) {
+    } else if ((MASK & 4) && m.type == 2) {
         GGX g; g.ax = m.alpha_x; g.ay = m.alpha_y;
         f = conductorEval(g, a3(m.ior), a3(m.k), wol, wil);
         pdf = conductorPdf(g, wol, wil);
-    } else if (m.type == 1) {
+    } else if ((MASK & 2) && m.type == 1) {
         GGX g; g.ax = m.alpha_x; g.ay = m.alpha_y;
         f = dielectricEval(g, m.ior[0], wol, wil);
         pdf = dielectricPdf(g, m.ior[0], wol, wil);

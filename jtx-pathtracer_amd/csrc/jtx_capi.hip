@@ -188,6 +188,8 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     ds.num_nodes = (int) nn; ds.num_prims = (int) np; ds.num_lights = d.num_lights; ds.num_materials = d.num_materials;
     ds.stack_depth = b.max_depth > 0 ? b.max_depth : 1;
     ds.lds_scene = (nn > 0 && nn * 32 + np * 48 <= kLdsSceneBudget) ? 1 : 0;
+    ds.material_mask = 0;
+    for (int i = 0; i < d.num_materials; ++i) ds.material_mask |= 1 << d.materials[i].type;
     for (int k = 0; k < 3; ++k) ds.sky[k] = d.sky_color[k];
     s.device_bytes = (nodes.size() + tris.size() + shade.size()) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
                      lights.size() * sizeof(DLight) + tex.size() * sizeof(DTexture) + texels.size() * sizeof(float);
@@ -345,12 +347,13 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         HIPCHK(hipMemsetAsync(s.counters.p, 0, 32 * sizeof(unsigned long long), stream));
     }
     p.counters = s.counters.p;
-    if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (wavefront)");
+    if (o.integrator < 0 || o.integrator > 3) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront) or 3 (wave-pool)");
     int integ = o.integrator;
-    if (integ == 0) { const char *e = getenv("JTX_INTEGRATOR"); integ = e ? atoi(e) : 0; if (integ < 1 || integ > 2) integ = 2; }
+    if (integ == 0) { const char *e = getenv("JTX_INTEGRATOR"); integ = e ? atoi(e) : 0; if (integ < 1 || integ > 3) integ = 1; }   // measured fastest on LDS-resident scenes
     auto ev = takeEvents(s);
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
+    else if (integ == 3) HIPCHK(jtx_launch_render_wavepool(p, owned, count, stream));
     else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
     HIPCHK(hipEventRecord(ev.second, stream));
     s.pending.push_back(ev);

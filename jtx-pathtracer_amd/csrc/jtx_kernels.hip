@@ -53,7 +53,7 @@ struct PathState {
 #define PH(i)
 #endif
 
-template <bool COUNT, class Src>
+template <bool COUNT, int MASK, class Src>
 JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int maxDepth, PathState &ps, Counters9 &cnt) {
     HitRec h;
     PH_DECL
@@ -83,7 +83,7 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int
             PH(2)
             if (!occluded) {
                 f3 f; float pb;
-                evalPdfBxdf(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
+                evalPdfBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
                 f = f * absdot(ls.wi, sf.normal);
                 const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
                 const float misWeight = powerHeuristic(1.0f, pl, 1.0f, pb);   // applied to delta lights too (Q10)
@@ -96,7 +96,7 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int
     f2 u2; u2.x = ps.rng.f(); u2.y = ps.rng.f();
     BSample bs;
     if (COUNT) cnt.n_shade++;
-    if (!sampleBxdf(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) return true;
+    if (!sampleBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) return true;
     if (bs.pdf > 0.0f) ps.beta = ps.beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);
     ps.o = sf.point + bs.wi * RAY_EPSILON;                             // integrator.cpp:212
     ps.d = bs.wi;
@@ -116,8 +116,8 @@ JD unsigned char toByte(float v) {                                     // image.
     return (unsigned char) (int) (255.999f * c);
 }
 
-template <bool COUNT, bool LDS_SCENE>
-__global__ void __launch_bounds__(BLOCK) k_render_pixels(RenderParams p) {
+template <bool COUNT, bool LDS_SCENE, int MASK>
+__global__ void __launch_bounds__(BLOCK, 8) k_render_pixels(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
     int *stack = smem;
@@ -152,9 +152,9 @@ __global__ void __launch_bounds__(BLOCK) k_render_pixels(RenderParams p) {
         while (alive) {
             bool done;
             if (LDS_SCENE) { LdsSrc src; src.nodes = lds_nodes; src.tris = lds_tris;
-                             done = pathBounce<COUNT>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
+                             done = pathBounce<COUNT, MASK>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
             else           { GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
-                             done = pathBounce<COUNT>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
+                             done = pathBounce<COUNT, MASK>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
             if (done) {
                 f3 c = ps.radiance;                                    // camera.cpp:110-112
                 if (c.x > 1.0f) c.x = 1.0f;
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(BLOCK) k_radiance_samples(DevScene sc, DCam ca
     PathState ps;
     startPath(cam, row[i], col[i], sample[i], ps);
     GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
-    while (!pathBounce<false>(sc, src, smem + threadIdx.x, BLOCK, maxDepth, ps, cnt)) {}
+    while (!pathBounce<false, MAT_ALL>(sc, src, smem + threadIdx.x, BLOCK, maxDepth, ps, cnt)) {}
     f3 c = ps.radiance;
     if (c.x > 1.0f) c.x = 1.0f;
     if (c.y > 1.0f) c.y = 1.0f;
@@ -303,13 +303,16 @@ hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, 
     const dim3 grid((unsigned) num_owned_tiles * 4u), block(BLOCK);
     const bool lds = p.scene.lds_scene != 0;
     const size_t shmem = ldsBytes(p.scene, lds);
-    if (lds) {
-        if (count) hipLaunchKernelGGL((k_render_pixels<true, true>), grid, block, shmem, stream, p);
-        else       hipLaunchKernelGGL((k_render_pixels<false, true>), grid, block, shmem, stream, p);
+    const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
+#define LAUNCH_RP(C, L, M) hipLaunchKernelGGL((k_render_pixels<C, L, M>), grid, block, shmem, stream, p)
+    if (lambert) {
+        if (lds) { if (count) LAUNCH_RP(true, true, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, true, MAT_DIFFUSE_ONLY); }
+        else     { if (count) LAUNCH_RP(true, false, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, false, MAT_DIFFUSE_ONLY); }
     } else {
-        if (count) hipLaunchKernelGGL((k_render_pixels<true, false>), grid, block, shmem, stream, p);
-        else       hipLaunchKernelGGL((k_render_pixels<false, false>), grid, block, shmem, stream, p);
+        if (lds) { if (count) LAUNCH_RP(true, true, MAT_ALL); else LAUNCH_RP(false, true, MAT_ALL); }
+        else     { if (count) LAUNCH_RP(true, false, MAT_ALL); else LAUNCH_RP(false, false, MAT_ALL); }
     }
+#undef LAUNCH_RP
     return hipGetLastError();
 }
 

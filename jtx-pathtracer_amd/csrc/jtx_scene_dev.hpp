@@ -31,6 +31,7 @@ struct DevScene {
     int num_nodes, num_prims, num_lights, num_materials;
     int stack_depth;       // LDS stack entries per lane = BVH leaf depth (+1), known from the build
     int lds_scene;         // != 0: nodes+tris are staged in LDS
+    int material_mask;     // OR of (1 << Material::type) over the scene's materials
     float sky[3];
 };
 
