@@ -1,8 +1,6 @@
 """ctypes binding of the C-ABI in include/jtx_mi.h (libjtx_mi.so, built in-tree by build.py).
 
-There is no fallback: if the shared library is missing, `load()` raises.  The struct classes here
-are layout-compatible with the oracle's `ora_*` structs (oracle/jtx_oracle.h), which lets the tests
-feed one scene description to both sides.
+There is no fallback: if the shared library is missing, `load()` raises.
 """
 import ctypes as C
 import os

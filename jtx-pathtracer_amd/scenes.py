@@ -10,8 +10,7 @@ assets it loads through Assimp (src/loader.cpp).  The benchmark scenes are there
 * atrium()   -- configs C3/C4: deterministic procedural "Sponza-class" atrium (~262 k triangles).
 * mixed()    -- config C5: Cornell room + spheres with all four material types (+ textures).
 
-`SceneData.to_desc()` produces the ctypes scene description accepted by both the C-ABI
-(jtx_mi_scene_create) and the oracle (ora_scene_create).
+`SceneData.to_desc()` produces the ctypes scene description accepted by jtx_mi_scene_create.
 """
 import ctypes as C
 import math

@@ -1,0 +1,71 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo runs of the pixel-tile sharding + per-frame reduce.
+
+The GPU renderer cannot run here, so each rank fills its shard from the CPU oracle's frame masked by
+the product's ownership rule (jtx.distributed.tile_owner_mask) -- exactly what jtx_mi_render_device
+produces for tile_rank/tile_world (the GPU test test_render_tile_sharding checks that) -- and the
+product's reduce_frame() sums the shards over torch.distributed.  Rank 0 must end up with the 1-rank
+frame bit for bit.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p_ in (ROOT, os.path.join(ROOT, "tests")):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, w, h, out_dir):
+    import oracle_lib as ol
+    import jtx_pathtracer_amd as jtx
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = jtx.scenes.cornell()
+        cam = data.camera_desc(w, h, 2, 1, 3)
+        acc, img, _ = ol.OracleScene(data).render(cam, threads=2)
+        mask = jtx.distributed.tile_owner_mask(w, h, rank, world)
+        assert jtx.distributed.owned_tiles(w, h, rank, world) == len(
+            {(r // 32, c // 32) for r, c in zip(*np.nonzero(mask))})
+        my_acc = torch.from_numpy(np.where(mask[..., None], acc, 0).astype(np.float32)).reshape(-1).clone()
+        my_img = torch.from_numpy(np.where(mask[..., None], img, 0).astype(np.uint8)).reshape(-1).clone()
+        jtx.distributed.reduce_frame(my_acc, my_img, dst=0)
+        if rank == 0:
+            ok = np.array_equal(my_acc.numpy().view(np.uint32), acc.reshape(-1).view(np.uint32)) and \
+                np.array_equal(my_img.numpy(), img.reshape(-1))
+            open(os.path.join(out_dir, "result"), "w").write("ok" if ok else "mismatch")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 100, 70), (3, 65, 33)])
+def test_tile_shard_reduce_gloo(world, w, h, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, w, h, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "result").read() == "ok"
+
+
+def test_owner_masks_partition_the_frame():
+    import jtx_pathtracer_amd as jtx
+    for (w, h, world) in [(1920, 1080, 8), (33, 7, 2), (1, 1, 4), (64, 64, 3)]:
+        cover = sum(jtx.distributed.tile_owner_mask(w, h, r, world).astype(np.int32) for r in range(world))
+        assert (cover == 1).all()
+        tiles = ((w + 31) // 32) * ((h + 31) // 32)
+        assert sum(jtx.distributed.owned_tiles(w, h, r, world) for r in range(world)) == tiles

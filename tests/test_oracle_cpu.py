@@ -1,0 +1,353 @@
+"""CPU tests (no GPU): the oracle against known answers, the reference-run check values recorded in
+SURVEY.md, the committed golden vectors; the host BVH builder against the oracle's; the C-ABI's
+exported symbols.  Whole file runs in well under a minute on 8 cores.
+"""
+import ctypes as C
+import json
+import os
+import re
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import jtx_pathtracer_amd as jtx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
+PROBE = GOLD["reference_probe"]
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------------------------------------
+# RNG: an independent pure-Python statement of util/rand.hpp
+# ------------------------------------------------------------------------------------------------
+M32 = 0xFFFFFFFF
+
+
+def py_fnv1a_3(x, y, n):
+    h = 2166136261
+    for v in (x, y, n):
+        h ^= v & M32
+        h = (h * 16777619) & M32
+    return h
+
+
+class PyRng:
+    def __init__(self, x, y, n):
+        self.state = 0                      # quirk Q1: state_ read as 0
+        self.advance()
+        self.state = (self.state + py_fnv1a_3(x, y, n)) & M32
+        self.advance()
+
+    def advance(self):
+        s = self.state
+        self.state = (s * 747796405 + 2891336453) & M32
+        word = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & M32
+        return ((word >> 2) ^ word) & M32   # NB ">> 2", not PCG's ">> 22" (rand.hpp:103)
+
+
+@pytest.mark.parametrize("seed", [(0, 0, 1), (1, 2, 3), (511, 17, 16), (1079, 1919, 64), (4000000000, 7, 9)])
+def test_rng_matches_independent_python(seed):
+    u, f = ol.rng_stream(*seed, 32)
+    r = PyRng(*seed)
+    ref = [r.advance() for _ in range(32)]
+    assert [int(x) for x in u] == ref
+    assert np.array_equal(f, np.array([(x & 0xFFFFFF) / 16777216.0 for x in ref], np.float32))
+    assert ol.load().ora_fnv1a_3(*seed) == py_fnv1a_3(*seed)
+
+
+def test_rng_golden_vectors():
+    for key, g in GOLD["rng"].items():
+        seed = tuple(int(v) for v in key.split(","))
+        u, f = ol.rng_stream(*seed, 16)
+        assert [int(x) for x in u] == g["u32"]
+        assert [int(x) for x in f.view(np.uint32)] == g["f32_bits"]
+
+
+def test_sample_range_quirk():
+    """sampleRange(n-1): exactly one advance, hi32(x*(n-1)); n == 1 -> index 0 (quirk Q2)."""
+    lib = ol.load()
+    for n_lights in (1, 2, 3, 5):
+        r = PyRng(3, 4, 5)
+        x = r.advance()
+        expect = 0 if n_lights - 1 <= 0 else (x * (n_lights - 1)) >> 32
+        assert lib.ora_rng_sample_range(3, 4, 5, 0, n_lights - 1) == expect
+        assert expect <= max(0, n_lights - 2)           # the last light is never chosen
+
+
+# ------------------------------------------------------------------------------------------------
+# deterministic sin/cos
+# ------------------------------------------------------------------------------------------------
+def test_sincos_accuracy_and_golden():
+    x = np.linspace(-1.0, 7.0, 200001).astype(np.float32)
+    s, c = ol.sincos(x)
+    # within 2 ulp of the correctly rounded value over the range the warps use ([-pi/4, 2*pi])
+    for got, ref in ((s, np.sin(x.astype(np.float64))), (c, np.cos(x.astype(np.float64)))):
+        err = np.abs(got.astype(np.float64) - ref)
+        ulp = np.spacing(np.maximum(np.abs(ref), 2.0 ** -20).astype(np.float32)).astype(np.float64)
+        assert (err / ulp).max() < 2.5
+    g = GOLD["sincos"]
+    xg = np.array(g["x_bits"], np.uint32).view(np.float32)
+    sg, cg = ol.sincos(xg)
+    assert [int(v) for v in sg.view(np.uint32)] == g["sin_bits"]
+    assert [int(v) for v in cg.view(np.uint32)] == g["cos_bits"]
+
+
+def test_det_epsilon_equivalence():
+    """mesh.hpp:114 compares |det| < 1e-8 in double; the kernels use |det| <= 1e-8f."""
+    e = np.float32(1e-8)
+    assert float(e) < 1e-8 < float(np.nextafter(e, np.float32(1)))
+
+
+# ------------------------------------------------------------------------------------------------
+# AABB::hit against an independent numpy statement of aabb.hpp:66-81
+# ------------------------------------------------------------------------------------------------
+def np_aabb_hit(pmin, pmax, o, d, t0, t1):
+    f = np.float32
+    t0, t1 = f(t0), f(t1)
+    with np.errstate(all="ignore"):
+        for i in range(3):
+            inv = f(1.0) / f(d[i])
+            tn = f((f(pmin[i]) - f(o[i])) * inv)
+            tf = f((f(pmax[i]) - f(o[i])) * inv)
+            if tn > tf:
+                tn, tf = tf, tn
+            t0 = tn if tn > t0 else t0
+            t1 = tf if tf < t1 else t1
+            if t0 > t1:
+                return False
+    return True
+
+
+def test_aabb_hit_random_and_axis_parallel():
+    lib = ol.load()
+    rs = np.random.RandomState(2)
+    f3 = C.c_float * 3
+    n_hit = 0
+    for k in range(3000):
+        a, b = rs.uniform(-5, 5, 3).astype(np.float32), rs.uniform(-5, 5, 3).astype(np.float32)
+        pmin, pmax = np.minimum(a, b), np.maximum(a, b)
+        o = rs.uniform(-8, 8, 3).astype(np.float32)
+        d = rs.normal(size=3).astype(np.float32)
+        if k % 2 == 0:
+            d = ((pmin + pmax) / 2 - o + rs.normal(size=3)).astype(np.float32)     # aimed at the box
+        if k % 5 == 0:
+            d[rs.randint(3)] = 0.0                      # axis-parallel: 1/d = inf, 0*inf = NaN paths
+        if k % 7 == 0:
+            o[rs.randint(3)] = pmin[rs.randint(3)]      # origin on a slab plane
+        if k % 11 == 0:
+            d[rs.randint(3)] = -0.0
+        got = lib.ora_aabb_hit(f3(*pmin), f3(*pmax), f3(*o), f3(*d), C.c_float(0.001), C.c_float(np.inf))
+        assert bool(got) == np_aabb_hit(pmin, pmax, o, d, 0.001, np.inf), (pmin, pmax, o, d)
+        n_hit += got
+    assert 50 < n_hit < 2700
+
+
+# ------------------------------------------------------------------------------------------------
+# The oracle against what the survey measured on the reference's own sources
+# ------------------------------------------------------------------------------------------------
+def fnv1a_bytes(b):
+    h = 2166136261
+    for x in b:
+        h ^= x
+        h = (h * 16777619) & M32
+    return h
+
+
+def test_reference_probe_quad_image_hash():
+    """createMeshScene quad, 64x64, 2x2 spp, depth 4 -> FNV-1a(RGB8) = 1af9ba89
+    on the reference's unmodified hot-path sources (state_=0 reading).  The oracle must reproduce it,
+    with the deterministic sin/cos and with libm's."""
+    q = jtx.scenes.quad_scene()
+    o = ol.OracleScene(q)
+    cam = q.camera_desc(64, 64, 2, 2, 4)
+    for mode in (0, 1):
+        ol.load().ora_set_sincos_mode(mode)
+        try:
+            _, img, _ = o.render(cam)
+        finally:
+            ol.load().ora_set_sincos_mode(0)
+        assert "%08x" % fnv1a_bytes(img.tobytes()) == PROBE["quad_64x64_2x2_d4_rgb8_fnv1a"]
+
+
+def test_reference_probe_cornell_bvh():
+    o = ol.OracleScene(jtx.scenes.cornell())
+    nodes, refs = o.bvh()
+    assert len(nodes) == PROBE["cornell_bvh_nodes"]
+    assert int((nodes["num_prims"] > 0).sum()) == PROBE["cornell_bvh_leaves"]
+    assert o.info()["max_depth"] == PROBE["cornell_bvh_depth"]
+    assert nodes["num_prims"].max() <= 2 and len(refs) == 32
+
+
+def test_reference_probe_cornell_ray_counts_config1():
+    """BASELINE config 1 (Cornell 512x512, 4x4 spp, depth 4): the reference traced 15.27 M closestHit +
+    11.07 M anyHit calls, 6.28 rays/sample."""
+    data = jtx.scenes.cornell()
+    _, _, cnt = ol.OracleScene(data).render(data.camera_desc(512, 512, 4, 4, 4))
+    # the survey prints two decimals (rounded or truncated): agree to the printed precision
+    assert abs(cnt["n_closest"] / 1e6 - PROBE["cornell_512_4x4_d4_closest_Mrays"]) < 0.01
+    assert abs(cnt["n_any"] / 1e6 - PROBE["cornell_512_4x4_d4_any_Mrays"]) < 0.01
+    assert abs((cnt["n_closest"] + cnt["n_any"]) / cnt["n_camera"] - PROBE["cornell_512_4x4_d4_rays_per_sample"]) < 0.01
+    assert cnt["n_shade"] == cnt["n_any"]        # one shadow ray per shading event (one light, always sampled)
+
+
+def test_reference_probe_cornell_ray_counts_1080p():
+    data = jtx.scenes.cornell()
+    _, _, cnt = ol.OracleScene(data).render(data.camera_desc(1920, 1080, 2, 2, 8))
+    assert abs(cnt["n_closest"] / 1e6 - PROBE["cornell_1920x1080_2x2_d8_closest_Mrays"]) < 0.1
+    assert abs(cnt["n_any"] / 1e6 - PROBE["cornell_1920x1080_2x2_d8_any_Mrays"]) < 0.1
+    assert abs((cnt["n_closest"] + cnt["n_any"]) / cnt["n_camera"] - PROBE["cornell_1920x1080_2x2_d8_rays_per_sample"]) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------
+# committed golden vectors (drift detection) and oracle self-consistency
+# ------------------------------------------------------------------------------------------------
+def _scene(name):
+    return {"cornell": jtx.scenes.cornell, "quad": jtx.scenes.quad_scene,
+            "mixed": lambda: jtx.scenes.mixed(sphere_res=(16, 8))}[name]()
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["renders"]))
+def test_render_golden(name):
+    g = GOLD["renders"][name]
+    data = _scene(name)
+    o = ol.OracleScene(data)
+    acc, img, cnt = o.render(data.camera_desc(*g["size"]))
+    assert o.info() == pytest.approx(g["bvh"])
+    assert cnt == g["counters"]
+    assert crc(acc) == g["acc_crc32"] and crc(img) == g["img_crc32"]
+
+
+def test_bxdf_golden():
+    g = GOLD["bxdf"]
+    data = _scene("mixed")
+    o = ol.OracleScene(data)
+    arr = {k: np.array(v, np.uint32).view(np.float32) for k, v in g["inputs"].items()}
+    nrm, wo, wi = arr["normal"].reshape(-1, 3), arr["wo"].reshape(-1, 3), arr["wi"].reshape(-1, 3)
+    uc, u2, uv = arr["uc"], arr["u2"].reshape(-1, 2), arr["uv"].reshape(-1, 2)
+    for m, gm in g["materials"].items():
+        sm = o.sampleBxdf(int(m), nrm, wo, uc, u2, uv)
+        assert crc(np.concatenate([sm["ok"].astype(np.float32), sm["f"].reshape(-1), sm["wi"].reshape(-1), sm["pdf"]])) == gm["sample_crc32"]
+        assert crc(o.evalBxdf(int(m), nrm, wo, wi, uv)) == gm["eval_crc32"]
+        assert crc(o.pdfBxdf(int(m), nrm, wo, wi, uv)) == gm["pdf_crc32"]
+
+
+def test_oracle_independent_of_threads_and_barriers():
+    data = jtx.scenes.cornell()
+    o = ol.OracleScene(data)
+    cam = data.camera_desc(70, 45, 2, 2, 4)
+    a1, i1, c1 = o.render(cam, threads=1)
+    a8, i8, c8 = o.render(cam, threads=8, reference_barriers=True)
+    assert np.array_equal(a1.view(np.uint32), a8.view(np.uint32)) and np.array_equal(i1, i8) and c1 == c8
+    # resume: strata [0,2) then [2,4) == [0,4)
+    part, _, _ = o.render(cam, sample_begin=0, sample_end=2)
+    part, ip, _ = o.render(cam, sample_begin=2, sample_end=4, acc=part)
+    assert np.array_equal(part.view(np.uint32), a1.view(np.uint32)) and np.array_equal(ip, i1)
+
+
+def test_bxdf_physical_sanity():
+    """Lambert: f = albedo/pi, pdf = |cos|/pi; sampled direction in wo's hemisphere; energy weight f*cos/pdf = albedo."""
+    data = jtx.scenes.cornell()
+    o = ol.OracleScene(data)
+    rs = np.random.RandomState(1)
+    n = 4000
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (n, 1))
+    wo = rs.normal(size=(n, 3)).astype(np.float32); wo[:, 2] = np.abs(wo[:, 2]) + 0.01
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True).astype(np.float32)
+    sm = o.sampleBxdf(0, nrm, wo, rs.uniform(0, 1, n).astype(np.float32), rs.uniform(0, 1, (n, 2)).astype(np.float32))
+    ok = sm["ok"] > 0
+    assert ok.mean() > 0.99
+    cosi = np.abs(sm["wi"][ok, 2])
+    w = sm["f"][ok] * cosi[:, None] / sm["pdf"][ok, None]
+    assert np.allclose(w, 0.73, rtol=2e-5)
+    assert (sm["wi"][ok, 2] > 0).all()
+    assert np.allclose(sm["pdf"][ok], cosi / np.pi, rtol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# product host logic: BVH builder and the C-ABI surface
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("maker", ["cornell", "quad", "mixed", "atrium_small", "degenerate"])
+def test_host_bvh_build_equals_oracle(maker):
+    if maker == "atrium_small":
+        data = jtx.scenes.atrium(target_tris=6000)
+    elif maker == "degenerate":
+        # many coincident triangles: centroid bounds degenerate -> multi-primitive leaf (bvh.cpp:36-46)
+        data = jtx.scenes.SceneData("dup")
+        data.materials = [jtx.scenes.material()]
+        idx, v, n, _ = jtx.scenes.quad((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1))
+        for _ in range(5):
+            data.add_mesh(idx, v, n, 0)
+    else:
+        data = _scene(maker)
+    nodes, refs, depth = jtx.api.bvh_build_host(data)
+    o = ol.OracleScene(data)
+    onodes, orefs = o.bvh()
+    assert nodes.tobytes() == onodes.tobytes()
+    assert refs.tobytes() == orefs.tobytes()
+    assert depth == o.info()["max_depth"]
+    # structure: every primitive in exactly one leaf, interior boxes contain their children
+    leaves = nodes[nodes["num_prims"] > 0]
+    covered = np.concatenate([np.arange(l["offset"], l["offset"] + l["num_prims"]) for l in leaves]) if len(leaves) else np.array([])
+    assert sorted(covered.tolist()) == list(range(data.num_triangles))
+    for i, nd in enumerate(nodes):
+        if nd["num_prims"] == 0:
+            for c in (i + 1, nd["offset"]):
+                assert (nodes[c]["pmin"] >= nd["pmin"]).all() and (nodes[c]["pmax"] <= nd["pmax"]).all()
+    if maker == "degenerate":
+        assert nodes["num_prims"].max() > 1
+
+
+def test_bvh_build_rejects_bad_input():
+    data = jtx.scenes.cornell()
+    data.meshes[2]["indices"][0, 0] = 9999
+    with pytest.raises(jtx.JtxMiError):
+        jtx.api.bvh_build_host(data)
+
+
+def test_capi_exports_every_declared_symbol():
+    """libjtx_mi.so loads and exports exactly the functions include/jtx_mi.h declares."""
+    lib = jtx._capi.load()
+    header = open(os.path.join(ROOT, "include", "jtx_mi.h")).read()
+    declared = set(re.findall(r"\b(jtx_mi_[a-z_0-9]+)\s*\(", header)) - {"jtx_mi_progress_cb"}
+    assert declared == set(jtx._capi.SYMBOLS), declared ^ set(jtx._capi.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.jtx_mi_version() == 1
+    assert C.sizeof(jtx._capi.BvhNode) == 32 and C.sizeof(jtx._capi.TriRef) == 8
+
+
+def test_no_cpu_fallback_in_product():
+    """Without a GPU every compute entry point must fail loudly, never fall back to the CPU."""
+    lib = jtx._capi.load()
+    n = C.c_int32(0)
+    if lib.jtx_mi_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    sc = jtx.Scene(jtx.scenes.cornell())
+    with pytest.raises(jtx.JtxMiError):
+        sc.buildBVH()
+    # and nothing in the product package includes, imports, links or loads anything under oracle/
+    pkg = os.path.join(ROOT, "jtx-pathtracer_amd")
+    bad = re.compile(r"jtx_oracle|oracle_lib|oracle/|libjtx_oracle|import\s+oracle|ora_[a-z_]+\(")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(text), f"{f} references the oracle"
+    assert not bad.search(open(os.path.join(ROOT, "include", "jtx_mi.h")).read())
+
+
+def test_scene_generators_are_deterministic_and_sized():
+    a, b = jtx.scenes.atrium(target_tris=20000), jtx.scenes.atrium(target_tris=20000)
+    assert a.num_triangles == b.num_triangles
+    for ma, mb in zip(a.meshes, b.meshes):
+        assert ma["vertices"].tobytes() == mb["vertices"].tobytes()
+    assert 10000 < a.num_triangles < 40000
+    m = jtx.scenes.mixed(sphere_res=(16, 8))
+    assert {x["type"] for x in m.materials} == {0, 1, 2, 3} and len(m.textures) == 2 and len(m.lights) == 2
+    assert jtx.scenes.cornell().num_triangles == 32
