@@ -1,0 +1,38 @@
+// host_api_demo.cpp -- drives the C++ host mirror the way the reference's main.cpp / Display::renderScene do:
+// createMeshScene (scene.cpp:137-174, with UVs and tex ids = -1) -> buildBVH -> StaticCamera{64,64,...,2,2,4} -> render.
+// Prints the FNV-1a hash of the RGB8 image; the reference's own sources give 1af9ba89 for this set-up.
+#include "../../jtx-pathtracer_amd/host/jtx_host_api.hpp"
+#include <cstdio>
+using namespace jtxmi;
+
+int main() {
+    try {
+        Scene scene; scene.name = "Mesh Scene";
+        scene.cameraProperties.center = Vec3(0, 0, 8); scene.cameraProperties.target = Vec3(0, 0, -1); scene.cameraProperties.up = Vec3(0, 1, 0);
+        scene.cameraProperties.yfov = 20; scene.cameraProperties.defocusAngle = 0; scene.cameraProperties.focusDistance = 3.4f;
+        scene.skyColor = Vec3(0.7f, 0.8f, 1.0f);
+        scene.materials.reserve(8);
+        Material m; m.type = Material::DIFFUSE; m.albedo = Vec3(1, 0.3f, 0.5f);
+        scene.materials.push_back(m);
+        Vec3 vertices[4] = {Vec3(-1, -1, -1), Vec3(-1, 1, -1), Vec3(1, 1, -1), Vec3(1, -1, -1)};
+        Vec3i indices[2] = {Vec3i(0, 1, 2), Vec3i(0, 2, 3)};
+        Vec3 normals[4] = {Vec3(0, 0, 1), Vec3(0, 0, 1), Vec3(0, 0, 1), Vec3(0, 0, 1)};
+        Vec2f uvs[4] = {{0, 0}, {0, 1}, {1, 1}, {1, 0}};
+        scene.meshes.push_back(Mesh(indices, 2, vertices, 4, normals, uvs, &scene.materials.back()));
+        scene.triangles.push_back({0, 0}); scene.triangles.push_back({1, 0});
+        scene.buildBVH();
+        StaticCamera camera(64, 64, scene.cameraProperties, 2, 2, 4);
+        camera.render(scene);                       // progressive, one pass per stratum
+        unsigned h = 2166136261u;
+        const unsigned char *b = &camera.img_.data()[0].R;
+        for (int i = 0; i < 64 * 64 * 3; ++i) { h ^= b[i]; h *= 16777619u; }
+        // single-ray API: the centre ray must hit the quad at t = 9 (camera z = 8, quad z = -1)
+        SurfaceIntersection rec;
+        const bool hit = scene.closestHit(Ray(Vec3(0.1f, 0.2f, 8), Vec3(0, 0, -1)), Interval(0.001f, INF), rec);
+        const bool shadow = scene.anyHit(Ray(Vec3(0.1f, 0.2f, 8), Vec3(0, 0, -1)), Interval(0.0f, 5.0f));
+        std::printf("hash %08x samples %d hit %d t %.3f shadow %d radius %.4f\n", h, camera.currentSample_.load(), (int) hit, rec.t, (int) shadow,
+                    scene.getSceneRadius());
+        scene.destroy();
+        return 0;
+    } catch (const std::exception &e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+}

@@ -246,3 +246,21 @@ def test_errors_are_reported(gpu):
     s.meshes[0]["material"] = 99
     with pytest.raises(gpu.JtxMiError):
         gpu.Scene(s).buildBVH()
+
+
+def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
+    """The C++ Scene/StaticCamera mirror (jtx-pathtracer_amd/host/jtx_host_api.hpp) driven like the reference's
+    main.cpp: createMeshScene quad, 64x64, 2x2 spp, depth 4.  The reference's own sources give the RGB8
+    FNV-1a hash 1af9ba89 for this set-up."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_api_demo")
+    libdir = os.path.join(root, "jtx-pathtracer_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "cpp", "host_api_demo.cpp"),
+                    "-L", libdir, "-ljtx_mi", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    kv = dict(zip(out[0::2], out[1::2]))
+    assert kv["hash"] == "1af9ba89"
+    assert kv["samples"] == "4" and kv["hit"] == "1" and kv["shadow"] == "0"
+    assert abs(float(kv["t"]) - 9.0) < 1e-5 and abs(float(kv["radius"]) - 2 ** 0.5) < 1e-4
