@@ -349,7 +349,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     p.counters = s.counters.p;
     if (o.integrator < 0 || o.integrator > 3) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront) or 3 (wave-pool)");
     int integ = o.integrator;
-    if (integ == 0) { const char *e = getenv("JTX_INTEGRATOR"); integ = e ? atoi(e) : 0; if (integ < 1 || integ > 3) integ = 1; }   // measured fastest on LDS-resident scenes
+    if (integ == 0) { const char *e = getenv("JTX_INTEGRATOR"); integ = e ? atoi(e) : 0; if (integ < 1 || integ > 3) integ = (s.dev.lds_scene && s.dev.material_mask == MAT_DIFFUSE_ONLY) ? 1 : 2; }   // measured policy, DESIGN.md "Integrators"
     auto ev = takeEvents(s);
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));

@@ -362,7 +362,7 @@ def atrium(target_tris=262144, seed=1):
     s.materials = [material(DIFFUSE, a) for a in albedos]
     L, W, H = 120.0, 40.0, 30.0          # nave length (x), width (z), height (y)
     # scale tessellation so that the total lands near target_tris
-    f = max(0.05, math.sqrt(target_tris / 262144.0))
+    f = max(0.05, math.sqrt(target_tris / 335360.0))      # 335360 = triangle count at f = 1
 
     def T(n):
         return max(1, int(round(n * f)))

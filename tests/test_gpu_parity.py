@@ -264,3 +264,88 @@ def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
     assert kv["hash"] == "1af9ba89"
     assert kv["samples"] == "4" and kv["hit"] == "1" and kv["shadow"] == "0"
     assert abs(float(kv["t"]) - 9.0) < 1e-5 and abs(float(kv["radius"]) - 2 ** 0.5) < 1e-4
+
+
+@pytest.mark.parametrize("integrator", [1, 2, 3])
+def test_render_atrium_small(gpu, integrator):
+    """config C3's scene family (deep BVH in HBM, DISTANT light + sky) at a size the oracle renders in seconds."""
+    data = gpu.scenes.atrium(target_tris=20000)
+    sc = gpu.Scene(data); sc.buildBVH()
+    assert not sc.info()["lds_resident"]
+    osc = ol.OracleScene(data)
+    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 160, 90, 2, 2, 8, integrator=integrator)
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
+    assert cam_g.counters == cnt
+
+
+def _frame_on_device(gpu, sc, cam, integrator, **kw):
+    import torch
+    H, W = cam.height, cam.width
+    dev = torch.device("cuda", 0)
+    acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        gpu.distributed.render_shard(sc, cam, kw.get("rank", 0), kw.get("world", 1), acc, img, stream=st.cuda_stream,
+                                     integrator=integrator, count_rays=kw.get("count", False))
+    torch.cuda.synchronize()
+    cnt = None
+    if kw.get("count"):
+        import ctypes as C
+        c = gpu._capi.Counters()
+        gpu._capi.check(gpu._capi.load().jtx_mi_get_counters(sc.handle, C.byref(c)))
+        cnt = c.as_dict()
+    return acc.cpu().numpy().reshape(H, W, 3), img.cpu().numpy().reshape(H, W, 3), cnt
+
+
+def test_full_size_config2_properties(gpu, cornell_pair):
+    """BASELINE config 2 at full size (1920x1080, 64 spp, depth 8), through size-independent properties:
+    two independent integrators agree bit for bit; counter invariants; 8 tile shards sum to the frame;
+    and 192 pixels picked at random equal the oracle's in-order sum of their 64 per-sample radiances."""
+    data, sc, osc = cornell_pair
+    cam = data.camera_desc(1920, 1080, 8, 8, 8)
+    acc1, img1, cnt1 = _frame_on_device(gpu, sc, cam, 1, count=True)
+    acc3, img3, cnt3 = _frame_on_device(gpu, sc, cam, 3, count=True)
+    assert np.array_equal(acc1.view(np.uint32), acc3.view(np.uint32)) and np.array_equal(img1, img3)
+    assert cnt1 == cnt3
+    assert cnt1["n_camera"] == 1920 * 1080 * 64
+    assert cnt1["n_shade"] == cnt1["n_any"]                    # one light: one shadow ray per shading event
+    assert cnt1["n_camera"] <= cnt1["n_closest"] <= cnt1["n_camera"] * 9
+    assert abs((cnt1["n_closest"] + cnt1["n_any"]) / cnt1["n_camera"] - 5.49) < 0.01     # SURVEY.md section 6
+    total = np.zeros_like(acc1)
+    for r in range(8):
+        a, _, _ = _frame_on_device(gpu, sc, cam, 1, rank=r, world=8)
+        total += a
+    assert np.array_equal(total.view(np.uint32), acc1.view(np.uint32))
+    rs = np.random.RandomState(4)
+    rows, cols = rs.randint(0, 1080, 192), rs.randint(0, 1920, 192)
+    rr = np.repeat(rows, 64).astype(np.int32); cc = np.repeat(cols, 64).astype(np.int32)
+    ss = np.tile(np.arange(64, dtype=np.int32), 192)
+    rad = osc.radiance_samples(cam, rr, cc, ss).reshape(192, 64, 3)
+    expect = np.zeros((192, 3), np.float32)
+    for s in range(64):
+        expect = expect + rad[:, s]
+    assert np.array_equal(acc1[rows, cols].view(np.uint32), expect.view(np.uint32))
+    expect_img = (255.999 * np.clip(np.sqrt(np.maximum(expect / np.float32(64), 0)), 0, 0.999).astype(np.float32)).astype(np.float32)
+    assert np.abs(img1[rows, cols].astype(np.int32) - expect_img.astype(np.int32)).max() <= 1
+
+
+def test_full_size_config3_properties(gpu):
+    """BASELINE config 3 (atrium ~262 k triangles, 1920x1080; 16 of the 64 strata to bound the run): the
+    pixel-persistent and the wave-pool integrators agree bit for bit; pixels checked against the oracle."""
+    data = gpu.scenes.atrium()
+    sc = gpu.Scene(data); sc.buildBVH()
+    cam = data.camera_desc(1920, 1080, 4, 4, 8)
+    acc1, img1, cnt1 = _frame_on_device(gpu, sc, cam, 1, count=True)
+    acc3, img3, cnt3 = _frame_on_device(gpu, sc, cam, 3, count=True)
+    assert np.array_equal(acc1.view(np.uint32), acc3.view(np.uint32)) and np.array_equal(img1, img3) and cnt1 == cnt3
+    osc = ol.OracleScene(data)
+    rs = np.random.RandomState(6)
+    rows, cols = rs.randint(0, 1080, 64), rs.randint(0, 1920, 64)
+    rr = np.repeat(rows, 16).astype(np.int32); cc = np.repeat(cols, 16).astype(np.int32); ss = np.tile(np.arange(16, dtype=np.int32), 64)
+    rad = osc.radiance_samples(cam, rr, cc, ss).reshape(64, 16, 3)
+    expect = np.zeros((64, 3), np.float32)
+    for s in range(16):
+        expect = expect + rad[:, s]
+    assert np.array_equal(acc1[rows, cols].view(np.uint32), expect.view(np.uint32))
