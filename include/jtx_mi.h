@@ -121,6 +121,7 @@ typedef struct {
 typedef struct {
     int32_t num_nodes, num_prims, max_depth, lds_resident;
     float   scene_radius;
+    int32_t auto_integrator;  /* what opts.integrator == 0 resolves to for this scene */
     uint64_t device_bytes;
 } jtx_mi_scene_info;
 

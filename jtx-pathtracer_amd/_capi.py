@@ -75,7 +75,8 @@ class Counters(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("num_prims", C.c_int32), ("max_depth", C.c_int32),
-                ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("device_bytes", C.c_uint64)]
+                ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("auto_integrator", C.c_int32),
+                ("device_bytes", C.c_uint64)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)

@@ -70,6 +70,7 @@ class Scene:
         check(self._lib.jtx_mi_scene_get_info(self.handle, C.byref(i)))
         return dict(num_nodes=i.num_nodes, num_prims=i.num_prims, max_depth=i.max_depth,
                     lds_resident=bool(i.lds_resident), scene_radius=float(i.scene_radius),
+                    auto_integrator=int(i.auto_integrator),
                     device_bytes=int(i.device_bytes))
 
     def bvh(self):

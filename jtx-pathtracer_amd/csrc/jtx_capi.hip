@@ -238,6 +238,14 @@ std::pair<hipEvent_t, hipEvent_t> takeEvents(jtx_mi_scene &s) {
     return e;
 }
 
+// opts.integrator == 0: the measured policy of DESIGN.md "Integrators" (env JTX_INTEGRATOR overrides)
+int autoIntegrator(const jtx_mi_scene &s) {
+    const char *e = getenv("JTX_INTEGRATOR");
+    const int v = e ? atoi(e) : 0;
+    if (v >= 1 && v <= 3) return v;
+    return (s.dev.lds_scene && s.dev.material_mask == MAT_DIFFUSE_ONLY) ? 1 : 2;
+}
+
 // ---- wavefront integrator orchestration ----
 // strata per batch: the batch's slot arrays (~132 B/slot) should stay near the 256 MiB Infinity Cache
 int wfStrataPerBatch(int pixels, int nstrata) {
@@ -349,7 +357,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     p.counters = s.counters.p;
     if (o.integrator < 0 || o.integrator > 3) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront) or 3 (wave-pool)");
     int integ = o.integrator;
-    if (integ == 0) { const char *e = getenv("JTX_INTEGRATOR"); integ = e ? atoi(e) : 0; if (integ < 1 || integ > 3) integ = (s.dev.lds_scene && s.dev.material_mask == MAT_DIFFUSE_ONLY) ? 1 : 2; }   // measured policy, DESIGN.md "Integrators"
+    if (integ == 0) integ = autoIntegrator(s);
     auto ev = takeEvents(s);
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
@@ -424,6 +432,7 @@ int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     if (!s || !out) return fail("null argument");
     out->num_nodes = s->dev.num_nodes; out->num_prims = s->dev.num_prims; out->max_depth = s->bvh.max_depth;
     out->lds_resident = s->dev.lds_scene; out->scene_radius = s->bvh.scene_radius; out->device_bytes = s->device_bytes;
+    out->auto_integrator = autoIntegrator(*s);
     return 0;
 }
 int jtx_mi_scene_get_bvh(const jtx_mi_scene *s, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out) {
