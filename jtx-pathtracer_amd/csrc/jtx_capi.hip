@@ -487,6 +487,13 @@ int jtx_mi_kernel_time(jtx_mi_scene *s, float *ms_total, int32_t *launches) {
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 
+#ifdef JTX_PROFILE_UTIL
+int jtx_mi_debug_util(jtx_mi_scene *s, unsigned long long *out3) {     // diagnostic builds only
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out3, s->counters.p + 20, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef JTX_PROFILE_PHASES
 int jtx_mi_debug_phases(jtx_mi_scene *s, unsigned long long *out6) {   // diagnostic builds only
     if (!s || !s->counters.p) return 1;

@@ -181,6 +181,15 @@ __global__ void __launch_bounds__(BLOCK, 8) k_render_pixels(RenderParams p) {
         }
     }
     if (COUNT) waveAddCounters(p.counters, cnt);
+#ifdef JTX_PROFILE_UTIL
+    if (COUNT) {
+        // every lane of a wave sits through the same traversal-loop iterations, but lanes that left the
+        // pixel loop early stop counting: take the wave maximum
+        unsigned a = cnt.it_interior, b = cnt.it_leaf, c = cnt.it_calls;
+        for (int off = 32; off > 0; off >>= 1) { a = max(a, __shfl_down(a, off, 64)); b = max(b, __shfl_down(b, off, 64)); c = max(c, __shfl_down(c, off, 64)); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&p.counters[20], (unsigned long long) a); atomicAdd(&p.counters[21], (unsigned long long) b); atomicAdd(&p.counters[22], (unsigned long long) c); }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -37,7 +37,15 @@ struct DevScene {
 
 struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode only)
     unsigned n_camera, n_closest, n_any, n_nodes_closest, n_tri_closest, n_accept, n_nodes_any, n_tri_any, n_shade;
+#ifdef JTX_PROFILE_UTIL
+    unsigned it_interior, it_leaf, it_calls;   // diagnostic: loop iterations this lane sat through (= wave iterations)
+#endif
 };
+#ifdef JTX_PROFILE_UTIL
+#define UTIL(x) x
+#else
+#define UTIL(x)
+#endif
 
 struct GlobalSrc {
     const float4 *nodes, *tris;
@@ -118,8 +126,11 @@ JD bool finiteNonZero(float x) { return fabsf(x) < __builtin_inff() && x != 0.0f
 // ray, the near-child-first rule (dirIsNeg[axis], scene.cpp:40-46) and the shrinking t.max are
 // exactly the reference's; only the interleaving between lanes differs.
 //  * stack: one LDS column per lane (stk[level * stride]), depth bounded by the BVH build.
+#ifndef JTX_STEPS_PER_VOTE
+#define JTX_STEPS_PER_VOTE 2     // interior steps between two scheduling votes (the ballots are pure overhead)
+#endif
 #ifndef JTX_LEAF_VOTE
-#define JTX_LEAF_VOTE 20      // lanes parked on a leaf that end the interior phase of a wave
+#define JTX_LEAF_VOTE 12      // lanes parked on a leaf that end the interior phase of a wave
 #endif
 
 template <bool ANY, bool COUNT, bool REGULAR, class Src>
@@ -134,26 +145,31 @@ JD bool traverseT(const Src &src, int *stk, int stride, f3 o, f3 d, f3 inv, int 
     // phase: the parked lanes test their leaf's triangles together, then pop.  A parked lane simply
     // waits, so each ray still sees exactly the reference's visit order and shrinking t.max.
     int leafOff = 0, leafN = 0;
+    UTIL(if (COUNT) cnt.it_calls++;)
     while (true) {
         while (true) {
-            if (leafN == 0 && cur >= 0) {
-                const float4 na = src.node(cur, 0);
-                const float4 nb = src.node(cur, 1);
-                if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
-                const bool boxHit = REGULAR ? slabRegular(na, nb, o, inv, tmin, tmax) : slabExact(na, nb, o, inv, tmin, tmax);
-                if (boxHit) {
-                    const int meta = __float_as_int(nb.w);
-                    const int off = __float_as_int(nb.z);
-                    if ((meta & 0xffff) != 0) { leafOff = off; leafN = meta & 0xffff; }
-                    else {
-                        const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
-                        stk[sp * stride] = neg ? cur + 1 : off;
-                        sp++;
-                        cur = neg ? off : cur + 1;
+#pragma unroll
+            for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
+                UTIL(if (COUNT) cnt.it_interior++;)
+                if (leafN == 0 && cur >= 0) {
+                    const float4 na = src.node(cur, 0);
+                    const float4 nb = src.node(cur, 1);
+                    if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
+                    const bool boxHit = REGULAR ? slabRegular(na, nb, o, inv, tmin, tmax) : slabExact(na, nb, o, inv, tmin, tmax);
+                    if (boxHit) {
+                        const int meta = __float_as_int(nb.w);
+                        const int off = __float_as_int(nb.z);
+                        if ((meta & 0xffff) != 0) { leafOff = off; leafN = meta & 0xffff; }
+                        else {
+                            const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
+                            stk[sp * stride] = neg ? cur + 1 : off;
+                            sp++;
+                            cur = neg ? off : cur + 1;
+                        }
+                    } else {
+                        if (sp == 0) cur = -1;
+                        else { --sp; cur = stk[sp * stride]; }
                     }
-                } else {
-                    if (sp == 0) cur = -1;
-                    else { --sp; cur = stk[sp * stride]; }
                 }
             }
             const unsigned long long walking = __ballot(leafN == 0 && cur >= 0);
@@ -161,6 +177,7 @@ JD bool traverseT(const Src &src, int *stk, int stride, f3 o, f3 d, f3 inv, int 
             if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE) break;
         }
         if (__ballot(leafN > 0) == 0ull) break;            // wave-uniform: every lane is DONE
+        UTIL(if (COUNT) cnt.it_leaf++;)
         if (leafN > 0) {
             for (int i = 0; i < leafN; ++i) {
                 const int prim = leafOff + i;
