@@ -135,7 +135,7 @@ def main():
     lib = jtx._capi.load()
 
     integrator = scene.info()["auto_integrator"]
-    INTEG_NAMES = {1: "pixel-persistent", 2: "hbm-wavefront", 3: "wave-pool"}
+    INTEG_NAMES = {1: "pixel-persistent", 2: "hbm-wavefront", 3: "wave-pool", 4: "pixel-persistent-fused"}
 
     def step(count=False, profile=False):
         jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count,
@@ -191,7 +191,7 @@ def main():
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
         my_bytes = algorithmic_bytes(mine)               # rank 0's launch
-        kernel_name = {1: "k_render_pixels", 3: "k_render_wavepool"}.get(integrator)
+        kernel_name = {1: "k_render_pixels", 3: "k_render_wavepool", 4: "k_render_fused"}.get(integrator)
         launches_per_frame = 1
         if integrator == 2:
             # dominant stage of the pipeline; its algorithmic bytes are the SURVEY 8d terms of that stage

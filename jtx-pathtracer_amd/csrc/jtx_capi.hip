@@ -242,7 +242,7 @@ std::pair<hipEvent_t, hipEvent_t> takeEvents(jtx_mi_scene &s) {
 int autoIntegrator(const jtx_mi_scene &s) {
     const char *e = getenv("JTX_INTEGRATOR");
     const int v = e ? atoi(e) : 0;
-    if (v >= 1 && v <= 3) return v;
+    if (v >= 1 && v <= 4) return v;
     return (s.dev.lds_scene && s.dev.material_mask == MAT_DIFFUSE_ONLY) ? 1 : 2;
 }
 
@@ -355,13 +355,14 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         HIPCHK(hipMemsetAsync(s.counters.p, 0, 32 * sizeof(unsigned long long), stream));
     }
     p.counters = s.counters.p;
-    if (o.integrator < 0 || o.integrator > 3) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront) or 3 (wave-pool)");
+    if (o.integrator < 0 || o.integrator > 4) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront), 3 (wave-pool) or 4 (pixel-persistent, fused rays)");
     int integ = o.integrator;
     if (integ == 0) integ = autoIntegrator(s);
     auto ev = takeEvents(s);
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
     else if (integ == 3) HIPCHK(jtx_launch_render_wavepool(p, owned, count, stream));
+    else if (integ == 4) HIPCHK(jtx_launch_render_fused(p, owned, count, stream));
     else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
     HIPCHK(hipEventRecord(ev.second, stream));
     s.pending.push_back(ev);

@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
         __builtin_amdgcn_wave_barrier();
 
         // =================== worker phase ===================
+        UTIL(if (COUNT) cnt.it_calls++;)
         int next = 0;                                          // wave-uniform: first unassigned list entry
         int ray = -1, cur = -1, sp = 0, leafOff = 0, leafN = 0, negmask = 0;
         bool isAny = false, hitAny = false;
@@ -207,8 +208,10 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
             }
             if (__ballot(ray >= 0) == 0ull) break;             // list exhausted and every lane retired
 
+            UTIL(if (COUNT) cnt.it_leaf++;)
             // ---- interior phase: one node per walking lane per iteration ----
             while (true) {
+                UTIL(if (COUNT) cnt.it_interior++;)
                 if (ray >= 0 && leafN == 0 && cur >= 0) {
                     const float4 na = nodes[2 * cur], nb = nodes[2 * cur + 1];
                     if (COUNT) { if (isAny) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
@@ -272,6 +275,13 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
             p.img[3 * pix + 2] = wpToByte(acc.z / invN);
         }
     }
+#ifdef JTX_PROFILE_UTIL
+    if (COUNT) {
+        unsigned a = cnt.it_interior, b = cnt.it_leaf, c = cnt.it_calls;
+        for (int off = 32; off > 0; off >>= 1) { a = max(a, __shfl_down(a, off, 64)); b = max(b, __shfl_down(b, off, 64)); c = max(c, __shfl_down(c, off, 64)); }
+        if (lane == 0) { atomicAdd(&p.counters[20], (unsigned long long) a); atomicAdd(&p.counters[21], (unsigned long long) b); atomicAdd(&p.counters[22], (unsigned long long) c); }
+    }
+#endif
     if (COUNT) {
         const unsigned v[9] = {cnt.n_camera, cnt.n_closest, cnt.n_any, cnt.n_nodes_closest, cnt.n_tri_closest, cnt.n_accept,
                                cnt.n_nodes_any, cnt.n_tri_any, cnt.n_shade};

@@ -156,7 +156,7 @@ def _render_both(gpu, data, sc, osc, w, h, xs, ys, depth, **kw):
     return cam_g, acc, img, cnt
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
 def test_render_config1_cornell_512(gpu, cornell_pair, integrator):
     """BASELINE config 1: Cornell 512x512, 16 spp (4x4), depth 4 -- whole frame, bit-exact, both integrators."""
     data, sc, osc = cornell_pair
@@ -167,7 +167,7 @@ def test_render_config1_cornell_512(gpu, cornell_pair, integrator):
     assert cnt["n_camera"] == 512 * 512 * 16
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
 def test_render_mixed_small(gpu, mixed_pair, integrator):
     data, sc, osc = mixed_pair
     cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 200, 120, 2, 2, 8, integrator=integrator)
@@ -176,7 +176,7 @@ def test_render_mixed_small(gpu, mixed_pair, integrator):
     assert cam_g.counters == cnt
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
 def test_render_ragged_sizes(gpu, cornell_pair, integrator):
     """widths/heights that are not multiples of the 8x8 wave block or the 32x32 tile; 1x1 image."""
     data, sc, osc = cornell_pair
@@ -207,7 +207,7 @@ def test_render_resume_and_progress(gpu, cornell_pair):
     assert stop.currentSample_ == 2
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
 def test_render_tile_sharding(gpu, cornell_pair, integrator):
     """pixel-tile shards of 3 ranks are disjoint, zero elsewhere, and sum to the 1-GPU frame exactly."""
     data, sc, osc = cornell_pair
@@ -266,7 +266,7 @@ def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
     assert abs(float(kv["t"]) - 9.0) < 1e-5 and abs(float(kv["radius"]) - 2 ** 0.5) < 1e-4
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
 def test_render_atrium_small(gpu, integrator):
     """config C3's scene family (deep BVH in HBM, DISTANT light + sky) at a size the oracle renders in seconds."""
     data = gpu.scenes.atrium(target_tris=20000)

@@ -5,7 +5,7 @@ import jtx_pathtracer_amd as jtx
 lib = jtx._capi.load()
 data = jtx.scenes.cornell(); sc = jtx.Scene(data); sc.buildBVH()
 cam = jtx.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
-cam.render(sc, count_rays=True, integrator=1)
+cam.render(sc, count_rays=True, integrator=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 f = lib.jtx_mi_debug_util; f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 out = (C.c_uint64 * 3)(); assert f(sc.handle, out) == 0
 c = cam.counters
