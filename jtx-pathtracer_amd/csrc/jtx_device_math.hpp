@@ -48,6 +48,13 @@ JD float tan2Theta(f3 w) { return sin2Theta(w) / cos2Theta(w); }
 JD float cosPhi(f3 w) { float s = sinTheta(w); return s == 0.0f ? 1.0f : clampf(w.x / s, -1.0f, 1.0f); }
 JD float sinPhi(f3 w) { float s = sinTheta(w); return s == 0.0f ? 0.0f : clampf(w.y / s, -1.0f, 1.0f); }
 JD bool isinf_(float x) { return fabsf(x) == __builtin_inff(); }
+// r + b*0 per component (what integrateMIS adds for an occluded light sample): r unless b is inf/NaN
+JD f3 addBetaTimesZero(f3 r, f3 b) { return r + b * mk3(0.0f); }
+JD int nonFiniteMask(f3 b) { return (fabsf(b.x) < __builtin_inff() ? 0 : 1) | (fabsf(b.y) < __builtin_inff() ? 0 : 2) | (fabsf(b.z) < __builtin_inff() ? 0 : 4); }
+JD f3 poisonNonFinite(f3 r, int mask) {      // == r + b*0 given nonFiniteMask(b)
+    const float qnan = __builtin_nanf("");
+    return mk3((mask & 1) ? qnan : r.x, (mask & 2) ? qnan : r.y, (mask & 4) ? qnan : r.z);
+}
 
 constexpr float PI_F        = 3.14159265358979323846f;
 constexpr float INV_PI      = 1.0f / PI_F;

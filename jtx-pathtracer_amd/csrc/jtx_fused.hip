@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
     float stmax = 0.0f;
     f3 beta = mk3(1.0f), rad = mk3(0.0f), pend = mk3(0.0f);
     Rng rng; rng.state = 0;
-    int depth = 0;
+    int depth = 0, pendNf = 0;                      // pendNf: components of beta that were inf/NaN when pend was formed
     bool shOccluded = false;
     HitRec hit; hit.t = 0.0f; hit.prim = -1; hit.b1 = hit.b2 = 0.0f;
 
@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
         if (alive) {
             if (hasShadow) {                                   // integrator.cpp:150-165
                 if (!shOccluded) rad = rad + pend;
+                else rad = poisonNonFinite(rad, pendNf);     // occluded: integrateMIS adds beta * {} (integrator.cpp:168,195)
                 hasShadow = false;
             }
             if (hasExt) {
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
                             const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
                             const float misWeight = powerHeuristic(1.0f, pl, 1.0f, pb);   // also for delta lights (Q10)
                             pend = beta * (misWeight * f * ls.radiance / pl);
+                            pendNf = nonFiniteMask(beta);
                             hasShadow = true;
                         }
                     }

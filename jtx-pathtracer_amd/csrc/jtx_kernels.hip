@@ -88,6 +88,10 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int
                 const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
                 const float misWeight = powerHeuristic(1.0f, pl, 1.0f, pb);   // applied to delta lights too (Q10)
                 ps.radiance = ps.radiance + ps.beta * (misWeight * f * ls.radiance / pl);
+            } else {
+                // sampleLights returns {} and integrateMIS still adds beta * {} (integrator.cpp:168,195):
+                // a no-op for finite beta, NaN where the throughput has overflowed
+                ps.radiance = ps.radiance + ps.beta * mk3(0.0f);
             }
         }
     }

@@ -18,7 +18,8 @@ struct RenderParams {
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
 enum { WF_LIVE = 1 };                                   // flags[]: extension ray pending / hit ready
-enum { WF_SH_PENDING = 1, WF_SH_UNOCCLUDED = 2 };       // sflags[]: shadow ray to trace / traced and unoccluded
+enum { WF_SH_PENDING = 1, WF_SH_UNOCCLUDED = 2,         // sflags[]: shadow ray to trace / traced and unoccluded
+       WF_SH_NF_SHIFT = 4, WF_SH_NF_MASK = 0x70 };       //   bits 4-6: components of beta that were inf/NaN at that vertex
 
 struct WfBuffers {
     int   *flags;                                   // WF_LIVE

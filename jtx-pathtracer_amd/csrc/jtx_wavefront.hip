@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
         // no geometry: every closest ray misses, every shadow ray is unoccluded
         for (int s = blockIdx.x * WBLOCK + threadIdx.x; s < p.num_slots; s += gridDim.x * WBLOCK) {
             if (!(flags[s] & want)) continue;
-            if (ANY) { p.b.sflags[s] = WF_SH_UNOCCLUDED; if (COUNT) cnt.n_any++; }
+            if (ANY) { p.b.sflags[s] = WF_SH_UNOCCLUDED; if (COUNT) cnt.n_any++; }   // no geometry: nothing occludes
             else { p.b.hit[s] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); if (COUNT) cnt.n_closest++; }
         }
         if (COUNT) { const unsigned long long a = ANY ? cnt.n_any : cnt.n_closest; if (a) atomicAdd(&p.counters[ANY ? 2 : 1], a); }
@@ -181,11 +181,12 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
     HitRec rec; rec.t = 0.0f; rec.prim = -1; rec.b1 = rec.b2 = 0.0f;
     int pslot = -1;
     float pox = 0.0f, poy = 0.0f, poz = 0.0f, pdx = 1.0f, pdy = 1.0f, pdz = 1.0f, ptmax = 0.0f;
+    int pnf = 0, nf = 0;                            // shadow rays: the beta-non-finite bits travelling with the slot
 
     while (true) {
         // ---- A. switch finished / empty lanes to their prefetched ray ----
         if (slot < 0 && pslot >= 0) {
-            slot = pslot; pslot = -1;
+            slot = pslot; pslot = -1; nf = pnf;
             o = mk3(pox, poy, poz); d = mk3(pdx, pdy, pdz);
             tmax = ANY ? ptmax : __builtin_inff();
             inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -210,7 +211,8 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
                 const int s = waveFetch(wf, pslot < 0, flags, want, p.num_slots, scratch);
                 if (s >= 0) {
                     pslot = s;
-                    if (ANY) { pox = p.b.sox[s]; poy = p.b.soy[s]; poz = p.b.soz[s]; pdx = p.b.sdx[s]; pdy = p.b.sdy[s]; pdz = p.b.sdz[s]; ptmax = p.b.stmax[s]; }
+                    if (ANY) { pox = p.b.sox[s]; poy = p.b.soy[s]; poz = p.b.soz[s]; pdx = p.b.sdx[s]; pdy = p.b.sdy[s]; pdz = p.b.sdz[s]; ptmax = p.b.stmax[s];
+                               pnf = p.b.sflags[s] & WF_SH_NF_MASK; }
                     else     { pox = p.b.rox[s]; poy = p.b.roy[s]; poz = p.b.roz[s]; pdx = p.b.rdx[s]; pdy = p.b.rdy[s]; pdz = p.b.rdz[s]; }
                 }
             }
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
 
         // ---- E. retire finished rays: one store, nothing to wait for ----
         if (slot >= 0 && cur < 0 && leafN == 0) {
-            if (ANY) p.b.sflags[slot] = hitAny ? 0 : WF_SH_UNOCCLUDED;     // shade / resolve add the pending radiance
+            if (ANY) p.b.sflags[slot] = hitAny ? nf : WF_SH_UNOCCLUDED;    // shade / resolve add the pending radiance (or poison)
             else p.b.hit[slot] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
             slot = -1;
         }
@@ -305,8 +307,12 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p) {
         int flag = 0;                                                     // path ends unless set below
         int sflag = 0;
         bool radDirty = false;
-        if (p.b.sflags[slot] == WF_SH_UNOCCLUDED) {                       // the previous vertex' light sample got through
+        const int sprev = p.b.sflags[slot];
+        if (sprev & WF_SH_UNOCCLUDED) {                                   // the previous vertex' light sample got through
             rad = rad + mk3(p.b.pendx[slot], p.b.pendy[slot], p.b.pendz[slot]);   // integrator.cpp:194-196
+            radDirty = true;
+        } else if (sprev & WF_SH_NF_MASK) {                               // occluded, but beta was inf/NaN: beta * {} is NaN
+            rad = poisonNonFinite(rad, (sprev >> WF_SH_NF_SHIFT) & 7);
             radDirty = true;
         }
         if (prim < 0) {                                                   // integrator.cpp:183-187
@@ -342,7 +348,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p) {
                         p.b.sdx[slot] = ls.wi.x; p.b.sdy[slot] = ls.wi.y; p.b.sdz[slot] = ls.wi.z;
                         p.b.stmax[slot] = lDist - RAY_EPSILON;
                         p.b.pendx[slot] = pend.x; p.b.pendy[slot] = pend.y; p.b.pendz[slot] = pend.z;
-                        sflag = WF_SH_PENDING;
+                        sflag = WF_SH_PENDING | (nonFiniteMask(beta) << WF_SH_NF_SHIFT);
                     }
                 }
                 const float u = rng.f();
@@ -389,8 +395,10 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_resolve(WfParams p, int s0, int n
     for (int sl = 0; sl < nstrata; ++sl) {
         const int slot = sl * p.pixels + pix;
         f3 c = mk3(p.b.radx[slot], p.b.rady[slot], p.b.radz[slot]);
-        if (p.b.sflags[slot] == WF_SH_UNOCCLUDED)                          // last vertex' light sample of an ended path
+        const int sf = p.b.sflags[slot];
+        if (sf & WF_SH_UNOCCLUDED)                                         // last vertex' light sample of an ended path
             c = c + mk3(p.b.pendx[slot], p.b.pendy[slot], p.b.pendz[slot]);
+        else if (sf & WF_SH_NF_MASK) c = poisonNonFinite(c, (sf >> WF_SH_NF_SHIFT) & 7);
         if (c.x > 1.0f) c.x = 1.0f;                                        // camera.cpp:110-112
         if (c.y > 1.0f) c.y = 1.0f;
         if (c.z > 1.0f) c.z = 1.0f;

@@ -85,13 +85,14 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
     f3 ro = mk3(0.0f), rd = mk3(1.0f);              // the extension ray in flight (needed to shade its hit)
     f3 beta = mk3(1.0f), rad = mk3(0.0f), pend = mk3(0.0f);
     Rng rng; rng.state = 0;
-    int depth = 0;
+    int depth = 0, pendNf = 0;                      // pendNf: components of beta that were inf/NaN when pend was formed
 
     while (true) {
         // =================== owner phase ===================
         if (alive) {
             if (hasShadow) {                                   // sampleLights' occlusion test came back (integrator.cpp:150-165)
                 if (pres[2 * lane].w == 0.0f) rad = rad + pend;
+                else rad = poisonNonFinite(rad, pendNf);     // occluded: integrateMIS adds beta * {} (integrator.cpp:168,195)
                 hasShadow = false;
             }
             if (hasExt) {
@@ -118,7 +119,8 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
                             f = f * absdot(ls.wi, sf.normal);
                             const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
                             const float misWeight = powerHeuristic(1.0f, pl, 1.0f, pb);   // also for delta lights (Q10)
-                            pend = beta * (misWeight * f * ls.radiance / pl);             // added if the shadow ray gets through
+                            pend = beta * (misWeight * f * ls.radiance / pl);
+                            pendNf = nonFiniteMask(beta);             // added if the shadow ray gets through
                             pray[2 * (2 * lane) + 0] = make_float4(so.x, so.y, so.z, lDist - RAY_EPSILON);
                             pray[2 * (2 * lane) + 1] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, __int_as_float(1));
                             hasShadow = true;

@@ -349,3 +349,53 @@ def test_full_size_config3_properties(gpu):
     for s in range(16):
         expect = expect + rad[:, s]
     assert np.array_equal(acc1[rows, cols].view(np.uint32), expect.view(np.uint32))
+
+
+def _edge_scene(gpu):
+    """Cornell + a transformed, UV-mapped, textured sphere + three lights (POINT, DISTANT, POINT), thin-lens camera."""
+    s = gpu.scenes.cornell()
+    albedo, mr = gpu.scenes._procedural_textures(64)
+    s.textures = [albedo, mr]
+    s.materials.append(gpu.scenes.material(gpu.scenes.METALLIC_ROUGHNESS, (1, 1, 1), alpha_x=0.3, alpha_y=0.4, albedo_tex=0, mr_tex=1))
+    s.materials.append(gpu.scenes.material(gpu.scenes.DIELECTRIC, ior=(1.5, 1.5, 1.5), alpha_x=0.2, alpha_y=0.1))
+    idx, v, n, uv = gpu.scenes.uv_sphere((0, 0, 0), 1.0, 16, 8)
+    c, s_ = np.cos(0.6), np.sin(0.6)
+    T = np.array([[70 * c, 0, 70 * s_, 330], [0, 90, 0, 240], [-70 * s_, 0, 70 * c, 150], [0, 0, 0, 1]], np.float32)   # rotate-Y * scale + translate
+    s.add_mesh(idx, v, n, 3, uvs=uv * 3.0 - 1.0, transform=T, name="xformed")       # uvs outside [0,1): wrap incl. negatives
+    T2 = np.array([[40, 0, 0, 150], [0, 40, 0, 380], [0, 0, 40, 300], [0, 0, 0, 1]], np.float32)
+    s.add_mesh(idx, v, n, 4, uvs=uv, transform=T2, name="glass")
+    s.lights = [gpu.scenes.light(gpu.scenes.POINT, (278.0, 500.0, 279.5), (1, 1, 1), 60000.0),
+                gpu.scenes.light(gpu.scenes.DISTANT, (0.2, -0.9, 0.3), (1, 0.9, 0.8), 0.5),
+                gpu.scenes.light(gpu.scenes.POINT, (100.0, 100.0, 100.0), (0, 1, 0), 90000.0)]   # never chosen (quirk Q2)
+    s.sky = (0.1, 0.2, 0.3)
+    s.camera["defocus_angle"] = 1.5
+    s.camera["focus_distance"] = 1000.0
+    return s
+
+
+@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("max_prims", [1, 4])
+def test_render_edge_cases(gpu, integrator, max_prims):
+    """mesh transforms baked on upload, texture wrap with negative uv, 3 lights (Q2), thin lens, maxPrimsInNode > 1."""
+    data = _edge_scene(gpu)
+    sc = gpu.Scene(data); sc.buildBVH(max_prims)
+    osc = ol.OracleScene(data)          # same data.max_prims_in_node
+    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 120, 90, 2, 2, 6, integrator=integrator)
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
+    assert cam_g.counters == cnt
+    if max_prims == 4:
+        assert sc.bvh()[0]["num_prims"].max() > 1
+
+
+@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+def test_render_depth_zero_and_no_lights(gpu, cornell_pair, integrator):
+    data, sc, osc = cornell_pair
+    cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 64, 48, 1, 2, 0, integrator=integrator)    # maxDepth 0: one closestHit per path
+    assert_same_f32(cam_g.acc_, acc, "depth 0")
+    assert cam_g.counters == cnt and cnt["n_any"] == 0 and cnt["n_closest"] == cnt["n_camera"]
+    nl = gpu.scenes.cornell(); nl.lights = []; nl.sky = (0.5, 0.6, 0.7)
+    s2 = gpu.Scene(nl); s2.buildBVH()
+    cam_g, acc, img, cnt = _render_both(gpu, nl, s2, ol.OracleScene(nl), 64, 48, 2, 1, 5, integrator=integrator)
+    assert_same_f32(cam_g.acc_, acc, "no lights")
+    assert cam_g.counters == cnt and cnt["n_any"] == 0

@@ -4,8 +4,8 @@ sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 import jtx_pathtracer_amd as jtx
 lib = jtx._capi.load()
-W, H, xs, ys, D = [int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (1920, 1080, 8, 8, 8))]
-data = jtx.scenes.cornell(); sc = jtx.Scene(data); sc.buildBVH()
+W, H, xs, ys, D = [int(x) for x in (sys.argv[2:7] if len(sys.argv) > 6 else (1920, 1080, 8, 8, 8))]
+data = getattr(jtx.scenes, sys.argv[1] if len(sys.argv) > 1 else "cornell")(); sc = jtx.Scene(data); sc.buildBVH()
 cam = data.camera_desc(W, H, xs, ys, D)
 dev = torch.device("cuda", 0)
 acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev); img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
