@@ -434,3 +434,105 @@ def quad_scene():
     s.sky = (0.7, 0.8, 1.0)
     s.camera = dict(center=(0, 0, 8), target=(0, 0, -1), up=(0, 1, 0), yfov=20.0, defocus_angle=0.0, focus_distance=3.4)
     return s
+
+
+# ------------------------------------------------------------------------------------------------
+# Wavefront OBJ ingestion: the geometry side of src/loader.cpp without Assimp
+# ------------------------------------------------------------------------------------------------
+def load_obj(path, default_material=None, materials_by_name=None):
+    """Minimal OBJ reader with the semantics of the reference's Assimp import (loader.cpp:21):
+    aiProcess_Triangulate (fan), no vertex joining (three fresh vertices per face corner, in face order),
+    aiProcess_GenNormals when a face has no vn (flat face normal), aiProcess_FlipUVs (v -> 1 - v),
+    PreTransformVertices with identity.  One mesh per `o` / `g` group and material (Assimp splits meshes
+    by material); one Triangle ref per face (loader.cpp:216-222).  `materials_by_name` maps usemtl /
+    object names to material dicts; everything else gets `default_material` (white Lambert 0.73).
+    Textures referenced by an .mtl are not decoded here (no image codec in this package)."""
+    default_material = default_material or material(DIFFUSE, (0.73, 0.73, 0.73))
+    materials_by_name = materials_by_name or {}
+    V, VN, VT = [], [], []
+    groups = []                       # (name, mtl, [face corners [(v, vt, vn), ...]])
+    cur = None
+    cur_name, cur_mtl = "default", None
+
+    def start():
+        nonlocal cur
+        cur = (cur_name, cur_mtl, [])
+        groups.append(cur)
+
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "v":
+                V.append(tuple(float(x) for x in t[1:4]))
+            elif t[0] == "vn":
+                VN.append(tuple(float(x) for x in t[1:4]))
+            elif t[0] == "vt":
+                VT.append((float(t[1]), float(t[2]) if len(t) > 2 else 0.0))
+            elif t[0] in ("o", "g"):
+                cur_name = t[1] if len(t) > 1 else "default"
+                cur = None
+            elif t[0] == "usemtl":
+                cur_mtl = t[1] if len(t) > 1 else None
+                cur = None
+            elif t[0] == "f":
+                if cur is None:
+                    start()
+                corners = []
+                for c in t[1:]:
+                    a = (c.split("/") + ["", ""])[:3]
+                    vi = int(a[0]); vti = int(a[1]) if a[1] else 0; vni = int(a[2]) if a[2] else 0
+                    corners.append((vi - 1 if vi > 0 else len(V) + vi,
+                                    (vti - 1 if vti > 0 else len(VT) + vti) if vti else None,
+                                    (vni - 1 if vni > 0 else len(VN) + vni) if vni else None))
+                for k in range(1, len(corners) - 1):            # triangle fan
+                    cur[2].append((corners[0], corners[k], corners[k + 1]))
+    scene = SceneData(path.rsplit("/", 1)[-1])
+    mat_index = {}
+
+    def mat_id(name, mtl):
+        key = mtl if mtl in materials_by_name else (name if name in materials_by_name else None)
+        m = materials_by_name.get(key, default_material)
+        k = id(m)
+        if k not in mat_index:
+            mat_index[k] = len(scene.materials)
+            scene.materials.append(dict(m))
+        return mat_index[k]
+
+    for name, mtl, faces in groups:
+        if not faces:
+            continue
+        pos, nrm, uvs = [], [], []
+        has_uv = all(c[1] is not None for f_ in faces for c in f_)
+        for f_ in faces:
+            p = [np.asarray(V[c[0]], np.float32) for c in f_]
+            if all(c[2] is not None for c in f_):
+                n = [VN[c[2]] for c in f_]
+            else:                                                # GenNormals: flat
+                g = np.cross(p[1] - p[0], p[2] - p[0]).astype(np.float32)
+                l = np.float32(np.sqrt(np.dot(g, g)))
+                g = g / l if l > 0 else g
+                n = [tuple(g)] * 3
+            pos += [tuple(x) for x in p]
+            nrm += n
+            if has_uv:
+                uvs += [(VT[c[1]][0], 1.0 - VT[c[1]][1]) for c in f_]   # FlipUVs
+        idx, v, nn, uv = _faces_to_mesh(pos, nrm, uvs if has_uv else None)
+        scene.add_mesh(idx, v, nn, mat_id(name, mtl), uvs=uv, name=name)
+    return scene
+
+
+def write_obj(scene, path):
+    """Inverse of load_obj for scenes built from three-vertices-per-face meshes (used by the tests)."""
+    with open(path, "w") as f:
+        vbase = 1
+        for m in scene.meshes:
+            f.write(f"o {m['name'] or 'mesh'}\n")
+            for v in m["vertices"]:
+                f.write("v %.9g %.9g %.9g\n" % tuple(float(x) for x in v))
+            for n in m["normals"]:
+                f.write("vn %.9g %.9g %.9g\n" % tuple(float(x) for x in n))
+            for t in m["indices"]:
+                f.write("f " + " ".join(f"{vbase + int(i)}//{vbase + int(i)}" for i in t) + "\n")
+            vbase += len(m["vertices"])
