@@ -17,7 +17,8 @@ struct RenderParams {
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
-enum { WF_LIVE = 1 };                                   // flags[]: extension ray pending / hit ready
+enum { WF_LIVE = 1, WF_TYPE_SHIFT = 8, WF_TYPE_MASK = 0xf00 };   // flags[]: extension ray pending / hit ready;
+                                                                // bits 8-11: 1 + Material::type of the hit (0 = miss)
 enum { WF_SH_PENDING = 1, WF_SH_UNOCCLUDED = 2,         // sflags[]: shadow ray to trace / traced and unoccluded
        WF_SH_NF_SHIFT = 4, WF_SH_NF_MASK = 0x70 };       //   bits 4-6: components of beta that were inf/NaN at that vertex
 
@@ -39,6 +40,7 @@ struct WfParams {
     WfBuffers b;
     int width, height, max_depth;
     int tile_rank, tile_world, tiles_x;
+    int sort_shade;                // != 0: closest-hit tags slots with the hit material type, shade runs once per type
     int pixels;                    // owned 32x32 tiles * 1024 (padded)
     int num_slots;                 // pixels * strata per batch
     float *acc; unsigned char *img;
@@ -49,7 +51,7 @@ struct WfParams {
 
 hipError_t jtx_wf_generate(const jtx::WfParams &p, int s0, int nstrata, hipStream_t st);
 hipError_t jtx_wf_trace(const jtx::WfParams &p, int any, int grid, bool count, hipStream_t st);
-hipError_t jtx_wf_shade(const jtx::WfParams &p, int grid, bool count, hipStream_t st);
+hipError_t jtx_wf_shade(const jtx::WfParams &p, int grid, bool count, int typeCode, int matMask, hipStream_t st);
 hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write_img, hipStream_t st);
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);

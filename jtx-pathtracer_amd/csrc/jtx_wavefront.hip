@@ -65,7 +65,8 @@ struct WaveFetch {
 // Hands live slots (flags[slot] & want) to the lanes with need == true.  Returns the slot or -1.
 // `scratch` is 64 ints of LDS private to the wave.  The flag words of the following group are
 // requested as soon as a group is opened, so the scan never waits on HBM in steady state.
-JD int waveFetch(WaveFetch &w, bool need, const int *flags, int want, int num_slots, int *scratch) {
+JD int waveFetch(WaveFetch &w, bool need, const int *flags, int want, int num_slots, int *scratch,
+                 int mask2 = 0, int value2 = 0, int value3 = -1) {
     const int lane = threadIdx.x & 63;
     int slot = -1;
     unsigned long long needMask = __ballot(need);
@@ -74,7 +75,8 @@ JD int waveFetch(WaveFetch &w, bool need, const int *flags, int want, int num_sl
             if (w.drained) break;
             if (w.nbase >= num_slots) { w.drained = true; break; }
             w.gbase = w.nbase;
-            w.gmask = __ballot((w.nflag & want) != 0);
+            // live test; the shade launches additionally select by the hit-material tag in bits 8-11
+            w.gmask = __ballot((w.nflag & want) != 0 && (mask2 == 0 || (w.nflag & mask2) == value2 || (w.nflag & mask2) == value3));
             w.request(flags, num_slots);
             continue;
         }
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
         for (int s = blockIdx.x * WBLOCK + threadIdx.x; s < p.num_slots; s += gridDim.x * WBLOCK) {
             if (!(flags[s] & want)) continue;
             if (ANY) { p.b.sflags[s] = WF_SH_UNOCCLUDED; if (COUNT) cnt.n_any++; }   // no geometry: nothing occludes
-            else { p.b.hit[s] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); if (COUNT) cnt.n_closest++; }
+            else { p.b.hit[s] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)); p.b.flags[s] = WF_LIVE; if (COUNT) cnt.n_closest++; }
         }
         if (COUNT) { const unsigned long long a = ANY ? cnt.n_any : cnt.n_closest; if (a) atomicAdd(&p.counters[ANY ? 2 : 1], a); }
         return;
@@ -270,7 +272,14 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
         // ---- E. retire finished rays: one store, nothing to wait for ----
         if (slot >= 0 && cur < 0 && leafN == 0) {
             if (ANY) p.b.sflags[slot] = hitAny ? nf : WF_SH_UNOCCLUDED;    // shade / resolve add the pending radiance (or poison)
-            else p.b.hit[slot] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
+            else {
+                p.b.hit[slot] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
+                if (p.sort_shade) {                                        // shading sorted by the hit material's type
+                    int tag = 0;
+                    if (hitAny) tag = (__float_as_int(tris[3 * rec.prim + 2].y) + 1) << WF_TYPE_SHIFT;
+                    p.b.flags[slot] = WF_LIVE | tag;
+                }
+            }
             slot = -1;
         }
     }
@@ -289,15 +298,18 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
 // ---- shade ---------------------------------------------------------------------------------------
 // Persistent; lanes are filled with live slots by the wave fetcher, so the shading code runs on full
 // waves even when most paths of the batch have already ended.
-template <bool COUNT>
-__global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p) {
+// typeCode: -1 = every live slot; else low 4 bits = 1 + Material::type to take, bit 4 = also take the misses.
+template <bool COUNT, int MASK>
+__global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p, int typeCode) {
     __shared__ int scratchAll[WBLOCK];
     const DevScene &sc = p.scene;
     int *scratch = scratchAll + (threadIdx.x & ~63);
     WaveFetch wf; wf.init(p.b.flags, p.num_slots);
     unsigned nshade = 0;
     while (true) {
-        const int slot = waveFetch(wf, true, p.b.flags, WF_LIVE, p.num_slots, scratch);
+        const int slot = typeCode < 0 ? waveFetch(wf, true, p.b.flags, WF_LIVE, p.num_slots, scratch)
+                                      : waveFetch(wf, true, p.b.flags, WF_LIVE, p.num_slots, scratch, WF_TYPE_MASK,
+                                                  (typeCode & 15) << WF_TYPE_SHIFT, (typeCode & 16) ? 0 : -1);
         if (__ballot(slot >= 0) == 0ull) break;
         if (slot < 0) continue;
         const float4 hv = p.b.hit[slot];
@@ -339,7 +351,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p) {
                         const float lDist = len(sf.point - ls.p);
                         // the contribution an unoccluded shadow ray will add (beta of THIS vertex)
                         f3 f; float pb;
-                        evalPdfBxdf(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
+                        evalPdfBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
                         f = f * absdot(ls.wi, sf.normal);
                         const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
                         const float misWeight = powerHeuristic(1.0f, pl, 1.0f, pb);
@@ -355,7 +367,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p) {
                 f2 u2; u2.x = rng.f(); u2.y = rng.f();
                 BSample bs;
                 if (COUNT) nshade++;
-                if (sampleBxdf(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) {
+                if (sampleBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) {
                     if (bs.pdf > 0.0f) beta = beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);
                     const f3 no = sf.point + bs.wi * RAY_EPSILON;         // integrator.cpp:212
                     p.b.rox[slot] = no.x; p.b.roy[slot] = no.y; p.b.roz[slot] = no.z;
@@ -435,9 +447,18 @@ hipError_t jtx_wf_trace(const WfParams &p, int any, int grid, bool count, hipStr
 #undef LT
     return hipGetLastError();
 }
-hipError_t jtx_wf_shade(const WfParams &p, int grid, bool count, hipStream_t st) {
-    if (count) hipLaunchKernelGGL((k_wf_shade<true>), dim3(grid), dim3(WBLOCK), 0, st, p);
-    else       hipLaunchKernelGGL((k_wf_shade<false>), dim3(grid), dim3(WBLOCK), 0, st, p);
+hipError_t jtx_wf_shade(const WfParams &p, int grid, bool count, int typeCode, int matMask, hipStream_t st) {
+#define LS(C, M) hipLaunchKernelGGL((k_wf_shade<C, M>), dim3(grid), dim3(WBLOCK), 0, st, p, typeCode)
+#define LSM(M) do { if (count) LS(true, M); else LS(false, M); } while (0)
+    switch (matMask) {
+        case 1: LSM(1); break;
+        case 2: LSM(2); break;
+        case 4: LSM(4); break;
+        case 8: LSM(8); break;
+        default: LSM(15); break;
+    }
+#undef LSM
+#undef LS
     return hipGetLastError();
 }
 hipError_t jtx_wf_resolve(const WfParams &p, int s0, int nstrata, int write_img, hipStream_t st) {
