@@ -32,6 +32,9 @@ struct DevScene {
     int stack_depth;       // LDS stack entries per lane = BVH leaf depth (+1), known from the build
     int lds_scene;         // != 0: nodes+tris are staged in LDS
     int material_mask;     // OR of (1 << Material::type) over the scene's materials
+    // top-of-tree treelet for BVHs that live in HBM (jtx_wavefront.hip): the first `treelet_n` nodes in
+    // breadth-first order, re-laid depth-first, staged into LDS by the trace kernels
+    const float4 *treelet; const int *treelet_gidx; int treelet_n;
     float sky[3];
 };
 

@@ -155,6 +155,15 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
         for (int i = threadIdx.x; i < nt; i += WBLOCK) lds_tris[i] = sc.tris[i];
         __syncthreads();
     }
+    // HBM-resident BVH: the top-of-tree treelet goes to LDS instead (same carve position)
+    float4 *tl = lds_nodes;
+    int *tlg = (int *) (tl + 2 * sc.treelet_n);
+    if (!LDS_SCENE && sc.treelet_n > 0) {
+        for (int i = threadIdx.x; i < 2 * sc.treelet_n; i += WBLOCK) tl[i] = sc.treelet[i];
+        for (int i = threadIdx.x; i < sc.treelet_n; i += WBLOCK) tlg[i] = sc.treelet_gidx[i];
+        __syncthreads();
+    }
+    const bool useTl = !LDS_SCENE && sc.treelet_n > 0;
     const float4 *nodes = LDS_SCENE ? lds_nodes : sc.nodes;
     const float4 *tris = LDS_SCENE ? lds_tris : sc.tris;
     int *stk = stack + threadIdx.x;
@@ -196,8 +205,9 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
             const bool regular = finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
                                  fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
                                  tmax == tmax;
-            cur = 0; sp = 0; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
+            cur = useTl ? -2 : 0; sp = 0; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
             if (!regular) {
+                cur = 0;
                 // axis-parallel / non-finite rays: the exact slab test, traced to the end right here
                 // (rare; keeps the main loop on the min/max form only)
                 GlobalSrc src; src.nodes = nodes; src.tris = tris;
@@ -226,15 +236,25 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
 
         // ---- C. interior phase: one node per walking lane per iteration ----
         while (true) {
-            if (slot >= 0 && leafN == 0 && cur >= 0) {
-                const float4 na = nodes[2 * cur], nb = nodes[2 * cur + 1];
+            // cur: >= 0 node index in HBM, <= -2 treelet slot (-2 - slot) in LDS, -1 finished
+            if (slot >= 0 && leafN == 0 && cur != -1) {
+                const bool inT = cur < -1;
+                const int ts = -2 - cur;
+                float4 na, nb;
+                if (inT) { na = tl[2 * ts]; nb = tl[2 * ts + 1]; }
+                else     { na = nodes[2 * cur]; nb = nodes[2 * cur + 1]; }
                 if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
                 const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
                 const int meta = __float_as_int(nb.w);
                 const int off = __float_as_int(nb.z);
                 const int nprims = meta & 0xffff;
                 const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
-                const int nearIdx = neg ? off : cur + 1, farIdx = neg ? cur + 1 : off;
+                int first = cur + 1, second = off;
+                if (inT) {
+                    first = (meta & (1 << 24)) ? tlg[ts] + 1 : cur - 1;        // next treelet record = -2 - (ts + 1)
+                    second = (meta & (1 << 25)) ? off : -2 - off;
+                }
+                const int nearIdx = neg ? second : first, farIdx = neg ? first : second;
                 const bool goDown = boxHit && nprims == 0;
                 const bool doPop = !boxHit && sp > 0;
                 if (goDown) stk[sp * WBLOCK] = farIdx;
@@ -244,9 +264,9 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
                 if (boxHit && nprims != 0) { leafN = nprims; leafOff = off; }
                 cur = goDown ? nearIdx : (boxHit ? cur : popped);
             }
-            const unsigned long long walking = __ballot(slot >= 0 && leafN == 0 && cur >= 0);
+            const unsigned long long walking = __ballot(slot >= 0 && leafN == 0 && cur != -1);
             const unsigned long long parked = __ballot(leafN > 0);
-            const unsigned long long finished = __ballot(slot >= 0 && leafN == 0 && cur < 0);
+            const unsigned long long finished = __ballot(slot >= 0 && leafN == 0 && cur == -1);
             if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE || __popcll(finished) >= JTX_RETIRE_VOTE) break;
         }
 
@@ -270,7 +290,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
         }
 
         // ---- E. retire finished rays: one store, nothing to wait for ----
-        if (slot >= 0 && cur < 0 && leafN == 0) {
+        if (slot >= 0 && cur == -1 && leafN == 0) {
             if (ANY) p.b.sflags[slot] = hitAny ? nf : WF_SH_UNOCCLUDED;    // shade / resolve add the pending radiance (or poison)
             else {
                 p.b.hit[slot] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
@@ -430,6 +450,7 @@ using namespace jtx;
 static size_t wfTraceLds(const DevScene &sc, bool lds) {
     size_t b = (size_t) sc.stack_depth * WBLOCK * sizeof(int) + WBLOCK * sizeof(int);
     if (lds) b += ((size_t) 2 * sc.num_nodes + (size_t) 3 * sc.num_prims) * sizeof(float4);
+    else b += (size_t) sc.treelet_n * (2 * sizeof(float4) + sizeof(int));
     return b;
 }
 

@@ -85,6 +85,7 @@ const float RAY_EPSILON = 1e-4f;              // scene.hpp:9
 // Each written operation is one fp32 rounding.  Valid (and tested) for |x| <= 16.
 // ---------------------------------------------------------------------------------------------
 std::atomic<int> g_sincos_mode{0};
+std::atomic<uint64_t> *g_node_hist = nullptr;     // diagnostic: per-node visit counts (ora_node_histogram)
 
 inline void det_sincos(float x, float *s_out, float *c_out) {
     const float TWO_OVER_PI = 0.636619772367581343f;
@@ -499,6 +500,7 @@ bool closestHit(const ora_scene &s, V3 o, V3 d, float tmin, float tmax, Hit &rec
     while (true) {
         const ora_bvh_node &node = s.nodes[cur];
         if (cnt) cnt->n_nodes_closest++;
+        if (g_node_hist) g_node_hist[cur].fetch_add(1, std::memory_order_relaxed);
         if (aabbHit(node.pmin, node.pmax, o, d, tmin, tmax)) {
             if (node.num_prims > 0) {
                 for (int i = 0; i < node.num_prims; ++i) {
@@ -537,6 +539,7 @@ bool anyHit(const ora_scene &s, V3 o, V3 d, float tmin, float tmax, Counters *cn
     while (true) {
         const ora_bvh_node &node = s.nodes[cur];
         if (cnt) cnt->n_nodes_any++;
+        if (g_node_hist) g_node_hist[cur].fetch_add(1, std::memory_order_relaxed);
         if (aabbHit(node.pmin, node.pmax, o, d, tmin, tmax)) {
             if (node.num_prims > 0) {
                 for (int i = 0; i < node.num_prims; ++i) {
@@ -1115,7 +1118,21 @@ inline uint8_t toByte(float v) {                                              //
 // =============================================================================================
 extern "C" {
 
+void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int sample_begin, int sample_end,
+                int reference_barriers, float *acc_rgb, uint8_t *img_rgb, ora_counters *counters);
+
 void ora_set_sincos_mode(int mode) { g_sincos_mode.store(mode); }
+
+// diagnostic: renders the frame once more and returns how often every BVH node was visited (closest + any)
+void ora_node_histogram(const ora_scene *s, const ora_camera_desc *cam, int threads, uint64_t *out) {
+    std::vector<std::atomic<uint64_t>> h(s->nodes.size());
+    for (auto &x : h) x.store(0);
+    g_node_hist = h.data();
+    std::vector<float> acc(3 * (size_t) cam->width * cam->height);
+    ora_render(s, cam, threads, 0, cam->x_pixel_samples * cam->y_pixel_samples, 0, acc.data(), nullptr, nullptr);
+    g_node_hist = nullptr;
+    for (size_t i = 0; i < h.size(); ++i) out[i] = h[i].load();
+}
 
 uint32_t ora_fnv1a_3(uint32_t x, uint32_t y, uint32_t n) { return fnv1a_3(x, y, n); }
 

@@ -160,6 +160,9 @@ void ora_radiance_samples(const ora_scene *s, const ora_camera_desc *cam, int n,
 void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int sample_begin, int sample_end,
                 int reference_barriers, float *acc_rgb, uint8_t *img_rgb, ora_counters *counters);
 
+/* diagnostic: per-node visit counts of one frame (closest + any), out[num_nodes] */
+void ora_node_histogram(const ora_scene *s, const ora_camera_desc *cam, int threads, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif
