@@ -14,7 +14,15 @@
 
 namespace jtx {
 
-constexpr int BLOCK = 256;
+#ifndef JTX_RP_BLOCK
+#define JTX_RP_BLOCK 256
+#endif
+#ifndef JTX_RP_OCC
+#define JTX_RP_OCC 8
+#endif
+constexpr int BLOCK = JTX_RP_BLOCK;          // threads per workgroup of the render / batch kernels
+constexpr int WAVES_PER_BLOCK = BLOCK / 64;
+constexpr int BLOCKS_PER_TILE = 16 / WAVES_PER_BLOCK;   // a 32x32 tile = 16 wave-sized 8x8 pixel blocks
 
 // ---- LDS carve: [stack: stack_depth x BLOCK ints][nodes][tris] (all 16-B aligned) ----
 JD void stageScene(const DevScene &sc, float4 *lds_nodes, float4 *lds_tris) {
@@ -121,7 +129,7 @@ JD unsigned char toByte(float v) {                                     // image.
 }
 
 template <bool COUNT, bool LDS_SCENE, int MASK>
-__global__ void __launch_bounds__(BLOCK, 8) k_render_pixels(RenderParams p) {
+__global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
     int *stack = smem;
@@ -131,9 +139,9 @@ __global__ void __launch_bounds__(BLOCK, 8) k_render_pixels(RenderParams p) {
 
     // work mapping: block = 4 waves = 4 consecutive 8x8 sub-blocks of one owned 32x32 tile
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int owned = blockIdx.x >> 2;                                 // index into this rank's tiles
+    const int owned = blockIdx.x / BLOCKS_PER_TILE;                    // index into this rank's tiles
     const int tile = p.tile_rank + owned * p.tile_world;               // global 32x32 tile id, row-major (camera.cpp:55-64)
-    const int sub = ((blockIdx.x & 3) << 2) | wave;                    // 0..15 sub-block inside the tile
+    const int sub = (blockIdx.x % BLOCKS_PER_TILE) * WAVES_PER_BLOCK + wave;   // 0..15 sub-block inside the tile
     const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
     const int row = trow * 32 + (sub >> 2) * 8 + (lane >> 3);
     const int col = tcol * 32 + (sub & 3) * 8 + (lane & 7);
@@ -313,7 +321,7 @@ static size_t ldsBytes(const DevScene &sc, bool withScene) {
 
 hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
-    const dim3 grid((unsigned) num_owned_tiles * 4u), block(BLOCK);
+    const dim3 grid((unsigned) num_owned_tiles * (unsigned) BLOCKS_PER_TILE), block(BLOCK);
     const bool lds = p.scene.lds_scene != 0;
     const size_t shmem = ldsBytes(p.scene, lds);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # local: rebuild the HIP library, then run GPU parity tests + a short bench on the MI355X box
 # env: INTEG=<1|2|3> integrator for the bench, NOTEST=1 skips pytest, STEPS
-cd /root/repo
+cd "$(dirname "$0")/.."
 python -c "import jtx_pathtracer_amd as j; j.build_all(force=True)" || exit 1
 T="timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 &&"
 [ -n "$NOTEST" ] && T=""

@@ -1,6 +1,6 @@
 # diagnostic: per-phase wave-cycle shares (needs a build with -DJTX_PROFILE_PHASES)
 import ctypes as C, sys
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jtx_pathtracer_amd as jtx
 lib = jtx._capi.load()
 data = jtx.scenes.cornell(); sc = jtx.Scene(data); sc.buildBVH()

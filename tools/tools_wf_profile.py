@@ -1,6 +1,6 @@
 # diagnostic: per-kernel-kind GPU time of one wavefront frame (C2 by default)
 import ctypes as C, sys, os
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import jtx_pathtracer_amd as jtx
 lib = jtx._capi.load()
