@@ -35,12 +35,13 @@ template <class T> struct DevBuf {
 };
 
 constexpr size_t kLdsSceneBudget = 40 * 1024;   // nodes+tris staged in LDS when they fit this
+constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + tris staged in LDS when they fit this (8 blocks/CU)
 
 } // namespace
 
 struct jtx_mi_scene {
     jtxh::BvhResult bvh;
-    DevBuf<float4> nodes, tris, shade, treelet;
+    DevBuf<float4> nodes, tnodes, tris, shade, treelet;
     DevBuf<int> treelet_gidx;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
@@ -142,6 +143,51 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         shade[4 * i + 3] = make_float4(uv[3], uv[4], uv[5], fmat);
     }
     s.nodes.upload(nodes); s.tris.upload(tris); s.shade.upload(shade);
+
+    // ---- threaded node records: one near-first depth-first ordering per direction-sign octant ----
+    // (layout and rationale: traverseThreaded in jtx_scene_dev.hpp)
+    {
+        std::vector<float4> tn(2 * 8 * nn);
+        if (nn) {
+            std::vector<int> size(nn, 1);                               // subtree sizes (children follow their parent in b.nodes)
+            for (size_t i = nn; i-- > 0;)
+                if (b.nodes[i].num_prims == 0) size[i] = 1 + size[i + 1] + size[b.nodes[i].offset];
+            std::vector<int> order(nn);
+            for (int k = 0; k < 8; ++k) {
+                // near-first DFS: dirIsNeg[axis] ? (second, first) : (first, second)   (scene.cpp:40-46)
+                std::vector<int> st{0}; size_t pos = 0;
+                while (!st.empty()) {
+                    const int g = st.back(); st.pop_back();
+                    order[pos++] = g;
+                    const jtx_mi_bvh_node &n = b.nodes[g];
+                    if (n.num_prims == 0) {
+                        const int first = g + 1, second = n.offset;
+                        const bool neg = (k >> n.axis) & 1;
+                        st.push_back(neg ? first : second);                // far child: visited after the near subtree
+                        st.push_back(neg ? second : first);
+                    }
+                }
+                for (size_t i = 0; i < nn; ++i) {
+                    const jtx_mi_bvh_node &n = b.nodes[order[i]];
+                    int z, w;
+                    if (n.num_prims == 0) {
+                        const size_t behind = i + (size_t) size[order[i]];
+                        z = behind < nn ? (int) ((size_t) k * nn + behind) : -1;
+                        w = 0;
+                    } else {
+                        z = n.offset;
+                        w = (int) n.num_prims | (i + 1 == nn ? (int) 0x80000000u : 0);
+                    }
+                    float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
+                    const size_t r = (size_t) k * nn + i;
+                    tn[2 * r + 0] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
+                    tn[2 * r + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+                }
+            }
+        }
+        s.tnodes.upload(tn);
+        s.dev.tnodes = s.tnodes.p;
+    }
 
     // ---- top-of-tree treelet (scenes whose BVH stays in HBM) ----
     // Node visits concentrate at the top of the tree (measured: the first 256 nodes in breadth-first order take
@@ -252,10 +298,11 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     ds.num_nodes = (int) nn; ds.num_prims = (int) np; ds.num_lights = d.num_lights; ds.num_materials = d.num_materials;
     ds.stack_depth = b.max_depth > 0 ? b.max_depth : 1;
     ds.lds_scene = (nn > 0 && nn * 32 + np * 48 <= kLdsSceneBudget) ? 1 : 0;
+    ds.lds_threaded = (nn > 0 && 8 * nn * 32 + np * 48 <= kLdsThreadedBudget) ? 1 : 0;
     ds.material_mask = 0;
     for (int i = 0; i < d.num_materials; ++i) ds.material_mask |= 1 << d.materials[i].type;
     for (int k = 0; k < 3; ++k) ds.sky[k] = d.sky_color[k];
-    s.device_bytes = (nodes.size() + tris.size() + shade.size()) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
+    s.device_bytes = (nodes.size() * 9 + tris.size() + shade.size()) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
                      lights.size() * sizeof(DLight) + tex.size() * sizeof(DTexture) + texels.size() * sizeof(float);
 }
 

@@ -24,10 +24,10 @@ constexpr int BLOCK = JTX_RP_BLOCK;          // threads per workgroup of the ren
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr int BLOCKS_PER_TILE = 16 / WAVES_PER_BLOCK;   // a 32x32 tile = 16 wave-sized 8x8 pixel blocks
 
-// ---- LDS carve: [stack: stack_depth x BLOCK ints][nodes][tris] (all 16-B aligned) ----
-JD void stageScene(const DevScene &sc, float4 *lds_nodes, float4 *lds_tris) {
-    const int nn = 2 * sc.num_nodes, nt = 3 * sc.num_prims;
-    for (int i = threadIdx.x; i < nn; i += BLOCK) lds_nodes[i] = sc.nodes[i];
+// ---- LDS carve of the stackless kernels: [8 threaded node orderings][tris] (16-B aligned), no stack ----
+JD void stageScene(const DevScene &sc, float4 *lds_tnodes, float4 *lds_tris) {
+    const int nn = 2 * 8 * sc.num_nodes, nt = 3 * sc.num_prims;
+    for (int i = threadIdx.x; i < nn; i += BLOCK) lds_tnodes[i] = sc.tnodes[i];
     for (int i = threadIdx.x; i < nt; i += BLOCK) lds_tris[i] = sc.tris[i];
     __syncthreads();
 }
@@ -62,10 +62,10 @@ struct PathState {
 #endif
 
 template <bool COUNT, int MASK, class Src>
-JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int maxDepth, PathState &ps, Counters9 &cnt) {
+JD bool pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &ps, Counters9 &cnt) {
     HitRec h;
     PH_DECL
-    const bool hit = traverse<false, COUNT>(src, sc.num_nodes, stk, stride, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
+    const bool hit = traverseNoStack<false, COUNT>(src, sc.num_nodes, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
     PH(0)
     if (!hit) {                                                       // integrator.cpp:183-187
         ps.radiance = ps.radiance + ps.beta * a3(sc.sky);
@@ -86,8 +86,7 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int *stk, int stride, int
             const float lDist = len(sf.point - ls.p);
             HitRec dummy;
             PH(1)
-            const bool occluded = traverse<true, COUNT>(src, sc.num_nodes, stk, stride, sOrigin, ls.wi, 0.0f,
-                                                        lDist - RAY_EPSILON, dummy, cnt);
+            const bool occluded = traverseNoStack<true, COUNT>(src, sc.num_nodes, sOrigin, ls.wi, 0.0f, lDist - RAY_EPSILON, dummy, cnt);
             PH(2)
             if (!occluded) {
                 f3 f; float pb;
@@ -132,10 +131,9 @@ template <bool COUNT, bool LDS_SCENE, int MASK>
 __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
-    int *stack = smem;
-    float4 *lds_nodes = (float4 *) (smem + sc.stack_depth * BLOCK);
-    float4 *lds_tris = lds_nodes + 2 * sc.num_nodes;
-    if (LDS_SCENE) stageScene(sc, lds_nodes, lds_tris);
+    float4 *lds_tnodes = (float4 *) smem;
+    float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
+    if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);
 
     // work mapping: block = 4 waves = 4 consecutive 8x8 sub-blocks of one owned 32x32 tile
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -148,7 +146,6 @@ __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParam
     const bool inside = row < p.height && col < p.width;
 
     Counters9 cnt = {};
-    int *stk = stack + threadIdx.x;
     if (inside) {
         const size_t pix = (size_t) row * p.width + col;
         f3 acc = mk3(0.0f);
@@ -163,10 +160,10 @@ __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParam
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
             bool done;
-            if (LDS_SCENE) { LdsSrc src; src.nodes = lds_nodes; src.tris = lds_tris;
-                             done = pathBounce<COUNT, MASK>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
-            else           { GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
-                             done = pathBounce<COUNT, MASK>(sc, src, stk, BLOCK, p.max_depth, ps, cnt); }
+            if (LDS_SCENE) { LdsSrc src; src.nodes = nullptr; src.tnodes = lds_tnodes; src.tris = lds_tris;
+                             done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
+            else           { GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                             done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
             if (done) {
                 f3 c = ps.radiance;                                    // camera.cpp:110-112
                 if (c.x > 1.0f) c.x = 1.0f;
@@ -215,9 +212,9 @@ __global__ void __launch_bounds__(BLOCK) k_closest_batch(DevScene sc, int n, con
     if (i >= n) return;
     Counters9 cnt = {};
     HitRec h; h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f;
-    GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
+    GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
     const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    const bool r = traverse<false, false>(src, sc.num_nodes, smem + threadIdx.x, BLOCK, ro, rd, tmin, tmax, h, cnt);
+    const bool r = traverseNoStack<false, false>(src, sc.num_nodes, ro, rd, tmin, tmax, h, cnt);
     hit[i] = r ? 1 : 0;
     Surface sf; sf.point = sf.normal = mk3(0.0f); sf.uv = mk2(0.0f, 0.0f);
     if (r) sf = makeSurface(sc.shade, h, ro, rd); else { h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f; }
@@ -234,9 +231,9 @@ __global__ void __launch_bounds__(BLOCK) k_any_batch(DevScene sc, int n, const f
     if (i >= n) return;
     Counters9 cnt = {};
     HitRec h;
-    GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
+    GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
     const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    hit[i] = traverse<true, false>(src, sc.num_nodes, smem + threadIdx.x, BLOCK, ro, rd, tmin[i], tmax[i], h, cnt) ? 1 : 0;
+    hit[i] = traverseNoStack<true, false>(src, sc.num_nodes, ro, rd, tmin[i], tmax[i], h, cnt) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_bxdf_batch(DevScene sc, int mode, int material, int n, const float *normal,
@@ -284,8 +281,8 @@ __global__ void __launch_bounds__(BLOCK) k_radiance_samples(DevScene sc, DCam ca
     Counters9 cnt = {};
     PathState ps;
     startPath(cam, row[i], col[i], sample[i], ps);
-    GlobalSrc src; src.nodes = sc.nodes; src.tris = sc.tris;
-    while (!pathBounce<false, MAT_ALL>(sc, src, smem + threadIdx.x, BLOCK, maxDepth, ps, cnt)) {}
+    GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
+    while (!pathBounce<false, MAT_ALL>(sc, src, maxDepth, ps, cnt)) {}
     f3 c = ps.radiance;
     if (c.x > 1.0f) c.x = 1.0f;
     if (c.y > 1.0f) c.y = 1.0f;
@@ -313,16 +310,16 @@ __global__ void __launch_bounds__(BLOCK) k_sincos(const float *x, int n, float *
 // ------------------------------------------------------------------------------------------------
 using namespace jtx;
 
-static size_t ldsBytes(const DevScene &sc, bool withScene) {
-    size_t b = (size_t) sc.stack_depth * BLOCK * sizeof(int);
-    if (withScene) b += ((size_t) 2 * sc.num_nodes + (size_t) 3 * sc.num_prims) * sizeof(float4);
+static size_t ldsBytes(const DevScene &sc, bool withScene) {      // stackless: only the staged scene, if any
+    size_t b = 0;
+    if (withScene) b += ((size_t) 2 * 8 * sc.num_nodes + (size_t) 3 * sc.num_prims) * sizeof(float4);
     return b;
 }
 
 hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned) num_owned_tiles * (unsigned) BLOCKS_PER_TILE), block(BLOCK);
-    const bool lds = p.scene.lds_scene != 0;
+    const bool lds = p.scene.lds_threaded != 0;
     const size_t shmem = ldsBytes(p.scene, lds);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
 #define LAUNCH_RP(C, L, M) hipLaunchKernelGGL((k_render_pixels<C, L, M>), grid, block, shmem, stream, p)
