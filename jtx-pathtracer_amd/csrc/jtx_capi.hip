@@ -354,7 +354,7 @@ int autoIntegrator(const jtx_mi_scene &s) {
     const char *e = getenv("JTX_INTEGRATOR");
     const int v = e ? atoi(e) : 0;
     if (v >= 1 && v <= 4) return v;
-    return (s.dev.lds_scene && s.dev.material_mask == MAT_DIFFUSE_ONLY) ? 1 : 2;
+    return (s.dev.lds_threaded || s.dev.material_mask == MAT_DIFFUSE_ONLY) ? 1 : 2;
 }
 
 // ---- wavefront integrator orchestration ----
@@ -557,7 +557,7 @@ void jtx_mi_scene_destroy(jtx_mi_scene *scene) {
 int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     if (!s || !out) return fail("null argument");
     out->num_nodes = s->dev.num_nodes; out->num_prims = s->dev.num_prims; out->max_depth = s->bvh.max_depth;
-    out->lds_resident = s->dev.lds_scene; out->scene_radius = s->bvh.scene_radius; out->device_bytes = s->device_bytes;
+    out->lds_resident = s->dev.lds_threaded; out->scene_radius = s->bvh.scene_radius; out->device_bytes = s->device_bytes;
     out->auto_integrator = autoIntegrator(*s);
     return 0;
 }

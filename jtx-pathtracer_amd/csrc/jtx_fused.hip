@@ -28,17 +28,15 @@ template <bool COUNT, bool LDS_SCENE, int MASK>
 __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
-    int *stack = smem;
-    float4 *lds_nodes = (float4 *) (smem + sc.stack_depth * FBLOCK);
-    float4 *lds_tris = lds_nodes + 2 * sc.num_nodes;
+    float4 *lds_tnodes = (float4 *) smem;                       // [8 threaded node orderings][tris], stackless
+    float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
     if (LDS_SCENE) {
-        const int nn = 2 * sc.num_nodes, nt = 3 * sc.num_prims;
-        for (int i = threadIdx.x; i < nn; i += FBLOCK) lds_nodes[i] = sc.nodes[i];
+        const int nn = 2 * 8 * sc.num_nodes, nt = 3 * sc.num_prims;
+        for (int i = threadIdx.x; i < nn; i += FBLOCK) lds_tnodes[i] = sc.tnodes[i];
         for (int i = threadIdx.x; i < nt; i += FBLOCK) lds_tris[i] = sc.tris[i];
         __syncthreads();
     }
-    GlobalSrc src; src.nodes = LDS_SCENE ? lds_nodes : sc.nodes; src.tris = LDS_SCENE ? lds_tris : sc.tris;
-    int *stk = stack + threadIdx.x;
+    GlobalSrc src; src.nodes = nullptr; src.tnodes = LDS_SCENE ? lds_tnodes : sc.tnodes; src.tris = LDS_SCENE ? lds_tris : sc.tris;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int owned = blockIdx.x >> 2;
     const int tile = p.tile_rank + owned * p.tile_world;
@@ -142,7 +140,7 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
         f3 inv = stage == 0 ? mk3(1.0f / sd.x, 1.0f / sd.y, 1.0f / sd.z) : rinv;
         float tmin = stage == 0 ? 0.0f : 0.001f, tmax = stage == 0 ? stmax : __builtin_inff();
         int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-        int cur = stage < 2 ? 0 : -1, sp = 0, leafOff = 0, leafN = 0;
+        int cur = stage < 2 ? negmask * sc.num_nodes : -1, leafOff = 0, leafN = 0;      // leafN: count | last-record flag
         bool hitAny = false;
         HitRec rec; rec.t = 0.0f; rec.prim = -1; rec.b1 = rec.b2 = 0.0f;
         bool needSetup = stage < 2;                            // validate (regular / empty scene) the ray just loaded
@@ -156,7 +154,7 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
                     if (stage == 1) {
                         o = ro; d = rd; inv = rinv; tmin = 0.001f; tmax = __builtin_inff();
                         negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-                        cur = 0; sp = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
+                        cur = negmask * sc.num_nodes; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
                         needSetup = true;
                     }
                 }
@@ -168,8 +166,8 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
                     if (sc.num_nodes == 0) { cur = -1; if (COUNT) { if (stage == 0) cnt.n_any++; else cnt.n_closest++; } }
                     else if (!regular) {
                         // axis-parallel / non-finite rays: exact slab test, traced to the end right here (rare)
-                        if (stage == 0) hitAny = traverseT<true, COUNT, false>(src, stk, FBLOCK, o, d, inv, negmask, tmin, tmax, rec, cnt);
-                        else            hitAny = traverseT<false, COUNT, false>(src, stk, FBLOCK, o, d, inv, negmask, tmin, tmax, rec, cnt);
+                        if (stage == 0) hitAny = traverseThreaded<true, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
+                        else            hitAny = traverseThreaded<false, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
                         cur = -1;
                     } else if (COUNT) { if (stage == 0) cnt.n_any++; else cnt.n_closest++; }
                 }
@@ -182,33 +180,24 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
 #pragma unroll
                 for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
                     if (leafN == 0 && cur >= 0) {
-                        const float4 na = src.node(cur, 0);
-                        const float4 nb = src.node(cur, 1);
+                        const float4 na = src.tnode(cur, 0);
+                        const float4 nb = src.tnode(cur, 1);
                         if (COUNT) { if (stage == 0) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
-                        if (slabRegular(na, nb, o, inv, tmin, tmax)) {
-                            const int meta = __float_as_int(nb.w);
-                            const int off = __float_as_int(nb.z);
-                            if ((meta & 0xffff) != 0) { leafOff = off; leafN = meta & 0xffff; }
-                            else {
-                                const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
-                                stk[sp * FBLOCK] = neg ? cur + 1 : off;
-                                sp++;
-                                cur = neg ? off : cur + 1;
-                            }
-                        } else {
-                            if (sp == 0) cur = -1;
-                            else { --sp; cur = stk[sp * FBLOCK]; }
-                        }
+                        const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
+                        const int w = __float_as_int(nb.w), z = __float_as_int(nb.z);
+                        if (boxHit && w != 0) { leafN = w; leafOff = z; }
+                        else cur = (boxHit || w != 0) ? (w < 0 ? -1 : cur + 1) : z;
                     }
                 }
                 const unsigned long long walking = __ballot(leafN == 0 && cur >= 0);
-                const unsigned long long parked = __ballot(leafN > 0);
+                const unsigned long long parked = __ballot(leafN != 0);
                 const unsigned long long ended = __ballot(stage < 2 && leafN == 0 && cur < 0);
                 if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE || __popcll(ended) >= JTX_SWITCH_VOTE) break;
             }
             // ---- leaf phase ----
-            if (leafN > 0) {
-                for (int i = 0; i < leafN; ++i) {
+            if (leafN != 0) {
+                const int n = leafN & 0xffff;
+                for (int i = 0; i < n; ++i) {
                     const int prim = leafOff + i;
                     if (COUNT) { if (stage == 0) cnt.n_tri_any++; else cnt.n_tri_closest++; }
                     float b1, b2, root;
@@ -219,9 +208,8 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
                     rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
                     if (COUNT) cnt.n_accept++;
                 }
+                cur = ((stage == 0 && hitAny) || leafN < 0) ? -1 : cur + 1;
                 leafN = 0;
-                if ((stage == 0 && hitAny) || sp == 0) cur = -1;
-                else { --sp; cur = stk[sp * FBLOCK]; }
             }
         }
     }
@@ -253,9 +241,9 @@ using namespace jtx;
 hipError_t jtx_launch_render_fused(const RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned) num_owned_tiles * 4u), block(FBLOCK);
-    const bool lds = p.scene.lds_scene != 0;
-    size_t shmem = (size_t) p.scene.stack_depth * FBLOCK * sizeof(int);
-    if (lds) shmem += ((size_t) 2 * p.scene.num_nodes + (size_t) 3 * p.scene.num_prims) * sizeof(float4);
+    const bool lds = p.scene.lds_threaded != 0;
+    size_t shmem = 0;
+    if (lds) shmem += ((size_t) 2 * 8 * p.scene.num_nodes + (size_t) 3 * p.scene.num_prims) * sizeof(float4);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
 #define LAUNCH_F(C, L, M) hipLaunchKernelGGL((k_render_fused<C, L, M>), grid, block, shmem, stream, p)
     if (lambert) {

@@ -18,7 +18,7 @@ namespace jtx {
 #define JTX_RP_BLOCK 256
 #endif
 #ifndef JTX_RP_OCC
-#define JTX_RP_OCC 8
+#define JTX_RP_OCC 7
 #endif
 constexpr int BLOCK = JTX_RP_BLOCK;          // threads per workgroup of the render / batch kernels
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;

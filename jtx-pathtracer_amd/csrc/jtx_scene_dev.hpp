@@ -136,7 +136,7 @@ JD bool finiteNonZero(float x) { return fabsf(x) < __builtin_inff() && x != 0.0f
 // exactly the reference's; only the interleaving between lanes differs.
 //  * stack: one LDS column per lane (stk[level * stride]), depth bounded by the BVH build.
 #ifndef JTX_STEPS_PER_VOTE
-#define JTX_STEPS_PER_VOTE 2     // interior steps between two scheduling votes (the ballots are pure overhead)
+#define JTX_STEPS_PER_VOTE 4     // interior steps between two scheduling votes (the ballots are pure overhead)
 #endif
 #ifndef JTX_LEAF_VOTE
 #define JTX_LEAF_VOTE 12      // lanes parked on a leaf that end the interior phase of a wave

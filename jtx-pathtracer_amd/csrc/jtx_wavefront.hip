@@ -145,28 +145,18 @@ template <int ANY, bool COUNT, bool LDS_SCENE>
 __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
-    int *stack = smem;
-    int *scratchAll = smem + sc.stack_depth * WBLOCK;
-    float4 *lds_nodes = (float4 *) (scratchAll + WBLOCK);
-    float4 *lds_tris = lds_nodes + 2 * sc.num_nodes;
+    // LDS: [wave scratch: WBLOCK ints][8 threaded node orderings][tris]  -- the traversal is stackless
+    int *scratchAll = smem;
+    float4 *lds_tnodes = (float4 *) (scratchAll + WBLOCK);
+    float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
     if (LDS_SCENE) {
-        const int nn = 2 * sc.num_nodes, nt = 3 * sc.num_prims;
-        for (int i = threadIdx.x; i < nn; i += WBLOCK) lds_nodes[i] = sc.nodes[i];
+        const int nn = 2 * 8 * sc.num_nodes, nt = 3 * sc.num_prims;
+        for (int i = threadIdx.x; i < nn; i += WBLOCK) lds_tnodes[i] = sc.tnodes[i];
         for (int i = threadIdx.x; i < nt; i += WBLOCK) lds_tris[i] = sc.tris[i];
         __syncthreads();
     }
-    // HBM-resident BVH: the top-of-tree treelet goes to LDS instead (same carve position)
-    float4 *tl = lds_nodes;
-    int *tlg = (int *) (tl + 2 * sc.treelet_n);
-    if (!LDS_SCENE && sc.treelet_n > 0) {
-        for (int i = threadIdx.x; i < 2 * sc.treelet_n; i += WBLOCK) tl[i] = sc.treelet[i];
-        for (int i = threadIdx.x; i < sc.treelet_n; i += WBLOCK) tlg[i] = sc.treelet_gidx[i];
-        __syncthreads();
-    }
-    const bool useTl = !LDS_SCENE && sc.treelet_n > 0;
-    const float4 *nodes = LDS_SCENE ? lds_nodes : sc.nodes;
+    const float4 *tnodes = LDS_SCENE ? lds_tnodes : sc.tnodes;
     const float4 *tris = LDS_SCENE ? lds_tris : sc.tris;
-    int *stk = stack + threadIdx.x;
     int *scratch = scratchAll + (threadIdx.x & ~63);
     const int *flags = ANY ? p.b.sflags : p.b.flags;
     const int want = ANY ? WF_SH_PENDING : WF_LIVE;
@@ -185,7 +175,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
     }
 
     WaveFetch wf; wf.init(flags, p.num_slots);
-    int slot = -1, cur = -1, sp = 0, leafOff = 0, leafN = 0, negmask = 0;
+    int slot = -1, cur = -1, leafOff = 0, leafN = 0, negmask = 0;      // leafN: count | last-record flag (threaded records)
     bool hitAny = false;
     f3 o = mk3(0.0f), d = mk3(1.0f), inv = mk3(1.0f);
     float tmax = 0.0f;
@@ -205,13 +195,12 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
             const bool regular = finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
                                  fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
                                  tmax == tmax;
-            cur = useTl ? -2 : 0; sp = 0; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
+            cur = negmask * sc.num_nodes; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
             if (!regular) {
-                cur = 0;
                 // axis-parallel / non-finite rays: the exact slab test, traced to the end right here
                 // (rare; keeps the main loop on the min/max form only)
-                GlobalSrc src; src.nodes = nodes; src.tris = tris;
-                hitAny = traverseT<ANY != 0, COUNT, false>(src, stk, WBLOCK, o, d, inv, negmask, tmin, tmax, rec, cnt);
+                GlobalSrc src; src.nodes = nullptr; src.tnodes = tnodes; src.tris = tris;
+                hitAny = traverseThreaded<ANY != 0, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
                 cur = -1;
             } else if (COUNT) { if (ANY) cnt.n_any++; else cnt.n_closest++; }
         }
@@ -236,44 +225,28 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
 
         // ---- C. interior phase: one node per walking lane per iteration ----
         while (true) {
-            // cur: >= 0 node index in HBM, <= -2 treelet slot (-2 - slot) in LDS, -1 finished
-            if (slot >= 0 && leafN == 0 && cur != -1) {
-                const bool inT = cur < -1;
-                const int ts = -2 - cur;
-                float4 na, nb;
-                if (inT) { na = tl[2 * ts]; nb = tl[2 * ts + 1]; }
-                else     { na = nodes[2 * cur]; nb = nodes[2 * cur + 1]; }
-                if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
-                const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
-                const int meta = __float_as_int(nb.w);
-                const int off = __float_as_int(nb.z);
-                const int nprims = meta & 0xffff;
-                const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
-                int first = cur + 1, second = off;
-                if (inT) {
-                    first = (meta & (1 << 24)) ? tlg[ts] + 1 : cur - 1;        // next treelet record = -2 - (ts + 1)
-                    second = (meta & (1 << 25)) ? off : -2 - off;
+#pragma unroll
+            for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
+                if (slot >= 0 && leafN == 0 && cur >= 0) {
+                    const float4 na = tnodes[2 * cur], nb = tnodes[2 * cur + 1];
+                    if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
+                    const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
+                    const int w = __float_as_int(nb.w), z = __float_as_int(nb.z);
+                    if (boxHit && w != 0) { leafN = w; leafOff = z; }                    // park on the leaf
+                    else cur = (boxHit || w != 0) ? (w < 0 ? -1 : cur + 1) : z;          // next record / skip link
                 }
-                const int nearIdx = neg ? second : first, farIdx = neg ? first : second;
-                const bool goDown = boxHit && nprims == 0;
-                const bool doPop = !boxHit && sp > 0;
-                if (goDown) stk[sp * WBLOCK] = farIdx;
-                int popped = -1;
-                if (doPop) popped = stk[(sp - 1) * WBLOCK];
-                sp += (goDown ? 1 : 0) - (doPop ? 1 : 0);
-                if (boxHit && nprims != 0) { leafN = nprims; leafOff = off; }
-                cur = goDown ? nearIdx : (boxHit ? cur : popped);
             }
-            const unsigned long long walking = __ballot(slot >= 0 && leafN == 0 && cur != -1);
-            const unsigned long long parked = __ballot(leafN > 0);
-            const unsigned long long finished = __ballot(slot >= 0 && leafN == 0 && cur == -1);
+            const unsigned long long walking = __ballot(slot >= 0 && leafN == 0 && cur >= 0);
+            const unsigned long long parked = __ballot(leafN != 0);
+            const unsigned long long finished = __ballot(slot >= 0 && leafN == 0 && cur < 0);
             if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE || __popcll(finished) >= JTX_RETIRE_VOTE) break;
         }
 
         // ---- D. leaf phase ----
-        if (leafN > 0) {
-            GlobalSrc src; src.nodes = nodes; src.tris = tris;
-            for (int i = 0; i < leafN; ++i) {
+        if (leafN != 0) {
+            GlobalSrc src; src.nodes = nullptr; src.tris = tris;
+            const int n = leafN & 0xffff;
+            for (int i = 0; i < n; ++i) {
                 const int prim = leafOff + i;
                 if (COUNT) { if (ANY) cnt.n_tri_any++; else cnt.n_tri_closest++; }
                 float b1, b2, root;
@@ -284,13 +257,12 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
                 rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
                 if (COUNT) cnt.n_accept++;
             }
+            cur = ((ANY && hitAny) || leafN < 0) ? -1 : cur + 1;
             leafN = 0;
-            if ((ANY && hitAny) || sp == 0) cur = -1;
-            else { --sp; cur = stk[sp * WBLOCK]; }
         }
 
         // ---- E. retire finished rays: one store, nothing to wait for ----
-        if (slot >= 0 && cur == -1 && leafN == 0) {
+        if (slot >= 0 && cur < 0 && leafN == 0) {
             if (ANY) p.b.sflags[slot] = hitAny ? nf : WF_SH_UNOCCLUDED;    // shade / resolve add the pending radiance (or poison)
             else {
                 p.b.hit[slot] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
@@ -448,9 +420,8 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_resolve(WfParams p, int s0, int n
 using namespace jtx;
 
 static size_t wfTraceLds(const DevScene &sc, bool lds) {
-    size_t b = (size_t) sc.stack_depth * WBLOCK * sizeof(int) + WBLOCK * sizeof(int);
-    if (lds) b += ((size_t) 2 * sc.num_nodes + (size_t) 3 * sc.num_prims) * sizeof(float4);
-    else b += (size_t) sc.treelet_n * (2 * sizeof(float4) + sizeof(int));
+    size_t b = WBLOCK * sizeof(int);
+    if (lds) b += ((size_t) 2 * 8 * sc.num_nodes + (size_t) 3 * sc.num_prims) * sizeof(float4);
     return b;
 }
 
@@ -459,7 +430,7 @@ hipError_t jtx_wf_generate(const WfParams &p, int s0, int nstrata, hipStream_t s
     return hipGetLastError();
 }
 hipError_t jtx_wf_trace(const WfParams &p, int any, int grid, bool count, hipStream_t st) {
-    const bool lds = p.scene.lds_scene != 0;
+    const bool lds = p.scene.lds_threaded != 0;
     const size_t sh = wfTraceLds(p.scene, lds);
     const dim3 g(grid), b(WBLOCK);
 #define LT(A, C, L) hipLaunchKernelGGL((k_wf_trace<A, C, L>), g, b, sh, st, p)

@@ -44,23 +44,22 @@ template <bool COUNT, bool LDS_SCENE>
 __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
-    int *stack = smem;
-    int *poolAll = smem + sc.stack_depth * PBLOCK;
-    float4 *lds_nodes = (float4 *) (poolAll + 4 * POOL_INTS);
-    float4 *lds_tris = lds_nodes + 2 * sc.num_nodes;
+    // LDS: [4 wave pools][8 threaded node orderings][tris]  -- the traversal is stackless
+    int *poolAll = smem;
+    float4 *lds_tnodes = (float4 *) (poolAll + 4 * POOL_INTS);
+    float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
     if (LDS_SCENE) {
-        const int nn = 2 * sc.num_nodes, nt = 3 * sc.num_prims;
-        for (int i = threadIdx.x; i < nn; i += PBLOCK) lds_nodes[i] = sc.nodes[i];
+        const int nn = 2 * 8 * sc.num_nodes, nt = 3 * sc.num_prims;
+        for (int i = threadIdx.x; i < nn; i += PBLOCK) lds_tnodes[i] = sc.tnodes[i];
         for (int i = threadIdx.x; i < nt; i += PBLOCK) lds_tris[i] = sc.tris[i];
         __syncthreads();
     }
-    const float4 *nodes = LDS_SCENE ? lds_nodes : sc.nodes;
+    const float4 *tnodes = LDS_SCENE ? lds_tnodes : sc.tnodes;
     const float4 *tris = LDS_SCENE ? lds_tris : sc.tris;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 *pray = (float4 *) (poolAll + wave * POOL_INTS);       // [POOL][2]
     float4 *pres = pray + 2 * POOL;                               // [POOL]
     int *plist = (int *) (pres + POOL);                           // [POOL]
-    int *stk = stack + threadIdx.x;
     const unsigned long long below = (1ull << lane) - 1ull;
 
     // work mapping: block = 4 waves = 4 consecutive 8x8 sub-blocks of one owned 32x32 tile (camera.cpp:55-64)
@@ -173,7 +172,7 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
         // =================== worker phase ===================
         UTIL(if (COUNT) cnt.it_calls++;)
         int next = 0;                                          // wave-uniform: first unassigned list entry
-        int ray = -1, cur = -1, sp = 0, leafOff = 0, leafN = 0, negmask = 0;
+        int ray = -1, cur = -1, leafOff = 0, leafN = 0, negmask = 0;      // leafN: count | last-record flag
         bool isAny = false, hitAny = false;
         f3 o = mk3(0.0f), d = mk3(1.0f), inv = mk3(1.0f);
         float tmin = 0.0f, tmax = 0.0f;
@@ -194,13 +193,13 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
                     const bool regular = finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
                                          fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
                                          tmax == tmax;
-                    cur = 0; sp = 0; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
+                    cur = negmask * sc.num_nodes; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
                     if (sc.num_nodes == 0) cur = -1;
                     else if (!regular) {
                         // axis-parallel / non-finite rays: the exact slab test, traced to the end right here (rare)
-                        GlobalSrc src; src.nodes = nodes; src.tris = tris;
-                        if (isAny) hitAny = traverseT<true, COUNT, false>(src, stk, PBLOCK, o, d, inv, negmask, tmin, tmax, rec, cnt);
-                        else       hitAny = traverseT<false, COUNT, false>(src, stk, PBLOCK, o, d, inv, negmask, tmin, tmax, rec, cnt);
+                        GlobalSrc src; src.nodes = nullptr; src.tnodes = tnodes; src.tris = tris;
+                        if (isAny) hitAny = traverseThreaded<true, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
+                        else       hitAny = traverseThreaded<false, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
                         cur = -1;
                     }
                     if (COUNT && (regular || sc.num_nodes == 0)) { if (isAny) cnt.n_any++; else cnt.n_closest++; }
@@ -214,35 +213,29 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
             // ---- interior phase: one node per walking lane per iteration ----
             while (true) {
                 UTIL(if (COUNT) cnt.it_interior++;)
-                if (ray >= 0 && leafN == 0 && cur >= 0) {
-                    const float4 na = nodes[2 * cur], nb = nodes[2 * cur + 1];
-                    if (COUNT) { if (isAny) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
-                    const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
-                    const int meta = __float_as_int(nb.w);
-                    const int off = __float_as_int(nb.z);
-                    const int nprims = meta & 0xffff;
-                    const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
-                    const int nearIdx = neg ? off : cur + 1, farIdx = neg ? cur + 1 : off;
-                    const bool goDown = boxHit && nprims == 0;
-                    const bool doPop = !boxHit && sp > 0;
-                    if (goDown) stk[sp * PBLOCK] = farIdx;
-                    int popped = -1;
-                    if (doPop) popped = stk[(sp - 1) * PBLOCK];
-                    sp += (goDown ? 1 : 0) - (doPop ? 1 : 0);
-                    if (boxHit && nprims != 0) { leafN = nprims; leafOff = off; }
-                    cur = goDown ? nearIdx : (boxHit ? cur : popped);
+#pragma unroll
+                for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
+                    if (ray >= 0 && leafN == 0 && cur >= 0) {
+                        const float4 na = tnodes[2 * cur], nb = tnodes[2 * cur + 1];
+                        if (COUNT) { if (isAny) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
+                        const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
+                        const int w = __float_as_int(nb.w), z = __float_as_int(nb.z);
+                        if (boxHit && w != 0) { leafN = w; leafOff = z; }
+                        else cur = (boxHit || w != 0) ? (w < 0 ? -1 : cur + 1) : z;
+                    }
                 }
                 const unsigned long long walking = __ballot(ray >= 0 && leafN == 0 && cur >= 0);
-                const unsigned long long parked = __ballot(leafN > 0);
+                const unsigned long long parked = __ballot(leafN != 0);
                 const unsigned long long free_ = __ballot(leafN == 0 && cur < 0);     // finished or never assigned
                 if (walking == 0ull || __popcll(parked) >= JTX_POOL_LEAF_VOTE ||
                     (next < nRays && __popcll(free_) >= JTX_POOL_ASSIGN_VOTE)) break;
             }
 
             // ---- leaf phase ----
-            if (leafN > 0) {
-                GlobalSrc src; src.nodes = nodes; src.tris = tris;
-                for (int i = 0; i < leafN; ++i) {
+            if (leafN != 0) {
+                GlobalSrc src; src.nodes = nullptr; src.tris = tris;
+                const int n = leafN & 0xffff;
+                for (int i = 0; i < n; ++i) {
                     const int prim = leafOff + i;
                     if (COUNT) { if (isAny) cnt.n_tri_any++; else cnt.n_tri_closest++; }
                     float b1, b2, root;
@@ -253,9 +246,8 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
                     rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
                     if (COUNT) cnt.n_accept++;
                 }
+                cur = ((isAny && hitAny) || leafN < 0) ? -1 : cur + 1;
                 leafN = 0;
-                if ((isAny && hitAny) || sp == 0) cur = -1;
-                else { --sp; cur = stk[sp * PBLOCK]; }
             }
 
             // ---- retire ----
@@ -302,9 +294,9 @@ using namespace jtx;
 hipError_t jtx_launch_render_wavepool(const RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned) num_owned_tiles * 4u), block(PBLOCK);
-    const bool lds = p.scene.lds_scene != 0;
-    size_t shmem = ((size_t) p.scene.stack_depth * PBLOCK + 4 * POOL_INTS) * sizeof(int);
-    if (lds) shmem += ((size_t) 2 * p.scene.num_nodes + (size_t) 3 * p.scene.num_prims) * sizeof(float4);
+    const bool lds = p.scene.lds_threaded != 0;
+    size_t shmem = (size_t) 4 * POOL_INTS * sizeof(int);
+    if (lds) shmem += ((size_t) 2 * 8 * p.scene.num_nodes + (size_t) 3 * p.scene.num_prims) * sizeof(float4);
     if (lds) {
         if (count) hipLaunchKernelGGL((k_render_wavepool<true, true>), grid, block, shmem, stream, p);
         else       hipLaunchKernelGGL((k_render_wavepool<false, true>), grid, block, shmem, stream, p);
