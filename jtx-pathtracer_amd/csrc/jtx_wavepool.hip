@@ -25,7 +25,7 @@ namespace jtx {
 
 constexpr int PBLOCK = 256;
 constexpr int POOL = 128;                       // ray slots per wave: 2 per lane
-constexpr int POOL_INTS = POOL * 8 + POOL * 4 + POOL;   // rays (2 float4) + results (float4) + list, in ints
+constexpr int POOL_INTS = POOL * 8 + POOL;               // rays (2 float4; the result overwrites the first) + list, in ints
 
 #ifndef JTX_POOL_ASSIGN_VOTE
 #define JTX_POOL_ASSIGN_VOTE 8                  // idle lanes that trigger an assignment of new rays
@@ -58,8 +58,7 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
     const float4 *tris = LDS_SCENE ? lds_tris : sc.tris;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 *pray = (float4 *) (poolAll + wave * POOL_INTS);       // [POOL][2]
-    float4 *pres = pray + 2 * POOL;                               // [POOL]
-    int *plist = (int *) (pres + POOL);                           // [POOL]
+    int *plist = (int *) (pray + 2 * POOL);                       // [POOL]
     const unsigned long long below = (1ull << lane) - 1ull;
 
     // work mapping: block = 4 waves = 4 consecutive 8x8 sub-blocks of one owned 32x32 tile (camera.cpp:55-64)
@@ -90,13 +89,13 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
         // =================== owner phase ===================
         if (alive) {
             if (hasShadow) {                                   // sampleLights' occlusion test came back (integrator.cpp:150-165)
-                if (pres[2 * lane].w == 0.0f) rad = rad + pend;
+                if (pray[2 * (2 * lane)].w == 0.0f) rad = rad + pend;
                 else rad = poisonNonFinite(rad, pendNf);     // occluded: integrateMIS adds beta * {} (integrator.cpp:168,195)
                 hasShadow = false;
             }
             if (hasExt) {
                 hasExt = false;
-                const float4 hv = pres[2 * lane + 1];
+                const float4 hv = pray[2 * (2 * lane + 1)];
                 const int prim = __float_as_int(hv.w);
                 if (prim < 0) {                                // integrator.cpp:183-187
                     rad = rad + beta * a3(sc.sky);
@@ -252,8 +251,8 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
 
             // ---- retire ----
             if (ray >= 0 && cur < 0 && leafN == 0) {
-                if (isAny) pres[ray] = make_float4(0.0f, 0.0f, 0.0f, hitAny ? 1.0f : 0.0f);
-                else pres[ray] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
+                if (isAny) pray[2 * ray] = make_float4(0.0f, 0.0f, 0.0f, hitAny ? 1.0f : 0.0f);
+                else pray[2 * ray] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
                 ray = -1;
             }
         }
