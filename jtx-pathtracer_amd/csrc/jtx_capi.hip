@@ -34,15 +34,13 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
-constexpr size_t kLdsSceneBudget = 40 * 1024;   // nodes+tris staged in LDS when they fit this
 constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + tris staged in LDS when they fit this (8 blocks/CU)
 
 } // namespace
 
 struct jtx_mi_scene {
     jtxh::BvhResult bvh;
-    DevBuf<float4> nodes, tnodes, tris, shade, treelet;
-    DevBuf<int> treelet_gidx;
+    DevBuf<float4> tnodes, tris, shade;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
     DevBuf<DTexture> textures;
@@ -109,15 +107,7 @@ void validate(const jtx_mi_scene_desc &d) {
 void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     const jtxh::BvhResult &b = s.bvh;
     const size_t nn = b.nodes.size(), np = b.refs.size();
-    std::vector<float4> nodes(2 * nn), tris(3 * np), shade(4 * np);
-    for (size_t i = 0; i < nn; ++i) {
-        const jtx_mi_bvh_node &n = b.nodes[i];
-        const int meta = (int) n.num_prims | ((int) n.axis << 16);
-        float fo, fm;
-        std::memcpy(&fo, &n.offset, 4); std::memcpy(&fm, &meta, 4);
-        nodes[2 * i + 0] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);   // (near, far) pairs per axis
-        nodes[2 * i + 1] = make_float4(n.pmin[2], n.pmax[2], fo, fm);
-    }
+    std::vector<float4> tris(3 * np), shade(4 * np);
     for (size_t i = 0; i < np; ++i) {
         const jtx_mi_mesh &m = d.meshes[b.refs[i].mesh_index];
         const int tri = b.refs[i].index;
@@ -142,7 +132,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         shade[4 * i + 2] = make_float4(n2[2], uv[0], uv[1], uv[2]);
         shade[4 * i + 3] = make_float4(uv[3], uv[4], uv[5], fmat);
     }
-    s.nodes.upload(nodes); s.tris.upload(tris); s.shade.upload(shade);
+    s.tris.upload(tris); s.shade.upload(shade);
 
     // ---- threaded node records: one near-first depth-first ordering per direction-sign octant ----
     // (layout and rationale: traverseThreaded in jtx_scene_dev.hpp)
@@ -189,68 +179,6 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         s.dev.tnodes = s.tnodes.p;
     }
 
-    // ---- top-of-tree treelet (scenes whose BVH stays in HBM) ----
-    // Node visits concentrate at the top of the tree (measured: the first 256 nodes in breadth-first order take
-    // 40 % of all visits on the 256 k-triangle atrium, 77 % on the mixed scene), and a divergent global load costs
-    // one L1 tag lookup per lane.  The first T breadth-first nodes form a connected top subtree; it is re-laid in
-    // depth-first order so that "first child = next record" still holds inside it, and staged into LDS by the
-    // trace kernels.  Record = the 32-B node with: offset = treelet slot of the second child (or its global index
-    // when meta bit 25 is set), meta bit 24 = first child is outside (global index gidx[slot] + 1).
-    {
-        size_t T = 0;
-        if (!(nn > 0 && nn * 32 + np * 48 <= kLdsSceneBudget) && nn > 0) {
-            // opt-in: measured on MI355X with T = 256, atrium 655 -> 617 ms/frame but mixed 467 -> 510 ms/frame
-            // (a wave still waits for its slowest lane's HBM/L2 node, and the LDS/HBM select costs issue slots)
-            const char *e = getenv("JTX_TREELET_NODES");
-            T = e ? (size_t) atoi(e) : 0;
-            if (T > nn) T = nn;
-        }
-        std::vector<float4> tl(2 * T);
-        std::vector<int> gidx(T);
-        if (T) {
-            std::vector<int> bfs; bfs.reserve(T);
-            std::vector<int> q{0};
-            while (!q.empty() && bfs.size() < T) {
-                std::vector<int> nq;
-                for (int g : q) {
-                    if (bfs.size() >= T) break;
-                    bfs.push_back(g);
-                    if (b.nodes[g].num_prims == 0) { nq.push_back(g + 1); nq.push_back(b.nodes[g].offset); }
-                }
-                q.swap(nq);
-            }
-            std::vector<int> slotOf(nn, -1);
-            std::vector<char> inSet(nn, 0);
-            for (int g : bfs) inSet[g] = 1;
-            // depth-first preorder restricted to the set
-            std::vector<int> st{0}; int next = 0;
-            while (!st.empty()) {
-                const int g = st.back(); st.pop_back();
-                slotOf[g] = next; gidx[next] = g; ++next;
-                if (b.nodes[g].num_prims == 0) {
-                    const int c2 = b.nodes[g].offset, c1 = g + 1;
-                    if (inSet[c2]) st.push_back(c2);
-                    if (inSet[c1]) st.push_back(c1);       // popped first => lands at slot + 1
-                }
-            }
-            for (size_t k = 0; k < T; ++k) {
-                const int g = gidx[k];
-                const jtx_mi_bvh_node &n = b.nodes[g];
-                int meta = (int) n.num_prims | ((int) n.axis << 16);
-                int off = n.offset;
-                if (n.num_prims == 0) {
-                    if (!inSet[g + 1]) meta |= 1 << 24;
-                    if (!inSet[n.offset]) meta |= 1 << 25; else off = slotOf[n.offset];
-                }
-                float fo, fm; std::memcpy(&fo, &off, 4); std::memcpy(&fm, &meta, 4);
-                tl[2 * k + 0] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
-                tl[2 * k + 1] = make_float4(n.pmin[2], n.pmax[2], fo, fm);
-            }
-        }
-        s.treelet.upload(tl); s.treelet_gidx.upload(gidx);
-        s.dev.treelet = s.treelet.p; s.dev.treelet_gidx = s.treelet_gidx.p; s.dev.treelet_n = (int) T;
-    }
-
     std::vector<DMaterial> mats(d.num_materials);
     std::vector<char> usedAsAlbedo(d.num_textures, 0);
     for (int i = 0; i < d.num_materials; ++i) {
@@ -293,16 +221,14 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     s.textures.upload(tex); s.texels.upload(texels);
 
     DevScene &ds = s.dev;
-    ds.nodes = s.nodes.p; ds.tris = s.tris.p; ds.shade = s.shade.p;
+    ds.tris = s.tris.p; ds.shade = s.shade.p;
     ds.materials = s.materials.p; ds.lights = s.lights.p; ds.textures = s.textures.p; ds.texels = s.texels.p;
     ds.num_nodes = (int) nn; ds.num_prims = (int) np; ds.num_lights = d.num_lights; ds.num_materials = d.num_materials;
-    ds.stack_depth = b.max_depth > 0 ? b.max_depth : 1;
-    ds.lds_scene = (nn > 0 && nn * 32 + np * 48 <= kLdsSceneBudget) ? 1 : 0;
     ds.lds_threaded = (nn > 0 && 8 * nn * 32 + np * 48 <= kLdsThreadedBudget) ? 1 : 0;
     ds.material_mask = 0;
     for (int i = 0; i < d.num_materials; ++i) ds.material_mask |= 1 << d.materials[i].type;
     for (int k = 0; k < 3; ++k) ds.sky[k] = d.sky_color[k];
-    s.device_bytes = (nodes.size() * 9 + tris.size() + shade.size()) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
+    s.device_bytes = ((size_t) 16 * nn + tris.size() + shade.size()) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
                      lights.size() * sizeof(DLight) + tex.size() * sizeof(DTexture) + texels.size() * sizeof(float);
 }
 
@@ -539,7 +465,6 @@ int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
         s = new jtx_mi_scene();
         HIPCHK(hipGetDevice(&s->device));
         jtxh::buildBVH(*desc, s->bvh);
-        if (s->bvh.max_depth > 120) throw std::runtime_error("BVH deeper than 120 levels: LDS traversal stack would not fit");
         flatten(*desc, *s);
         HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, s->device)); s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(FBLOCK, 8) k_render_fused(RenderParams p) {
         for (int i = threadIdx.x; i < nt; i += FBLOCK) lds_tris[i] = sc.tris[i];
         __syncthreads();
     }
-    GlobalSrc src; src.nodes = nullptr; src.tnodes = LDS_SCENE ? lds_tnodes : sc.tnodes; src.tris = LDS_SCENE ? lds_tris : sc.tris;
+    GlobalSrc src; src.tnodes = LDS_SCENE ? lds_tnodes : sc.tnodes; src.tris = LDS_SCENE ? lds_tris : sc.tris;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int owned = blockIdx.x >> 2;
     const int tile = p.tile_rank + owned * p.tile_world;

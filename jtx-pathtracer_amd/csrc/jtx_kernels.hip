@@ -160,9 +160,9 @@ __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParam
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
             bool done;
-            if (LDS_SCENE) { LdsSrc src; src.nodes = nullptr; src.tnodes = lds_tnodes; src.tris = lds_tris;
+            if (LDS_SCENE) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris;
                              done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
-            else           { GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
+            else           { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
                              done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
             if (done) {
                 f3 c = ps.radiance;                                    // camera.cpp:110-112
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(BLOCK) k_closest_batch(DevScene sc, int n, con
     if (i >= n) return;
     Counters9 cnt = {};
     HitRec h; h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f;
-    GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
+    GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
     const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     const bool r = traverseNoStack<false, false>(src, sc.num_nodes, ro, rd, tmin, tmax, h, cnt);
     hit[i] = r ? 1 : 0;
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(BLOCK) k_any_batch(DevScene sc, int n, const f
     if (i >= n) return;
     Counters9 cnt = {};
     HitRec h;
-    GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
+    GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
     const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     hit[i] = traverseNoStack<true, false>(src, sc.num_nodes, ro, rd, tmin[i], tmax[i], h, cnt) ? 1 : 0;
 }
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(BLOCK) k_radiance_samples(DevScene sc, DCam ca
     Counters9 cnt = {};
     PathState ps;
     startPath(cam, row[i], col[i], sample[i], ps);
-    GlobalSrc src; src.nodes = sc.nodes; src.tnodes = sc.tnodes; src.tris = sc.tris;
+    GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
     while (!pathBounce<false, MAT_ALL>(sc, src, maxDepth, ps, cnt)) {}
     f3 c = ps.radiance;
     if (c.x > 1.0f) c.x = 1.0f;

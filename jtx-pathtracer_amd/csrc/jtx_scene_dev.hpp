@@ -1,10 +1,10 @@
 // jtx_scene_dev.hpp -- device scene layout and the BVH traversal / ray-triangle stage.
 //
 // HBM layout (built once per scene by jtx_mi_scene_create, see DESIGN.md "Data layout"):
-//   nodes : 2 x float4 per node  [min.x max.x min.y max.y] [min.z max.z asfloat(offset) asfloat(num_prims | axis<<16)]
-//           -- the reference's 32-B LinearBVHNode (bvh.hpp:7-15) re-packed so one node = two 16-B lanes
-//              of one dwordx4 pair (a 128-B gfx950 cache line holds 4 nodes; the implicit first child
-//              cur+1 shares the parent's line 3 times out of 4).
+//   tnodes: 8 x num_nodes x 2 float4: the reference's 32-B LinearBVHNode (bvh.hpp:7-15) in the near-first
+//           depth-first order of each of the 8 direction-sign octants, with a skip link
+//           [min.x max.x min.y max.y] [min.z max.z link leaf]  (see traverseThreaded).  A 128-B gfx950
+//           cache line holds 4 records, and the record visited next on a hit is the adjacent one.
 //   tris  : 3 x float4 per primitive IN BVH ORDER [v0.xyz e1.x] [e1.yz e2.xy] [e2.z - - -]
 //           -- Mesh::transform baked, e1 = v1-v0, e2 = v2-v0 precomputed in fp32 exactly as
 //              mesh.hpp:109-110 computes them per test, so the per-test index gather + three
@@ -12,7 +12,7 @@
 //   shade : 4 x float4 per primitive [n0.xyz n1.x] [n1.yz n2.xy] [n2.z uv0.xy uv1.x] [uv1.y uv2.xy asfloat(material)]
 //           -- read once per accepted path vertex (the reference interpolates at every accept,
 //              mesh.hpp:133-145; only the last one survives, so deferring is equivalent).
-// When nodes+tris fit the LDS budget they are staged into LDS once per workgroup (LdsSrc).
+// When the 8 orderings + tris fit the LDS budget they are staged into LDS once per workgroup (LdsSrc).
 #pragma once
 #include "jtx_bxdf.hpp"
 
@@ -21,7 +21,6 @@ namespace jtx {
 struct DLight { int type; float position[3]; float intensity[3]; float scale; float scene_radius; int pad[3]; };
 
 struct DevScene {
-    const float4    *nodes;
     const float4    *tnodes;      // threaded (stackless) node records: 8 direction-sign orderings x num_nodes x 2 float4
     const float4    *tris;
     const float4    *shade;
@@ -30,13 +29,8 @@ struct DevScene {
     const DTexture  *textures;
     const float     *texels;
     int num_nodes, num_prims, num_lights, num_materials;
-    int stack_depth;       // LDS stack entries per lane = BVH leaf depth (+1), known from the build
-    int lds_scene;         // != 0: nodes+tris are staged in LDS
     int lds_threaded;      // != 0: the 8 threaded orderings + tris are staged in LDS (stackless kernels)
     int material_mask;     // OR of (1 << Material::type) over the scene's materials
-    // top-of-tree treelet for BVHs that live in HBM (jtx_wavefront.hip): the first `treelet_n` nodes in
-    // breadth-first order, re-laid depth-first, staged into LDS by the trace kernels
-    const float4 *treelet; const int *treelet_gidx; int treelet_n;
     float sky[3];
 };
 
@@ -53,16 +47,12 @@ struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode
 #endif
 
 struct GlobalSrc {
-    const float4 *nodes, *tris;
-    const float4 *tnodes = nullptr;
-    JD float4 node(int i, int h) const { return nodes[2 * i + h]; }
+    const float4 *tnodes, *tris;
     JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
 };
 struct LdsSrc {           // pointers into the workgroup's LDS copy
-    const float4 *nodes, *tris;
-    const float4 *tnodes = nullptr;
-    JD float4 node(int i, int h) const { return nodes[2 * i + h]; }
+    const float4 *tnodes, *tris;
     JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
 };
@@ -142,71 +132,6 @@ JD bool finiteNonZero(float x) { return fabsf(x) < __builtin_inff() && x != 0.0f
 #define JTX_LEAF_VOTE 12      // lanes parked on a leaf that end the interior phase of a wave
 #endif
 
-template <bool ANY, bool COUNT, bool REGULAR, class Src>
-JD bool traverseT(const Src &src, int *stk, int stride, f3 o, f3 d, f3 inv, int negmask, float tmin, float tmax,
-                  HitRec &rec, Counters9 &cnt) {
-    int sp = 0, cur = 0;
-    bool hitAnything = false;
-    if (COUNT) { if (ANY) cnt.n_any++; else cnt.n_closest++; }
-    // Per lane: WALK (cur = node to visit), PARKED on a leaf (leafN > 0) or DONE (cur < 0).
-    // The wave alternates two phases.  Interior phase: every walking lane visits one node per
-    // iteration; it ends when no lane walks any more or when JTX_LEAF_VOTE lanes are parked.  Leaf
-    // phase: the parked lanes test their leaf's triangles together, then pop.  A parked lane simply
-    // waits, so each ray still sees exactly the reference's visit order and shrinking t.max.
-    int leafOff = 0, leafN = 0;
-    UTIL(if (COUNT) cnt.it_calls++;)
-    while (true) {
-        while (true) {
-#pragma unroll
-            for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
-                UTIL(if (COUNT) cnt.it_interior++;)
-                if (leafN == 0 && cur >= 0) {
-                    const float4 na = src.node(cur, 0);
-                    const float4 nb = src.node(cur, 1);
-                    if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
-                    const bool boxHit = REGULAR ? slabRegular(na, nb, o, inv, tmin, tmax) : slabExact(na, nb, o, inv, tmin, tmax);
-                    if (boxHit) {
-                        const int meta = __float_as_int(nb.w);
-                        const int off = __float_as_int(nb.z);
-                        if ((meta & 0xffff) != 0) { leafOff = off; leafN = meta & 0xffff; }
-                        else {
-                            const bool neg = (negmask >> ((meta >> 16) & 0xff)) & 1;
-                            stk[sp * stride] = neg ? cur + 1 : off;
-                            sp++;
-                            cur = neg ? off : cur + 1;
-                        }
-                    } else {
-                        if (sp == 0) cur = -1;
-                        else { --sp; cur = stk[sp * stride]; }
-                    }
-                }
-            }
-            const unsigned long long walking = __ballot(leafN == 0 && cur >= 0);
-            const unsigned long long parked = __ballot(leafN > 0);
-            if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE) break;
-        }
-        if (__ballot(leafN > 0) == 0ull) break;            // wave-uniform: every lane is DONE
-        UTIL(if (COUNT) cnt.it_leaf++;)
-        if (leafN > 0) {
-            for (int i = 0; i < leafN; ++i) {
-                const int prim = leafOff + i;
-                if (COUNT) { if (ANY) cnt.n_tri_any++; else cnt.n_tri_closest++; }
-                float b1, b2, root;
-                if (!triTest(src, prim, o, d, tmin, tmax, b1, b2, root)) continue;
-                hitAnything = true;
-                if (ANY) break;
-                tmax = root;
-                rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
-                if (COUNT) cnt.n_accept++;
-            }
-            leafN = 0;
-            if ((ANY && hitAnything) || sp == 0) cur = -1;
-            else { --sp; cur = stk[sp * stride]; }
-        }
-    }
-    return hitAnything;
-}
-
 // ---- threaded (stackless) traversal -------------------------------------------------------------------
 // In Scene::closestHit / anyHit the child visited first depends only on the SIGN of the ray direction
 // along the node's split axis (dirIsNeg[axis], scene.cpp:11-12,40-46).  For a fixed sign octant the
@@ -278,19 +203,6 @@ JD bool traverseNoStack(const Src &src, int num_nodes, f3 o, f3 d, float tmin, f
                          tmin == tmin && tmax == tmax;
     if (__builtin_expect(regular, 1)) return traverseThreaded<ANY, COUNT, true>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
     return traverseThreaded<ANY, COUNT, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);   // axis-parallel & co.
-}
-
-template <bool ANY, bool COUNT, class Src>
-JD bool traverse(const Src &src, int num_nodes, int *stk, int stride, f3 o, f3 d, float tmin, float tmax,
-                 HitRec &rec, Counters9 &cnt) {
-    if (num_nodes == 0) return false;
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-    const bool regular = finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
-                         fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
-                         tmin == tmin && tmax == tmax;
-    if (__builtin_expect(regular, 1)) return traverseT<ANY, COUNT, true>(src, stk, stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
-    return traverseT<ANY, COUNT, false>(src, stk, stride, o, d, inv, negmask, tmin, tmax, rec, cnt);   // axis-parallel & co.
 }
 
 struct Surface { f3 point, normal; f2 uv; int material; };

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
             if (!regular) {
                 // axis-parallel / non-finite rays: the exact slab test, traced to the end right here
                 // (rare; keeps the main loop on the min/max form only)
-                GlobalSrc src; src.nodes = nullptr; src.tnodes = tnodes; src.tris = tris;
+                GlobalSrc src; src.tnodes = tnodes; src.tris = tris;
                 hitAny = traverseThreaded<ANY != 0, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
                 cur = -1;
             } else if (COUNT) { if (ANY) cnt.n_any++; else cnt.n_closest++; }
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
 
         // ---- D. leaf phase ----
         if (leafN != 0) {
-            GlobalSrc src; src.nodes = nullptr; src.tris = tris;
+            GlobalSrc src; src.tris = tris;
             const int n = leafN & 0xffff;
             for (int i = 0; i < n; ++i) {
                 const int prim = leafOff + i;

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
                     if (sc.num_nodes == 0) cur = -1;
                     else if (!regular) {
                         // axis-parallel / non-finite rays: the exact slab test, traced to the end right here (rare)
-                        GlobalSrc src; src.nodes = nullptr; src.tnodes = tnodes; src.tris = tris;
+                        GlobalSrc src; src.tnodes = tnodes; src.tris = tris;
                         if (isAny) hitAny = traverseThreaded<true, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
                         else       hitAny = traverseThreaded<false, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
                         cur = -1;
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(PBLOCK) k_render_wavepool(RenderParams p) {
 
             // ---- leaf phase ----
             if (leafN != 0) {
-                GlobalSrc src; src.nodes = nullptr; src.tris = tris;
+                GlobalSrc src; src.tris = tris;
                 const int n = leafN & 0xffff;
                 for (int i = 0; i < n; ++i) {
                     const int prim = leafOff + i;
