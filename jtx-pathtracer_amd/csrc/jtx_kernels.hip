@@ -127,7 +127,9 @@ JD unsigned char toByte(float v) {                                     // image.
     return (unsigned char) (int) (255.999f * c);
 }
 
-template <bool COUNT, bool LDS_SCENE, int MASK>
+// SPLIT = strata-split mode: gridDim.y groups of strata per pixel block, per-sample radiance goes to p.rad and
+// k_resolve_samples adds it to the film in sample order (same sums; more waves for small shards / frames).
+template <bool COUNT, bool LDS_SCENE, int MASK, bool SPLIT>
 __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
@@ -148,15 +150,18 @@ __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParam
     Counters9 cnt = {};
     if (inside) {
         const size_t pix = (size_t) row * p.width + col;
+        const int sBegin = SPLIT ? p.sample_begin + (int) blockIdx.y * p.strata_per_group : p.sample_begin;
+        const int sEnd = SPLIT ? (sBegin + p.strata_per_group < p.sample_end ? sBegin + p.strata_per_group : p.sample_end) : p.sample_end;
+        const int pslot = owned * 1024 + sub * 64 + lane;             // compact index of an owned pixel (strata-split mode)
         f3 acc = mk3(0.0f);
-        if (p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
-        int s = p.sample_begin;
+        if (!SPLIT && p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
+        int s = sBegin;
         PathState ps;
 #ifdef JTX_PROFILE_PHASES
         for (int i = 0; i < 6; ++i) ps.ph[i] = 0;
         long long k0 = clock64();
 #endif
-        bool alive = s < p.sample_end;
+        bool alive = s < sEnd;
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
             bool done;
@@ -169,9 +174,10 @@ __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParam
                 if (c.x > 1.0f) c.x = 1.0f;
                 if (c.y > 1.0f) c.y = 1.0f;
                 if (c.z > 1.0f) c.z = 1.0f;
-                acc = acc + c;                                         // image.hpp:82-86
+                if (SPLIT) p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + pslot] = make_float4(c.x, c.y, c.z, 0.0f);
+                else acc = acc + c;                                    // image.hpp:82-86
                 ++s;
-                if (s < p.sample_end) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
+                if (s < sEnd) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
                 else alive = false;
             }
         }
@@ -181,12 +187,14 @@ __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParam
             atomicAdd(&p.counters[16 + 5], (unsigned long long) (clock64() - k0));
         }
 #endif
+        if (!SPLIT) {
         p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
         if (p.img) {
             const float inv = (float) p.sample_end;                    // currSample + 1 of the last pass (camera.cpp:115)
             p.img[3 * pix] = toByte(acc.x / inv);
             p.img[3 * pix + 1] = toByte(acc.y / inv);
             p.img[3 * pix + 2] = toByte(acc.z / inv);
+        }
         }
     }
     if (COUNT) waveAddCounters(p.counters, cnt);
@@ -322,7 +330,11 @@ hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, 
     const bool lds = p.scene.lds_threaded != 0;
     const size_t shmem = ldsBytes(p.scene, lds);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
-#define LAUNCH_RP(C, L, M) hipLaunchKernelGGL((k_render_pixels<C, L, M>), grid, block, shmem, stream, p)
+    const bool split = p.rad != nullptr;
+    const int groups = split ? (p.sample_end - p.sample_begin + p.strata_per_group - 1) / p.strata_per_group : 1;
+    const dim3 grid2(grid.x, (unsigned) groups);
+#define LAUNCH_RP(C, L, M) do { if (split) hipLaunchKernelGGL((k_render_pixels<C, L, M, true>), grid2, block, shmem, stream, p); \
+                                else hipLaunchKernelGGL((k_render_pixels<C, L, M, false>), grid, block, shmem, stream, p); } while (0)
     if (lambert) {
         if (lds) { if (count) LAUNCH_RP(true, true, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, true, MAT_DIFFUSE_ONLY); }
         else     { if (count) LAUNCH_RP(true, false, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, false, MAT_DIFFUSE_ONLY); }
@@ -331,6 +343,38 @@ hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, 
         else     { if (count) LAUNCH_RP(true, false, MAT_ALL); else LAUNCH_RP(false, false, MAT_ALL); }
     }
 #undef LAUNCH_RP
+    return hipGetLastError();
+}
+
+// strata-split mode: add the per-sample radiances to the film in sample order (image.hpp:82-86, 47-52)
+namespace jtx {
+__global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
+    const int pslot = blockIdx.x * BLOCK + threadIdx.x;
+    const int owned = pslot >> 10, sub = (pslot >> 6) & 15, lane = pslot & 63;
+    const int tile = p.tile_rank + owned * p.tile_world;
+    const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
+    const int row = trow * 32 + (sub >> 2) * 8 + (lane >> 3);
+    const int col = tcol * 32 + (sub & 3) * 8 + (lane & 7);
+    if (pslot >= p.rad_stride || row >= p.height || col >= p.width) return;
+    const size_t pix = (size_t) row * p.width + col;
+    f3 acc = mk3(0.0f);
+    if (p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
+    const int n = p.sample_end - p.sample_begin;
+    for (int i = 0; i < n; ++i) {
+        const float4 c = p.rad[(size_t) i * p.rad_stride + pslot];
+        acc = acc + mk3(c.x, c.y, c.z);
+    }
+    p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
+    if (p.img) {
+        const float inv = (float) p.sample_end;
+        p.img[3 * pix] = toByte(acc.x / inv); p.img[3 * pix + 1] = toByte(acc.y / inv); p.img[3 * pix + 2] = toByte(acc.z / inv);
+    }
+}
+} // namespace jtx
+
+hipError_t jtx_launch_resolve_samples(const RenderParams &p, int num_owned_tiles, hipStream_t stream) {
+    if (num_owned_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve_samples, dim3((unsigned) (num_owned_tiles * 1024 / BLOCK)), dim3(BLOCK), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -14,6 +14,10 @@ struct RenderParams {
     float *acc;                    // W*H*3 float sums (AccumulationBuffer)
     unsigned char *img;            // W*H*3 u8 (RGB8Image) or null
     unsigned long long *counters;  // 9 x u64 or null
+    // strata-split mode (small shards): blockIdx.y picks a group of `strata_per_group` strata, lanes write the
+    // clamped per-sample radiance to rad[(s - sample_begin) * rad_stride + owned pixel slot]; k_resolve_samples
+    // then adds them to the film in sample order
+    float4 *rad; int strata_per_group; int rad_stride;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
@@ -55,6 +59,7 @@ hipError_t jtx_wf_shade(const jtx::WfParams &p, int grid, bool count, int typeCo
 hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write_img, hipStream_t st);
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
+hipError_t jtx_launch_resolve_samples(const jtx::RenderParams &p, int num_owned_tiles, hipStream_t stream);
 hipError_t jtx_launch_render_fused(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_wavepool(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_closest_batch(const jtx::DevScene &sc, int n, const float *o, const float *d, float tmin, float tmax,
