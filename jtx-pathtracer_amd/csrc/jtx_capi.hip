@@ -527,8 +527,10 @@ int jtx_mi_render_device(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const j
         if (sb >= se) throw std::runtime_error("empty sample range");
         std::lock_guard<std::mutex> lk(s->mu);
         hipStream_t st = stream ? (hipStream_t) stream : s->stream;
-        if (sb == 0 && (o.tile_world > 1))      // non-owned pixels must read as exactly 0 for the reduce
-            HIPCHK(hipMemsetAsync(d_acc_rgb, 0, sizeof(float) * 3 * (size_t) cam->width * cam->height, st));
+        if (o.tile_world > 1) {                 // non-owned pixels must read as exactly 0 for the reduce
+            if (sb == 0) HIPCHK(hipMemsetAsync(d_acc_rgb, 0, sizeof(float) * 3 * (size_t) cam->width * cam->height, st));
+            if (d_img_rgb) HIPCHK(hipMemsetAsync(d_img_rgb, 0, 3 * (size_t) cam->width * cam->height, st));
+        }
         launchRender(*s, *cam, o, sb, se, (float *) d_acc_rgb, (unsigned char *) d_img_rgb, st);
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }

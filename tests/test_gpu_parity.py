@@ -399,3 +399,23 @@ def test_render_depth_zero_and_no_lights(gpu, cornell_pair, integrator):
     cam_g, acc, img, cnt = _render_both(gpu, nl, s2, ol.OracleScene(nl), 64, 48, 2, 1, 5, integrator=integrator)
     assert_same_f32(cam_g.acc_, acc, "no lights")
     assert cam_g.counters == cnt and cnt["n_any"] == 0
+
+
+def test_shard_buffers_are_zeroed_every_frame(gpu, cornell_pair):
+    """multi-GPU step: the reduce target on rank 0 holds last frame's full image; the next shard render must
+    zero everything it does not own (acc and img) before the next reduce."""
+    import torch
+    data, sc, osc = cornell_pair
+    cam = data.camera_desc(100, 70, 2, 1, 3)
+    dev = torch.device("cuda", 0)
+    acc = torch.full((70 * 100 * 3,), 7.0, dtype=torch.float32, device=dev)
+    img = torch.full((70 * 100 * 3,), 9, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        gpu.distributed.render_shard(sc, cam, 1, 3, acc, img, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    mask = gpu.distributed.tile_owner_mask(100, 70, 1, 3)
+    a = acc.cpu().numpy().reshape(70, 100, 3); i = img.cpu().numpy().reshape(70, 100, 3)
+    assert (a[~mask] == 0).all() and (i[~mask] == 0).all()
+    ref_acc, ref_img, _ = osc.render(cam)
+    assert np.array_equal(a[mask].view(np.uint32), ref_acc[mask].view(np.uint32)) and np.array_equal(i[mask], ref_img[mask])
