@@ -123,6 +123,8 @@ typedef struct {
     float   scene_radius;
     int32_t auto_integrator;  /* what opts.integrator == 0 resolves to for this scene */
     uint64_t device_bytes;
+    int32_t wide_depth;       /* levels of the 8-ary quantised BVH the uncounted kernels walk (0 = not built) */
+    int32_t wide_bytes;       /* its size in bytes */
 } jtx_mi_scene_info;
 
 typedef struct jtx_mi_scene jtx_mi_scene;
@@ -139,6 +141,12 @@ int         jtx_mi_set_device(int32_t device);
  * nodes_out needs room for 2*num_tri_refs nodes, refs_out for num_tri_refs.  No GPU needed. */
 int jtx_mi_bvh_build(const jtx_mi_scene_desc *desc, jtx_mi_bvh_node *nodes_out, int32_t *num_nodes_out,
                      jtx_mi_tri_ref *refs_out, int32_t *max_depth_out);
+
+/* Host-only: the 8-ary quantised node set the uncounted kernels walk for HBM-resident scenes, derived from the
+ * flat nodes of jtx_mi_bvh_build (layout: DESIGN.md "Data layout", 16-byte granules = 4 uint32 each; 0 granules
+ * when the tree is a single leaf or cannot be quantised).  granules_out may be NULL to query the size.  No GPU needed. */
+int jtx_mi_wide_build(const jtx_mi_bvh_node *nodes, int32_t num_nodes, uint32_t *granules_out, int64_t capacity,
+                      int64_t *num_granules_out, int32_t *depth_out);
 
 /* Scene::buildBVH + upload: builds the BVH on the host, bakes transforms, lays nodes / triangles /
  * shading records out for the kernels and copies them to the current device. */

@@ -76,7 +76,7 @@ class Counters(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("num_prims", C.c_int32), ("max_depth", C.c_int32),
                 ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("auto_integrator", C.c_int32),
-                ("device_bytes", C.c_uint64)]
+                ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)
@@ -92,6 +92,7 @@ SYMBOLS = {
     "jtx_mi_device_count": (C.c_int, [_i]),
     "jtx_mi_set_device": (C.c_int, [C.c_int32]),
     "jtx_mi_bvh_build": (C.c_int, [P(SceneDesc), P(BvhNode), _i, P(TriRef), _i]),
+    "jtx_mi_wide_build": (C.c_int, [P(BvhNode), C.c_int32, _u32, C.c_int64, P(C.c_int64), _i]),
     "jtx_mi_scene_create": (C.c_int, [P(SceneDesc), P(_scene)]),
     "jtx_mi_scene_destroy": (None, [_scene]),
     "jtx_mi_scene_get_info": (C.c_int, [_scene, P(SceneInfo)]),

@@ -70,7 +70,7 @@ class Scene:
         check(self._lib.jtx_mi_scene_get_info(self.handle, C.byref(i)))
         return dict(num_nodes=i.num_nodes, num_prims=i.num_prims, max_depth=i.max_depth,
                     lds_resident=bool(i.lds_resident), scene_radius=float(i.scene_radius),
-                    auto_integrator=int(i.auto_integrator),
+                    auto_integrator=int(i.auto_integrator), wide_depth=int(i.wide_depth), wide_bytes=int(i.wide_bytes),
                     device_bytes=int(i.device_bytes))
 
     def bvh(self):
@@ -172,6 +172,19 @@ def bvh_build_host(data):
     nn, md = C.c_int32(), C.c_int32()
     check(lib.jtx_mi_bvh_build(C.byref(desc), nodes, C.byref(nn), refs, C.byref(md)))
     return nodes_to_numpy(nodes, nn.value), refs_to_numpy(refs, data.num_triangles), md.value
+
+
+def wide_build_host(nodes):
+    """Host-only: the 8-ary quantised node set derived from flat BVH nodes (numpy NODE_DTYPE) ->
+    (uint32 array [granules, 4], depth)."""
+    lib = capi.load()
+    nn = len(nodes)
+    raw = (capi.BvhNode * max(1, nn)).from_buffer_copy(np.ascontiguousarray(nodes).tobytes() or bytes(32))
+    ng, depth = C.c_int64(), C.c_int32()
+    check(lib.jtx_mi_wide_build(raw, nn, None, 0, C.byref(ng), C.byref(depth)))
+    out = np.zeros((max(1, ng.value), 4), np.uint32)
+    check(lib.jtx_mi_wide_build(raw, nn, out.ctypes.data_as(C.POINTER(C.c_uint32)), ng.value, C.byref(ng), C.byref(depth)))
+    return out[: ng.value], depth.value
 
 
 class StaticCamera:

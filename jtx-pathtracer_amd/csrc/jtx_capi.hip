@@ -41,6 +41,7 @@ constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + 
 struct jtx_mi_scene {
     jtxh::BvhResult bvh;
     DevBuf<float4> tnodes, tris, shade;
+    DevBuf<uint4> wide;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
     DevBuf<DTexture> textures;
@@ -102,6 +103,125 @@ void validate(const jtx_mi_scene_desc &d) {
     }
     for (int i = 0; i < d.num_lights; ++i)
         if (d.lights[i].type < 0 || d.lights[i].type > 1) throw std::runtime_error("light.type out of range");
+}
+
+// ---- wide-node builder (layout + proof sketch: traverseWide in jtx_scene_dev.hpp) ----
+constexpr int kWideMinExp = -60, kWideMaxExp = 40;   // cell = 2^e; with |1/d| in [2^-40, 2^40] (WIDE_RANGE) cell / d is exact
+constexpr int kMaxWideDepth = 11;          // 11 x 8 B x 256 lanes = 22 KB of LDS stack per workgroup (7 workgroups / CU)
+
+struct WideBuilder {
+    const std::vector<jtx_mi_bvh_node> &nodes;
+    std::vector<uint4> &out;
+    int depth = 0;
+    bool ok = true;
+
+    // sign of (p + q * cell) - x in exact arithmetic (q * cell is exact in double; two-sum for the addition)
+    static int gridCmp(float p, int q, float cell, float x) {
+        const double a = (double) p, b = (double) q * (double) cell;
+        const double t = a + b, bb = t - a, err = (a - (t - bb)) + (b - bb);
+        if (t != (double) x) return t < (double) x ? -1 : 1;
+        return err < 0 ? -1 : (err > 0 ? 1 : 0);
+    }
+    static bool finite3(const float v[3]) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+    bool leaf(int i) const { return nodes[i].num_prims != 0; }
+
+    void writeLeaf(size_t at, int i) {
+        const jtx_mi_bvh_node &n = nodes[i];
+        auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        out[at] = make_uint4(fb(n.pmin[0]), fb(n.pmax[0]), fb(n.pmin[1]), fb(n.pmax[1]));
+        out[at + 1] = make_uint4(fb(n.pmin[2]), fb(n.pmax[2]), (uint32_t) n.offset, (uint32_t) n.num_prims);
+    }
+
+    void fill(int b, size_t at, int level) {
+        if (!ok) return;
+        if (level + 1 > depth) depth = level + 1;
+        const jtx_mi_bvh_node &nb = nodes[b];
+        int child[8]; for (int &c : child) c = -1;
+        int a0 = nb.axis, a1[2] = {-1, -1}, a2[4] = {-1, -1, -1, -1};
+        const int c1[2] = {b + 1, nb.offset};
+        for (int i = 0; i < 2; ++i) {
+            if (leaf(c1[i])) { child[i << 2] = c1[i]; continue; }
+            a1[i] = nodes[c1[i]].axis;
+            const int c2[2] = {c1[i] + 1, nodes[c1[i]].offset};
+            for (int j = 0; j < 2; ++j) {
+                if (leaf(c2[j])) { child[(i << 2) | (j << 1)] = c2[j]; continue; }
+                a2[2 * i + j] = nodes[c2[j]].axis;
+                child[(i << 2) | (j << 1)] = c2[j] + 1;
+                child[(i << 2) | (j << 1) | 1] = nodes[c2[j]].offset;
+            }
+        }
+        if (!finite3(nb.pmin) || !finite3(nb.pmax)) { ok = false; return; }
+        // grid: origin = the node's min corner, cell = 2^e per axis with origin + 255 * 2^e >= max corner (exactly)
+        uint32_t ebyte[3]; float cell[3];
+        for (int k = 0; k < 3; ++k) {
+            const double ext = (double) nb.pmax[k] - (double) nb.pmin[k];
+            int e = ext > 0 ? std::ilogb(ext / 255.0) : kWideMinExp;
+            if (e < kWideMinExp) e = kWideMinExp;              // cell / d must stay a normal float (exact scaling)
+            while (e <= kWideMaxExp && gridCmp(nb.pmin[k], 255, std::ldexp(1.0f, e), nb.pmax[k]) < 0) ++e;
+            if (e > kWideMaxExp || std::fabs(nb.pmin[k]) > 1099511627776.0f || std::fabs(nb.pmax[k]) > 1099511627776.0f) { ok = false; return; }
+            ebyte[k] = (uint32_t) (e + 127); cell[k] = std::ldexp(1.0f, e);
+        }
+        uint32_t imask = 0, lmask = 0;
+        uint8_t qlo[3][8] = {}, qhi[3][8] = {};
+        for (int s = 0; s < 8; ++s) {
+            if (child[s] < 0) continue;
+            const jtx_mi_bvh_node &c = nodes[child[s]];
+            (leaf(child[s]) ? lmask : imask) |= 1u << s;
+            for (int k = 0; k < 3; ++k) {
+                if (!(c.pmin[k] >= nb.pmin[k] && c.pmax[k] <= nb.pmax[k] && c.pmin[k] <= c.pmax[k])) { ok = false; return; }   // nesting is the premise
+                const float p = nb.pmin[k], sc = cell[k];
+                int q = (int) std::floor(((double) c.pmin[k] - (double) p) / (double) sc);
+                q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                while (q > 0 && gridCmp(p, q, sc, c.pmin[k]) > 0) --q;
+                while (q < 255 && gridCmp(p, q + 1, sc, c.pmin[k]) <= 0) ++q;
+                if (gridCmp(p, q, sc, c.pmin[k]) > 0) { ok = false; return; }
+                qlo[k][s] = (uint8_t) q;
+                q = (int) std::ceil(((double) c.pmax[k] - (double) p) / (double) sc);
+                q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                while (q < 255 && gridCmp(p, q, sc, c.pmax[k]) < 0) ++q;
+                while (q > 0 && gridCmp(p, q - 1, sc, c.pmax[k]) >= 0) --q;
+                if (gridCmp(p, q, sc, c.pmax[k]) < 0) { ok = false; return; }
+                qhi[k][s] = (uint8_t) q;
+            }
+        }
+        // visiting order: which collapsed binary nodes go to their second child first, per octant
+        uint32_t order[2] = {0, 0};
+        for (int o = 0; o < 8; ++o) {
+            auto neg = [&](int axis) { return axis >= 0 ? (uint32_t) ((o >> axis) & 1) : 0u; };
+            const uint32_t B = neg(a2[0]) | neg(a1[0]) << 1 | neg(a2[1]) << 2 | neg(a0) << 3 | neg(a2[2]) << 4 | neg(a1[1]) << 5 | neg(a2[3]) << 6;
+            order[o >> 2] |= B << (8 * (o & 3));
+        }
+        const int ni = __builtin_popcount(imask), nl = __builtin_popcount(lmask);
+        const size_t base = out.size();
+        out.resize(base + 5 * (size_t) ni + 2 * (size_t) nl);
+        if (base + 5 * (size_t) ni + 2 * (size_t) nl > 0xffffffffull) { ok = false; return; }
+        auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        auto pack = [](const uint8_t *q) { return (uint32_t) q[0] | (uint32_t) q[1] << 8 | (uint32_t) q[2] << 16 | (uint32_t) q[3] << 24; };
+        out[at + 0] = make_uint4(fb(nb.pmin[0]), fb(nb.pmin[1]), fb(nb.pmin[2]), ebyte[0] | ebyte[1] << 8 | ebyte[2] << 16);
+        out[at + 1] = make_uint4((uint32_t) base, imask | lmask << 8, order[0], order[1]);
+        out[at + 2] = make_uint4(pack(qlo[0]), pack(qlo[0] + 4), pack(qlo[1]), pack(qlo[1] + 4));
+        out[at + 3] = make_uint4(pack(qlo[2]), pack(qlo[2] + 4), pack(qhi[0]), pack(qhi[0] + 4));
+        out[at + 4] = make_uint4(pack(qhi[1]), pack(qhi[1] + 4), pack(qhi[2]), pack(qhi[2] + 4));
+        int ri = 0, rl = 0;
+        for (int s = 0; s < 8; ++s) {
+            if (child[s] < 0) continue;
+            if (leaf(child[s])) writeLeaf(base + 5 * (size_t) ni + 2 * (size_t) rl++, child[s]);
+            else ++ri;
+        }
+        ri = 0;
+        for (int s = 0; s < 8; ++s)
+            if (child[s] >= 0 && !leaf(child[s])) fill(child[s], base + 5 * (size_t) ri++, level + 1);
+    }
+};
+
+bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &out, int &depth) {
+    out.clear(); depth = 0;
+    if (nodes.size() < 2 || nodes[0].num_prims != 0) return false;      // a single leaf: nothing to collapse
+    WideBuilder wb{nodes, out};
+    out.resize(5);
+    wb.fill(0, 0, 0);
+    depth = wb.depth;
+    return wb.ok;
 }
 
 // Flatten the scene into the kernel layout documented in jtx_scene_dev.hpp.
@@ -180,6 +300,17 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         s.dev.tnodes = s.tnodes.p;
     }
 
+    // ---- wide (8-ary, quantised) nodes for the uncounted kernels of HBM-resident scenes (traverseWide) ----
+    s.wide.release(); s.dev.wide = nullptr; s.dev.wide_depth = 0;
+    {
+        std::vector<uint4> wide; int depth = 0;
+        const char *off = getenv("JTX_NO_WIDE");
+        if (!(off && atoi(off)) && buildWide(b.nodes, wide, depth) && depth <= kMaxWideDepth) {
+            s.wide.upload(wide);
+            s.dev.wide = s.wide.p; s.dev.wide_depth = depth;
+        }
+    }
+
     std::vector<DMaterial> mats(d.num_materials);
     std::vector<char> usedAsAlbedo(d.num_textures, 0);
     for (int i = 0; i < d.num_materials; ++i) {
@@ -229,7 +360,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     ds.material_mask = 0;
     for (int i = 0; i < d.num_materials; ++i) ds.material_mask |= 1 << d.materials[i].type;
     for (int k = 0; k < 3; ++k) ds.sky[k] = d.sky_color[k];
-    s.device_bytes = ((size_t) 16 * nn + tris.size() + shade.size()) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
+    s.device_bytes = ((size_t) 16 * nn + tris.size() + shade.size() + s.wide.n) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
                      lights.size() * sizeof(DLight) + tex.size() * sizeof(DTexture) + texels.size() * sizeof(float);
 }
 
@@ -281,7 +412,7 @@ int autoIntegrator(const jtx_mi_scene &s) {
     const char *e = getenv("JTX_INTEGRATOR");
     const int v = e ? atoi(e) : 0;
     if (v >= 1 && v <= 4) return v;
-    return (s.dev.lds_threaded || s.dev.material_mask == MAT_DIFFUSE_ONLY) ? 1 : 2;
+    return (s.dev.lds_threaded || s.dev.material_mask == MAT_DIFFUSE_ONLY || s.dev.wide) ? 1 : 2;
 }
 
 // ---- wavefront integrator orchestration ----
@@ -475,6 +606,23 @@ int jtx_mi_bvh_build(const jtx_mi_scene_desc *desc, jtx_mi_bvh_node *nodes_out, 
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 
+int jtx_mi_wide_build(const jtx_mi_bvh_node *nodes, int32_t num_nodes, uint32_t *granules_out, int64_t capacity,
+                      int64_t *num_granules_out, int32_t *depth_out) {
+    try {
+        if (!nodes || num_nodes < 0) throw std::runtime_error("null nodes");
+        std::vector<jtx_mi_bvh_node> v(nodes, nodes + num_nodes);
+        std::vector<uint4> wide; int depth = 0;
+        if (!buildWide(v, wide, depth)) { wide.clear(); depth = 0; }
+        if (num_granules_out) *num_granules_out = (int64_t) wide.size();
+        if (depth_out) *depth_out = depth;
+        if (granules_out) {
+            if ((int64_t) wide.size() > capacity) throw std::runtime_error("granules_out too small");
+            std::memcpy(granules_out, wide.data(), wide.size() * sizeof(uint4));
+        }
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
 int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
     jtx_mi_scene *s = nullptr;
     try {
@@ -506,6 +654,7 @@ int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     out->num_nodes = s->dev.num_nodes; out->num_prims = s->dev.num_prims; out->max_depth = s->bvh.max_depth;
     out->lds_resident = s->dev.lds_threaded; out->scene_radius = s->bvh.scene_radius; out->device_bytes = s->device_bytes;
     out->auto_integrator = autoIntegrator(*s);
+    out->wide_depth = s->dev.wide_depth; out->wide_bytes = (int32_t) (s->wide.n * sizeof(uint4));
     return 0;
 }
 int jtx_mi_scene_get_bvh(const jtx_mi_scene *s, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out) {

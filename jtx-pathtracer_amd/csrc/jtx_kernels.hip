@@ -20,6 +20,9 @@ namespace jtx {
 #ifndef JTX_RP_OCC
 #define JTX_RP_OCC 7
 #endif
+#ifndef JTX_WIDE_OCC
+#define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
+#endif
 constexpr int BLOCK = JTX_RP_BLOCK;          // threads per workgroup of the render / batch kernels
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr int BLOCKS_PER_TILE = 16 / WAVES_PER_BLOCK;   // a 32x32 tile = 16 wave-sized 8x8 pixel blocks
@@ -129,9 +132,12 @@ JD unsigned char toByte(float v) {                                     // image.
 
 // SPLIT = strata-split mode: gridDim.y groups of strata per pixel block, per-sample radiance goes to p.rad and
 // k_resolve_samples adds it to the film in sample order (same sums; more waves for small shards / frames).
-template <bool COUNT, bool LDS_SCENE, int MASK, bool SPLIT>
-__global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParams p) {
+// SRC: where the traversal reads the BVH -- SRC_GLOBAL threaded records in HBM, SRC_LDS the same staged in LDS,
+// SRC_WIDE the 8-ary quantised nodes in HBM with the per-lane stack in LDS (uncounted kernels only).
+template <bool COUNT, int SRC, int MASK, bool SPLIT>
+__global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) k_render_pixels(RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr bool LDS_SCENE = SRC == SRC_LDS;
     const DevScene &sc = p.scene;
     float4 *lds_tnodes = (float4 *) smem;
     float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
@@ -165,10 +171,13 @@ __global__ void __launch_bounds__(BLOCK, JTX_RP_OCC) k_render_pixels(RenderParam
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
             bool done;
-            if (LDS_SCENE) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris;
-                             done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
-            else           { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
-                             done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
+            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris;
+                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
+            else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                                  src.stk = (uint2 *) smem + threadIdx.x; src.stride = BLOCK;
+                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
+            else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
             if (done) {
                 f3 c = ps.radiance;                                    // camera.cpp:110-112
                 if (c.x > 1.0f) c.x = 1.0f;
@@ -328,7 +337,8 @@ hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, 
     if (num_owned_tiles <= 0) return hipSuccess;
     const dim3 grid((unsigned) num_owned_tiles * (unsigned) BLOCKS_PER_TILE), block(BLOCK);
     const bool lds = p.scene.lds_threaded != 0;
-    const size_t shmem = ldsBytes(p.scene, lds);
+    const bool wide = !lds && !count && p.scene.wide != nullptr;
+    const size_t shmem = wide ? (size_t) p.scene.wide_depth * BLOCK * sizeof(uint2) : ldsBytes(p.scene, lds);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
     const bool split = p.rad != nullptr;
     const int groups = split ? (p.sample_end - p.sample_begin + p.strata_per_group - 1) / p.strata_per_group : 1;
@@ -336,11 +346,13 @@ hipError_t jtx_launch_render_pixels(const RenderParams &p, int num_owned_tiles, 
 #define LAUNCH_RP(C, L, M) do { if (split) hipLaunchKernelGGL((k_render_pixels<C, L, M, true>), grid2, block, shmem, stream, p); \
                                 else hipLaunchKernelGGL((k_render_pixels<C, L, M, false>), grid, block, shmem, stream, p); } while (0)
     if (lambert) {
-        if (lds) { if (count) LAUNCH_RP(true, true, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, true, MAT_DIFFUSE_ONLY); }
-        else     { if (count) LAUNCH_RP(true, false, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, false, MAT_DIFFUSE_ONLY); }
+        if (lds)       { if (count) LAUNCH_RP(true, SRC_LDS, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, SRC_LDS, MAT_DIFFUSE_ONLY); }
+        else if (wide) LAUNCH_RP(false, SRC_WIDE, MAT_DIFFUSE_ONLY);
+        else           { if (count) LAUNCH_RP(true, SRC_GLOBAL, MAT_DIFFUSE_ONLY); else LAUNCH_RP(false, SRC_GLOBAL, MAT_DIFFUSE_ONLY); }
     } else {
-        if (lds) { if (count) LAUNCH_RP(true, true, MAT_ALL); else LAUNCH_RP(false, true, MAT_ALL); }
-        else     { if (count) LAUNCH_RP(true, false, MAT_ALL); else LAUNCH_RP(false, false, MAT_ALL); }
+        if (lds)       { if (count) LAUNCH_RP(true, SRC_LDS, MAT_ALL); else LAUNCH_RP(false, SRC_LDS, MAT_ALL); }
+        else if (wide) LAUNCH_RP(false, SRC_WIDE, MAT_ALL);
+        else           { if (count) LAUNCH_RP(true, SRC_GLOBAL, MAT_ALL); else LAUNCH_RP(false, SRC_GLOBAL, MAT_ALL); }
     }
 #undef LAUNCH_RP
     return hipGetLastError();

@@ -22,6 +22,7 @@ struct DLight { int type; float position[3]; float intensity[3]; float scale; fl
 
 struct DevScene {
     const float4    *tnodes;      // threaded (stackless) node records: 8 direction-sign orderings x num_nodes x 2 float4
+    const uint4     *wide;        // 8-ary quantised nodes + leaf records (traverseWide), or null
     const float4    *tris;
     const float4    *shade;
     const DMaterial *materials;
@@ -29,6 +30,7 @@ struct DevScene {
     const DTexture  *textures;
     const float     *texels;
     int num_nodes, num_prims, num_lights, num_materials;
+    int wide_depth;        // levels of the wide tree = LDS stack entries per lane
     int lds_threaded;      // != 0: the 8 threaded orderings + tris are staged in LDS (stackless kernels)
     int material_mask;     // OR of (1 << Material::type) over the scene's materials
     float sky[3];
@@ -45,6 +47,8 @@ struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode
 #else
 #define UTIL(x)
 #endif
+
+enum { SRC_GLOBAL = 0, SRC_LDS = 1, SRC_WIDE = 2 };
 
 struct GlobalSrc {
     const float4 *tnodes, *tris;
@@ -192,15 +196,184 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
     return hitAnything;
 }
 
+// ---- wide (8-ary, quantised) traversal for HBM-resident scenes ---------------------------------------
+// What the reference computes for a REGULAR ray (see slabRegular) does not depend on the interior
+// nodes at all: boxes nest exactly (a node's box is the min/max of its children's, bvh.cpp:21-24) and
+// every operation of the slab test is monotone in the box planes and in t.max, so "the leaf's own box
+// test passes" implies "every ancestor's test passed" -- earlier, with a t.max that was no smaller.
+// closestHit / anyHit are therefore:  walk the LEAVES in the octant's fixed near-first order; test the
+// leaf's box against the current interval; if it passes, test its triangles.  Any structure that walks
+// the leaves in that order and only skips leaves whose box test would fail gives bit-identical hits.
+// The uncounted kernels use that freedom (the counted ones keep the reference's node visits):
+//   wide node (80 B = 5 x 16 B): the <= 8 descendants three binary levels below a node, slot = path
+//     bits (b2 b1 b0; 0 = first child i+1, 1 = second child), each with a box quantised OUTWARD to
+//     8 bits per plane on the node's own grid (plane = fma(q, 2^e, origin), checked on the host with
+//     the same fma), so a slab test on it can only pass more often than on the exact box.
+//       [origin.xyz | ex ey ez] [children base | imask lmask | order bytes oct 0-3 | oct 4-7]
+//       [lo.x x8 | lo.y x8] [lo.z x8 | hi.x x8] [hi.y x8 | hi.z x8]
+//     children block (16-B granules): interior children (5 granules each, slot order), then leaf
+//     records (2 granules each, slot order).  order byte of an octant: which of the 7 collapsed
+//     binary nodes visit their second child first (bits 0,2,4,6: level 3; 1,5: level 2; 3: level 1).
+//   leaf record (32 B): the exact leaf box + primitivesOffset + numPrimitives, tested with slabRegular.
+// The per-lane stack holds one 64-bit entry per wide level {children base, imask, lmask, pending hits in
+// visiting order, order byte} in LDS.  A stale hit bit (t.max shrank since the node was tested) only
+// costs a visit.  Irregular rays (a zero / non-finite direction component ...) take the exact binary path.
+#ifndef JTX_WIDE_LEAF_VOTE
+#define JTX_WIDE_LEAF_VOTE 4
+#endif
+#ifndef JTX_WIDE_STEPS
+#define JTX_WIDE_STEPS 1
+#endif
+
+// outward slack of the wide-node slab test: mu = 2^-23 (4 |b| + 512 |a|) + 2^-100 per axis (error budget in DESIGN.md)
+#define WIDE_MU_B 4.76837158203125e-07f
+#define WIDE_MU_A 6.103515625e-05f
+#define WIDE_MU_0 7.888609052210118e-31f
+constexpr float WIDE_RANGE = 1099511627776.0f;   // 2^40: |1/d|, 1/|1/d| and |o| of a ray the wide nodes may take (no overflow, a exact)
+
+JD float ubyteToFloat(unsigned v, int k) { return (float) ((v >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
+
+template <bool ANY, class Src>
+JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk, int stride, f3 o, f3 d, f3 inv,
+                     int negmask, float tmin, float tmax, HitRec &rec) {
+    // group = the children of one wide node still to visit; the start group is "the root"
+    unsigned gbase = 0u, gbits = 0x00010001u;            // imask = 1 (slot 0 interior), pending = order position 0
+    int sp = 0, pendLeaf = -1;
+    bool done = false, hitAnything = false;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const int octShift = (negmask & 3) * 8;
+#ifdef JTX_WIDE_GUARD
+    int guard = 0;
+#endif
+    while (true) {
+        while (true) {
+#pragma unroll
+            for (int rep = 0; rep < JTX_WIDE_STEPS; ++rep) {
+#ifdef JTX_WIDE_GUARD
+                if (++guard > 200000) done = true;          // debugging aid: a corrupt node set cannot hang the wave
+#endif
+                if (pendLeaf < 0 && !done) {
+                    if ((gbits & 0x00ff0000u) == 0u) {                    // group exhausted: pop
+                        if (sp == 0) done = true;
+                        else { --sp; const uint2 e = stk[sp * stride]; gbase = e.x; gbits = e.y; }
+                    }
+                    if (!done) {
+                        const unsigned pending = (gbits >> 16) & 0xffu;
+                        const int k = __builtin_ctz(pending);
+                        gbits &= ~(0x10000u << k);
+                        const unsigned B = gbits >> 24;
+                        const unsigned b2 = ((unsigned) k >> 2) ^ ((B >> 3) & 1u);
+                        const unsigned b1 = (((unsigned) k >> 1) & 1u) ^ ((B >> (1u + 4u * b2)) & 1u);
+                        const unsigned b0 = ((unsigned) k & 1u) ^ ((B >> (4u * b2 + 2u * b1)) & 1u);
+                        const unsigned bit = 1u << (4u * b2 + 2u * b1 + b0), below = bit - 1u;
+                        const unsigned imask = gbits & 0xffu, lmask = (gbits >> 8) & 0xffu;
+                        if (imask & bit) {
+                            const unsigned a = gbase + 5u * (unsigned) __popc(imask & below);
+                            if (gbits & 0x00ff0000u) { stk[sp * stride] = make_uint2(gbase, gbits); ++sp; }
+                            const uint4 n0 = wide[a], n1 = wide[a + 1], n2 = wide[a + 2], n3 = wide[a + 3], n4 = wide[a + 4];
+                            // per axis: t(q) = q * a + b with a = cell / d (exact: a power-of-two scaling), b = (origin - o) / d,
+                            // pushed outward by mu >= every rounding difference to AABB::hit on a contained box
+                            const float axx = __uint_as_float((n0.w & 0xffu) << 23) * inv.x, bxx = (__uint_as_float(n0.x) - o.x) * inv.x;
+                            const float ayy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * inv.y, byy = (__uint_as_float(n0.y) - o.y) * inv.y;
+                            const float azz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * inv.z, bzz = (__uint_as_float(n0.z) - o.z) * inv.z;
+                            const float mux = __fmaf_rn(fabsf(bxx), WIDE_MU_B, __fmaf_rn(fabsf(axx), WIDE_MU_A, WIDE_MU_0));
+                            const float muy = __fmaf_rn(fabsf(byy), WIDE_MU_B, __fmaf_rn(fabsf(ayy), WIDE_MU_A, WIDE_MU_0));
+                            const float muz = __fmaf_rn(fabsf(bzz), WIDE_MU_B, __fmaf_rn(fabsf(azz), WIDE_MU_A, WIDE_MU_0));
+                            const float bnx = bxx - mux, bfx = bxx + mux, bny = byy - muy, bfy = byy + muy, bnz = bzz - muz, bfz = bzz + muz;
+                            // near / far plane bytes of each axis by the direction sign (== min/max of the pair for a regular ray)
+                            const unsigned nxq[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, fxq[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
+                            const unsigned nyq[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, fyq[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
+                            const unsigned nzq[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, fzq[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
+                            unsigned hits = 0u;
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) {
+                                const int w = s >> 2, b = s & 3;
+                                const float t0 = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)),
+                                                       fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), tmin));
+                                const float t1 = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)),
+                                                       fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), tmax));
+                                hits |= (t0 <= t1 ? 1u : 0u) << s;
+                            }
+                            hits &= (n1.y | (n1.y >> 8)) & 0xffu;
+                            // slot space -> visiting order of this ray's octant
+                            const unsigned ob = ((negmask & 4 ? n1.w : n1.z) >> octShift) & 0xffu;
+                            const unsigned e2 = ob & 0x55u, e1 = ((ob >> 1) & 0x11u) * 3u, e0 = (ob & 8u) ? 0x0fu : 0u;
+                            unsigned t = ((hits >> 1) ^ hits) & e2; hits ^= t | (t << 1);
+                            t = ((hits >> 2) ^ hits) & e1; hits ^= t | (t << 2);
+                            t = ((hits >> 4) ^ hits) & e0; hits ^= t | (t << 4);
+                            gbase = n1.x;
+                            gbits = (n1.y & 0xffffu) | (hits << 16) | (ob << 24);
+                        } else {
+                            pendLeaf = (int) (gbase + 5u * (unsigned) __popc(imask) + 2u * (unsigned) __popc(lmask & below));
+                        }
+                    }
+                }
+            }
+            const unsigned long long walking = __ballot(pendLeaf < 0 && !done);
+            const unsigned long long parked = __ballot(pendLeaf >= 0);
+            if (walking == 0ull || __popcll(parked) >= JTX_WIDE_LEAF_VOTE) break;
+        }
+        if (__ballot(pendLeaf >= 0) == 0ull) break;          // wave-uniform: every lane is done
+        if (pendLeaf >= 0) {
+            const uint4 ua = wide[pendLeaf], ub = wide[pendLeaf + 1];
+            const float4 la = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
+            const float4 lb = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), 0.0f, 0.0f);
+            if (slabRegular(la, lb, o, inv, tmin, tmax)) {
+                const int n = (int) ub.w, off = (int) ub.z;
+                for (int i = 0; i < n; ++i) {
+                    const int prim = off + i;
+                    float b1, b2, root;
+                    if (!triTest(src, prim, o, d, tmin, tmax, b1, b2, root)) continue;
+                    hitAnything = true;
+                    if (ANY) break;
+                    tmax = root;
+                    rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+                }
+                if (ANY && hitAnything) done = true;
+            }
+            pendLeaf = -1;
+        }
+    }
+    return hitAnything;
+}
+
+JD bool regularRay(f3 o, f3 inv, float tmin, float tmax) {
+    return finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
+           fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
+           tmin == tmin && tmax == tmax;
+}
+
+// HBM-resident scene, uncounted kernels: wide traversal; a wave with an irregular ray walks the binary records
+struct WideSrc {
+    const uint4 *wide;
+    const float4 *tnodes, *tris;
+    uint2 *stk;               // this lane's LDS stack column
+    int stride;               // entries between two levels (= workgroup size)
+    JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
+    JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
+};
+
+template <bool ANY, bool COUNT>
+JD bool traverseNoStack(const WideSrc &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
+    static_assert(!COUNT, "the counted kernels reproduce the reference's node visits: binary records only");
+    if (num_nodes == 0) return false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+    const float hi = fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z)), lo = fminf(fminf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
+    const bool wideOk = regularRay(o, inv, tmin, tmax) && hi <= WIDE_RANGE && lo >= 1.0f / WIDE_RANGE &&
+                        fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= WIDE_RANGE;
+    if (__builtin_expect(__ballot(!wideOk) == 0ull, 1))
+        return traverseWide<ANY>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec);
+    return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
+}
+
 // stackless entry point (k_render_pixels and the per-ray test kernels)
 template <bool ANY, bool COUNT, class Src>
 JD bool traverseNoStack(const Src &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-    const bool regular = finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
-                         fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
-                         tmin == tmin && tmax == tmax;
+    const bool regular = regularRay(o, inv, tmin, tmax);
     if (__builtin_expect(regular, 1)) return traverseThreaded<ANY, COUNT, true>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
     return traverseThreaded<ANY, COUNT, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);   // axis-parallel & co.
 }

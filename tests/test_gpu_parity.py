@@ -419,3 +419,51 @@ def test_shard_buffers_are_zeroed_every_frame(gpu, cornell_pair):
     assert (a[~mask] == 0).all() and (i[~mask] == 0).all()
     ref_acc, ref_img, _ = osc.render(cam)
     assert np.array_equal(a[mask].view(np.uint32), ref_acc[mask].view(np.uint32)) and np.array_equal(i[mask], ref_img[mask])
+
+
+# ---- uncounted kernels (the timed path): HBM-resident scenes walk the 8-ary quantised BVH there ----
+def test_wide_bvh_is_built_for_hbm_scenes(gpu, mixed_pair, cornell_pair):
+    assert mixed_pair[1].info()["wide_depth"] >= 2 and mixed_pair[1].info()["wide_bytes"] > 0
+    assert cornell_pair[1].info()["lds_resident"]            # LDS-resident scenes keep the threaded records
+
+
+@pytest.mark.parametrize("integrator", [1, 2])
+def test_uncounted_render_mixed(gpu, mixed_pair, integrator):
+    """count_rays=False is what bench.py times: same film as the oracle, bit for bit."""
+    data, sc, osc = mixed_pair
+    cam_g = gpu.StaticCamera(200, 120, data.camera, 2, 2, 8)
+    cam_g.render(sc, count_rays=False, integrator=integrator)
+    acc, img, _ = osc.render(data.camera_desc(200, 120, 2, 2, 8), count=False)
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
+
+
+@pytest.mark.parametrize("tris,prims", [(20000, 1), (60000, 1), (20000, 4)])
+def test_uncounted_render_atrium(gpu, tris, prims):
+    data = gpu.scenes.atrium(target_tris=tris)
+    data.max_prims_in_node = prims
+    sc = gpu.Scene(data); sc.buildBVH()
+    assert sc.info()["wide_depth"] >= 3
+    osc = ol.OracleScene(data)
+    cam_g = gpu.StaticCamera(160, 90, data.camera, 2, 2, 8)
+    cam_g.render(sc, count_rays=False, integrator=1)
+    acc, img, _ = osc.render(data.camera_desc(160, 90, 2, 2, 8), count=False)
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
+
+
+def test_uncounted_render_axis_parallel_shadow_rays(gpu):
+    """A DISTANT light straight overhead makes every shadow ray axis-parallel (1/d = inf): those waves must
+    take the exact binary records (AABB::hit's inf/NaN behaviour is not monotone), the others the wide nodes."""
+    data = gpu.scenes.atrium(target_tris=20000)
+    for l in data.lights:
+        if l["type"] == 1:
+            l["position"] = (0.0, -1.0, 0.0)
+    sc = gpu.Scene(data); sc.buildBVH()
+    osc = ol.OracleScene(data)
+    cam_g = gpu.StaticCamera(128, 72, data.camera, 2, 2, 6)
+    cam_g.render(sc, count_rays=False, integrator=1)
+    acc, img, cnt = osc.render(data.camera_desc(128, 72, 2, 2, 6))
+    assert cnt["n_any"] > 0
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
