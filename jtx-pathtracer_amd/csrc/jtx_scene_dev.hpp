@@ -198,7 +198,7 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 
 // ---- wide (8-ary, quantised) traversal for HBM-resident scenes ---------------------------------------
 // What the reference computes for a REGULAR ray (see slabRegular) does not depend on the interior
-// nodes at all: boxes nest exactly (a node's box is the min/max of its children's, bvh.cpp:21-24) and
+// nodes at all: boxes nest exactly (a node's box is the union of its children's, initBranch bvh.hpp:31-37) and
 // every operation of the slab test is monotone in the box planes and in t.max, so "the leaf's own box
 // test passes" implies "every ancestor's test passed" -- earlier, with a t.max that was no smaller.
 // closestHit / anyHit are therefore:  walk the LEAVES in the octant's fixed near-first order; test the
