@@ -233,114 +233,130 @@ constexpr float WIDE_RANGE = 1099511627776.0f;   // 2^40: |1/d|, 1/|1/d| and |o|
 
 JD float ubyteToFloat(unsigned v, int k) { return (float) ((v >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
 
+struct WideRay { f3 o, d, inv; float tmin, tmax; int negmask; };
+struct WideState {
+    unsigned gbase, gbits;       // current group: children base | imask, lmask, pending hits (visiting order), order byte
+    int sp, pendLeaf;            // stack entries in use; granule of the leaf record the lane is parked on (-1: none)
+    bool done, hitAnything;
+    // group = the children of one wide node still to visit; the start group is "the root"
+    JD void start() { gbase = 0u; gbits = 0x00010001u; sp = 0; pendLeaf = -1; done = false; hitAnything = false; }
+    JD bool walking() const { return pendLeaf < 0 && !done; }
+};
+
+// One interior step of a walking lane: take the next child of the current group (popping the stack when the
+// group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
+JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws) {
+    if ((ws.gbits & 0x00ff0000u) == 0u) {                    // group exhausted: pop
+        if (ws.sp == 0) { ws.done = true; return; }
+        --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
+    }
+    const unsigned pending = (ws.gbits >> 16) & 0xffu;
+    const int k = __builtin_ctz(pending);
+    ws.gbits &= ~(0x10000u << k);
+    const unsigned B = ws.gbits >> 24;
+    const unsigned b2 = ((unsigned) k >> 2) ^ ((B >> 3) & 1u);
+    const unsigned b1 = (((unsigned) k >> 1) & 1u) ^ ((B >> (1u + 4u * b2)) & 1u);
+    const unsigned b0 = ((unsigned) k & 1u) ^ ((B >> (4u * b2 + 2u * b1)) & 1u);
+    const unsigned bit = 1u << (4u * b2 + 2u * b1 + b0), below = bit - 1u;
+    const unsigned imask = ws.gbits & 0xffu, lmask = (ws.gbits >> 8) & 0xffu;
+    if (!(imask & bit)) {
+        ws.pendLeaf = (int) (ws.gbase + 5u * (unsigned) __popc(imask) + 2u * (unsigned) __popc(lmask & below));
+        return;
+    }
+    const unsigned a = ws.gbase + 5u * (unsigned) __popc(imask & below);
+    if (ws.gbits & 0x00ff0000u) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
+    const uint4 n0 = wide[a], n1 = wide[a + 1], n2 = wide[a + 2], n3 = wide[a + 3], n4 = wide[a + 4];
+    const f3 o = r.o, inv = r.inv;
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    // per axis: t(q) = q * a + b with a = cell / d (exact: a power-of-two scaling), b = (origin - o) / d,
+    // pushed outward by mu >= every rounding difference to AABB::hit on a contained box
+    const float axx = __uint_as_float((n0.w & 0xffu) << 23) * inv.x, bxx = (__uint_as_float(n0.x) - o.x) * inv.x;
+    const float ayy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * inv.y, byy = (__uint_as_float(n0.y) - o.y) * inv.y;
+    const float azz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * inv.z, bzz = (__uint_as_float(n0.z) - o.z) * inv.z;
+    const float mux = __fmaf_rn(fabsf(bxx), WIDE_MU_B, __fmaf_rn(fabsf(axx), WIDE_MU_A, WIDE_MU_0));
+    const float muy = __fmaf_rn(fabsf(byy), WIDE_MU_B, __fmaf_rn(fabsf(ayy), WIDE_MU_A, WIDE_MU_0));
+    const float muz = __fmaf_rn(fabsf(bzz), WIDE_MU_B, __fmaf_rn(fabsf(azz), WIDE_MU_A, WIDE_MU_0));
+    const float bnx = bxx - mux, bfx = bxx + mux, bny = byy - muy, bfy = byy + muy, bnz = bzz - muz, bfz = bzz + muz;
+    // near / far plane bytes of each axis by the direction sign (== min/max of the pair for a regular ray)
+    const unsigned nxq[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, fxq[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
+    const unsigned nyq[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, fyq[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
+    const unsigned nzq[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, fzq[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
+    unsigned hits = 0u;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int w = s >> 2, b = s & 3;
+        const float t0 = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)),
+                               fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), r.tmin));
+        const float t1 = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)),
+                               fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), r.tmax));
+        hits |= (t0 <= t1 ? 1u : 0u) << s;
+    }
+    hits &= (n1.y | (n1.y >> 8)) & 0xffu;
+    // slot space -> visiting order of this ray's octant
+    const unsigned ob = ((r.negmask & 4 ? n1.w : n1.z) >> ((r.negmask & 3) * 8)) & 0xffu;
+    const unsigned e2 = ob & 0x55u, e1 = ((ob >> 1) & 0x11u) * 3u, e0 = (ob & 8u) ? 0x0fu : 0u;
+    unsigned t = ((hits >> 1) ^ hits) & e2; hits ^= t | (t << 1);
+    t = ((hits >> 2) ^ hits) & e1; hits ^= t | (t << 2);
+    t = ((hits >> 4) ^ hits) & e0; hits ^= t | (t << 4);
+    ws.gbase = n1.x;
+    ws.gbits = (n1.y & 0xffffu) | (hits << 16) | (ob << 24);
+}
+
+// The leaf a lane is parked on: AABB::hit on the exact box, then the leaf's triangles (mesh.hpp:106-192)
+template <class Src>
+JD void wideLeafStep(const uint4 *__restrict__ wide, const Src &src, bool any, WideRay &r, WideState &ws, HitRec &rec) {
+    const uint4 ua = wide[ws.pendLeaf], ub = wide[ws.pendLeaf + 1];
+    const float4 la = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
+    const float4 lb = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), 0.0f, 0.0f);
+    if (slabRegular(la, lb, r.o, r.inv, r.tmin, r.tmax)) {
+        const int n = (int) ub.w, off = (int) ub.z;
+        for (int i = 0; i < n; ++i) {
+            const int prim = off + i;
+            float b1, b2, root;
+            if (!triTest(src, prim, r.o, r.d, r.tmin, r.tmax, b1, b2, root)) continue;
+            ws.hitAnything = true;
+            if (any) break;
+            r.tmax = root;
+            rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+        }
+        if (any && ws.hitAnything) ws.done = true;
+    }
+    ws.pendLeaf = -1;
+}
+
 template <bool ANY, class Src>
 JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk, int stride, f3 o, f3 d, f3 inv,
                      int negmask, float tmin, float tmax, HitRec &rec) {
-    // group = the children of one wide node still to visit; the start group is "the root"
-    unsigned gbase = 0u, gbits = 0x00010001u;            // imask = 1 (slot 0 interior), pending = order position 0
-    int sp = 0, pendLeaf = -1;
-    bool done = false, hitAnything = false;
-    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-    const int octShift = (negmask & 3) * 8;
-#ifdef JTX_WIDE_GUARD
-    int guard = 0;
-#endif
+    WideRay r; r.o = o; r.d = d; r.inv = inv; r.tmin = tmin; r.tmax = tmax; r.negmask = negmask;
+    WideState ws; ws.start();
     while (true) {
         while (true) {
 #pragma unroll
-            for (int rep = 0; rep < JTX_WIDE_STEPS; ++rep) {
-#ifdef JTX_WIDE_GUARD
-                if (++guard > 200000) done = true;          // debugging aid: a corrupt node set cannot hang the wave
-#endif
-                if (pendLeaf < 0 && !done) {
-                    if ((gbits & 0x00ff0000u) == 0u) {                    // group exhausted: pop
-                        if (sp == 0) done = true;
-                        else { --sp; const uint2 e = stk[sp * stride]; gbase = e.x; gbits = e.y; }
-                    }
-                    if (!done) {
-                        const unsigned pending = (gbits >> 16) & 0xffu;
-                        const int k = __builtin_ctz(pending);
-                        gbits &= ~(0x10000u << k);
-                        const unsigned B = gbits >> 24;
-                        const unsigned b2 = ((unsigned) k >> 2) ^ ((B >> 3) & 1u);
-                        const unsigned b1 = (((unsigned) k >> 1) & 1u) ^ ((B >> (1u + 4u * b2)) & 1u);
-                        const unsigned b0 = ((unsigned) k & 1u) ^ ((B >> (4u * b2 + 2u * b1)) & 1u);
-                        const unsigned bit = 1u << (4u * b2 + 2u * b1 + b0), below = bit - 1u;
-                        const unsigned imask = gbits & 0xffu, lmask = (gbits >> 8) & 0xffu;
-                        if (imask & bit) {
-                            const unsigned a = gbase + 5u * (unsigned) __popc(imask & below);
-                            if (gbits & 0x00ff0000u) { stk[sp * stride] = make_uint2(gbase, gbits); ++sp; }
-                            const uint4 n0 = wide[a], n1 = wide[a + 1], n2 = wide[a + 2], n3 = wide[a + 3], n4 = wide[a + 4];
-                            // per axis: t(q) = q * a + b with a = cell / d (exact: a power-of-two scaling), b = (origin - o) / d,
-                            // pushed outward by mu >= every rounding difference to AABB::hit on a contained box
-                            const float axx = __uint_as_float((n0.w & 0xffu) << 23) * inv.x, bxx = (__uint_as_float(n0.x) - o.x) * inv.x;
-                            const float ayy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * inv.y, byy = (__uint_as_float(n0.y) - o.y) * inv.y;
-                            const float azz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * inv.z, bzz = (__uint_as_float(n0.z) - o.z) * inv.z;
-                            const float mux = __fmaf_rn(fabsf(bxx), WIDE_MU_B, __fmaf_rn(fabsf(axx), WIDE_MU_A, WIDE_MU_0));
-                            const float muy = __fmaf_rn(fabsf(byy), WIDE_MU_B, __fmaf_rn(fabsf(ayy), WIDE_MU_A, WIDE_MU_0));
-                            const float muz = __fmaf_rn(fabsf(bzz), WIDE_MU_B, __fmaf_rn(fabsf(azz), WIDE_MU_A, WIDE_MU_0));
-                            const float bnx = bxx - mux, bfx = bxx + mux, bny = byy - muy, bfy = byy + muy, bnz = bzz - muz, bfz = bzz + muz;
-                            // near / far plane bytes of each axis by the direction sign (== min/max of the pair for a regular ray)
-                            const unsigned nxq[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, fxq[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
-                            const unsigned nyq[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, fyq[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
-                            const unsigned nzq[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, fzq[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
-                            unsigned hits = 0u;
-#pragma unroll
-                            for (int s = 0; s < 8; ++s) {
-                                const int w = s >> 2, b = s & 3;
-                                const float t0 = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)),
-                                                       fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), tmin));
-                                const float t1 = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)),
-                                                       fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), tmax));
-                                hits |= (t0 <= t1 ? 1u : 0u) << s;
-                            }
-                            hits &= (n1.y | (n1.y >> 8)) & 0xffu;
-                            // slot space -> visiting order of this ray's octant
-                            const unsigned ob = ((negmask & 4 ? n1.w : n1.z) >> octShift) & 0xffu;
-                            const unsigned e2 = ob & 0x55u, e1 = ((ob >> 1) & 0x11u) * 3u, e0 = (ob & 8u) ? 0x0fu : 0u;
-                            unsigned t = ((hits >> 1) ^ hits) & e2; hits ^= t | (t << 1);
-                            t = ((hits >> 2) ^ hits) & e1; hits ^= t | (t << 2);
-                            t = ((hits >> 4) ^ hits) & e0; hits ^= t | (t << 4);
-                            gbase = n1.x;
-                            gbits = (n1.y & 0xffffu) | (hits << 16) | (ob << 24);
-                        } else {
-                            pendLeaf = (int) (gbase + 5u * (unsigned) __popc(imask) + 2u * (unsigned) __popc(lmask & below));
-                        }
-                    }
-                }
-            }
-            const unsigned long long walking = __ballot(pendLeaf < 0 && !done);
-            const unsigned long long parked = __ballot(pendLeaf >= 0);
+            for (int rep = 0; rep < JTX_WIDE_STEPS; ++rep)
+                if (ws.walking()) wideNodeStep(wide, stk, stride, r, ws);
+            const unsigned long long walking = __ballot(ws.walking());
+            const unsigned long long parked = __ballot(ws.pendLeaf >= 0);
             if (walking == 0ull || __popcll(parked) >= JTX_WIDE_LEAF_VOTE) break;
         }
-        if (__ballot(pendLeaf >= 0) == 0ull) break;          // wave-uniform: every lane is done
-        if (pendLeaf >= 0) {
-            const uint4 ua = wide[pendLeaf], ub = wide[pendLeaf + 1];
-            const float4 la = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
-            const float4 lb = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), 0.0f, 0.0f);
-            if (slabRegular(la, lb, o, inv, tmin, tmax)) {
-                const int n = (int) ub.w, off = (int) ub.z;
-                for (int i = 0; i < n; ++i) {
-                    const int prim = off + i;
-                    float b1, b2, root;
-                    if (!triTest(src, prim, o, d, tmin, tmax, b1, b2, root)) continue;
-                    hitAnything = true;
-                    if (ANY) break;
-                    tmax = root;
-                    rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
-                }
-                if (ANY && hitAnything) done = true;
-            }
-            pendLeaf = -1;
-        }
+        if (__ballot(ws.pendLeaf >= 0) == 0ull) break;          // wave-uniform: every lane is done
+        if (ws.pendLeaf >= 0) wideLeafStep(wide, src, ANY, r, ws, rec);
     }
-    return hitAnything;
+    return ws.hitAnything;
 }
+
+JD bool wideRayOk(f3 o, f3 inv, float tmin, float tmax);
 
 JD bool regularRay(f3 o, f3 inv, float tmin, float tmax) {
     return finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
            fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
            tmin == tmin && tmax == tmax;
+}
+
+// rays the wide nodes may take: regular, and in the range where cell / d is exact and nothing overflows
+JD bool wideRayOk(f3 o, f3 inv, float tmin, float tmax) {
+    const float hi = fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z)), lo = fminf(fminf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
+    return regularRay(o, inv, tmin, tmax) && hi <= WIDE_RANGE && lo >= 1.0f / WIDE_RANGE &&
+           fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= WIDE_RANGE;
 }
 
 // HBM-resident scene, uncounted kernels: wide traversal; a wave with an irregular ray walks the binary records
@@ -359,10 +375,7 @@ JD bool traverseNoStack(const WideSrc &src, int num_nodes, f3 o, f3 d, float tmi
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-    const float hi = fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z)), lo = fminf(fminf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
-    const bool wideOk = regularRay(o, inv, tmin, tmax) && hi <= WIDE_RANGE && lo >= 1.0f / WIDE_RANGE &&
-                        fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= WIDE_RANGE;
-    if (__builtin_expect(__ballot(!wideOk) == 0ull, 1))
+    if (__builtin_expect(__ballot(!wideRayOk(o, inv, tmin, tmax)) == 0ull, 1))
         return traverseWide<ANY>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec);
     return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
 }

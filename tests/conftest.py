@@ -27,6 +27,14 @@ def _has_gpu():
 @pytest.fixture(scope="session")
 def gpu():
     """The product library on a GPU box.  GPU tests FAIL (not skip) when the HIP library is missing."""
+    # torch (device buffers of the *_device tests) brings its own HIP runtime: let it initialise first, as in
+    # bench.py, so that any test subset sees the same load order as the whole suite
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except ImportError:
+        pass
     import jtx_pathtracer_amd as jtx
     jtx._capi.load()            # raises if libjtx_mi.so is absent: no silent fallback
     if not _has_gpu():
