@@ -263,6 +263,93 @@ class StaticCamera:
             f.write(self.img_[::-1].tobytes())
 
 
+class DynamicCamera(StaticCamera):
+    """DynamicCamera (src/camera.hpp:198-256, camera.cpp:130-255): the UI's restartable progressive render.
+    render(scene) returns at once; a worker thread accumulates samplesPerPass strata per pass into acc_ / img_
+    and advances currentSample_ after each pass; render() again abandons the frame in flight after its
+    current pass and starts over (camera moved / scene edited).  A pass is one GPU launch, so one host thread."""
+
+    def __init__(self, width, height, cameraProperties, xPixelSamples, yPixelSamples, maxDepth, samplesPerPass=1, threadCount=4):
+        super().__init__(width, height, cameraProperties, xPixelSamples, yPixelSamples, maxDepth, threadCount)
+        import threading
+        self.samplesPerPass_ = max(1, int(samplesPerPass))
+        self._cv = threading.Condition()
+        self._generation = self._running = 0
+        self._busy = self._pending = self._stop = False
+        self._scene = None
+        self._error = None
+        self._thread = threading.Thread(target=self._workerThread, daemon=True)
+        self._thread.start()
+
+    def render(self, scene, **_unused):
+        with self._cv:
+            self._pending = False
+            self._generation += 1
+            self._cv.wait_for(lambda: not self._busy)
+            self._scene = scene
+            self.acc_[...] = 0; self.img_[...] = 0
+            self.currentSample_ = 0
+            self._error = None
+            self._pending = True
+            self._cv.notify_all()
+
+    def resize(self, w, h):
+        with self._cv:
+            self._pending = False
+            self._generation += 1
+            self._cv.wait_for(lambda: not self._busy)
+            super().resize(w, h)
+            self._scene = None
+            self.currentSample_ = 0
+
+    def stopRender(self):
+        with self._cv:
+            self._stop = True
+            self._generation += 1
+            self._cv.notify_all()
+        self._thread.join()
+
+    def finished(self):
+        return self.currentSample_ >= self.getSpp()
+
+    def wait(self, timeout=None):
+        with self._cv:
+            ok = self._cv.wait_for(lambda: not self._busy and not self._pending and
+                                   (self._scene is None or self.finished() or self._error), timeout)
+            if self._error:
+                raise RuntimeError(self._error)
+            return ok
+
+    def _workerThread(self):
+        def tick(_cur, _total, _user):
+            self.currentSample_ += self.samplesPerPass_                 # end-of-pass barrier, camera.cpp:141-147
+            with self._cv:
+                return 1 if (self._generation != self._running or self._stop) else 0
+
+        cb = capi.PROGRESS_CB(tick)
+        with self._cv:
+            while True:
+                self._cv.wait_for(lambda: self._stop or self._pending)
+                if self._stop:
+                    return
+                self._pending = False
+                self._running = self._generation
+                self._busy = True
+                scene, cam = self._scene, self.desc()
+                o = capi.RenderOpts()
+                o.samples_per_tick = self.samplesPerPass_
+                self._cv.release()
+                try:
+                    rc = self._lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), _fp(self.acc_),
+                                                 self.img_.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None)
+                    err = None if rc == 0 else self._lib.jtx_mi_last_error().decode()
+                finally:
+                    self._cv.acquire()
+                self._error = err
+                self._busy = False
+                self._cv.notify_all()
+
+
 def camera_rays(cam_desc, row, col, sample):
     lib = capi.load()
     row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32); sample = np.ascontiguousarray(sample, np.int32)

@@ -9,6 +9,9 @@
 
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <limits>
@@ -206,6 +209,73 @@ public:
     }
 private:
     static int tick(int32_t cur, int32_t, void *user) { auto *self = (StaticCamera *) user; self->currentSample_.store(cur); return self->stopRender_ ? 1 : 0; }
+};
+
+// DynamicCamera (camera.hpp:198-256, camera.cpp:130-255): the interactive, restartable progressive render the UI
+// drives.  render(scene) returns at once; a worker accumulates samplesPerPass strata per pass into acc_ / img_ and
+// advances currentSample_ after every pass (the reference's end-of-pass barrier, camera.cpp:141-147); calling
+// render() again (camera moved, scene edited) abandons the frame in flight after its current pass and starts over.
+// The reference spreads a pass over threadCount CPU workers; here a pass is one launch on the GPU, so one host
+// thread feeds it.
+class DynamicCamera : public Camera {
+public:
+    DynamicCamera(int width, int height, CameraProperties cp, int xs, int ys, int maxDepth, int samplesPerPass = 1, int threadCount = 4)
+        : Camera(width, height, cp, xs, ys, maxDepth, threadCount), samplesPerPass_(samplesPerPass > 0 ? samplesPerPass : 1) { startThreads(); }
+    ~DynamicCamera() { stopThreads(); }
+    void resize(int w, int h) {                                        // camera.cpp:191-194
+        std::unique_lock<std::mutex> lk(mu_);
+        pending_ = false; ++generation_; idle_.wait(lk, [&] { return !busy_; });   // let the pass in flight drain before the buffers move
+        Camera::resize(w, h); scene_ = nullptr; currentSample_.store(0);
+    }
+    void render(const Scene &scene) {                                  // camera.cpp:196-211
+        std::unique_lock<std::mutex> lk(mu_);
+        pending_ = false; ++generation_; idle_.wait(lk, [&] { return !busy_; });
+        scene_ = &scene; acc_.clear(); img_.clear(); currentSample_.store(0); error_.clear();
+        pending_ = true;
+        lk.unlock(); wake_.notify_all();
+    }
+    void stopRender() { stopThreads(); }                               // camera.hpp:227
+    bool finished() const { return currentSample_.load() >= getSpp(); }
+    // not in the reference (its UI polls currentSample_): block until the frame is complete or failed
+    void wait() { std::unique_lock<std::mutex> lk(mu_); idle_.wait(lk, [&] { return !busy_ && !pending_ && (scene_ == nullptr || finished() || !error_.empty()); }); if (!error_.empty()) throw std::runtime_error(error_); }
+private:
+    int samplesPerPass_;
+    const Scene *scene_ = nullptr;
+    std::thread thread_;
+    std::mutex mu_;
+    std::condition_variable wake_, idle_;
+    unsigned long generation_ = 0, running_ = 0;
+    bool busy_ = false, pending_ = false, stopThreads_ = false;
+    std::string error_;
+    void startThreads() { stopThreads_ = false; thread_ = std::thread(&DynamicCamera::workerThread, this); }
+    void stopThreads() {                                               // camera.cpp:178-189
+        { std::unique_lock<std::mutex> lk(mu_); stopThreads_ = true; ++generation_; }
+        wake_.notify_all();
+        if (thread_.joinable()) thread_.join();
+    }
+    static int tick(int32_t, int32_t, void *user) {                    // end of a pass: camera.cpp:141-147
+        auto *self = (DynamicCamera *) user;
+        self->currentSample_.fetch_add(self->samplesPerPass_);
+        std::unique_lock<std::mutex> lk(self->mu_);
+        return (self->generation_ != self->running_ || self->stopThreads_) ? 1 : 0;
+    }
+    void workerThread() {                                              // camera.cpp:213-255
+        std::unique_lock<std::mutex> lk(mu_);
+        while (true) {
+            wake_.wait(lk, [&] { return stopThreads_ || pending_; });
+            if (stopThreads_) break;
+            pending_ = false; running_ = generation_; busy_ = true;
+            const Scene *scene = scene_;
+            jtx_mi_camera_desc c = desc();
+            jtx_mi_render_opts o{}; o.samples_per_tick = samplesPerPass_;
+            lk.unlock();
+            const int rc = jtx_mi_render(scene->handle(), &c, &o, &acc_.data()[0].x, &img_.data()[0].R, &DynamicCamera::tick, this);
+            lk.lock();
+            if (rc) error_ = jtx_mi_last_error();
+            busy_ = false;
+            idle_.notify_all();
+        }
+    }
 };
 
 // sampleBxdf / evalBxdf / pdfBxdf (bxdf.hpp:131-133), single-sample forms

@@ -32,6 +32,23 @@ int main() {
         const bool shadow = scene.anyHit(Ray(Vec3(0.1f, 0.2f, 8), Vec3(0, 0, -1)), Interval(0.0f, 5.0f));
         std::printf("hash %08x samples %d hit %d t %.3f shadow %d radius %.4f\n", h, camera.currentSample_.load(), (int) hit, rec.t, (int) shadow,
                     scene.getSceneRadius());
+        // DynamicCamera (the UI's progressive camera): non-blocking render, restart on a camera change
+        DynamicCamera dyn(64, 64, scene.cameraProperties, 2, 2, 4, 1);
+        dyn.render(scene); dyn.wait();
+        unsigned hd = 2166136261u;
+        const unsigned char *bd = &dyn.img_.data()[0].R;
+        for (int i = 0; i < 64 * 64 * 3; ++i) { hd ^= bd[i]; hd *= 16777619u; }
+        dyn.properties_.center = Vec3(0.5f, 0.25f, 8);                  // move the camera and start over, twice in a row
+        dyn.render(scene); dyn.render(scene); dyn.wait();
+        StaticCamera moved(64, 64, dyn.properties_, 2, 2, 4);
+        moved.renderFinal(scene);
+        int same = 1;
+        for (int i = 0; i < 64 * 64; ++i) {
+            const RGB a = dyn.img_.data()[i], c = moved.img_.data()[i];
+            if (a.R != c.R || a.G != c.G || a.B != c.B) same = 0;
+        }
+        dyn.stopRender();
+        std::printf("dynhash %08x dynsamples %d restart_same %d\n", hd, dyn.currentSample_.load(), same);
         scene.destroy();
         return 0;
     } catch (const std::exception &e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }

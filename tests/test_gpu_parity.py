@@ -258,12 +258,14 @@ def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
     exe = str(tmp_path / "host_api_demo")
     libdir = os.path.join(root, "jtx-pathtracer_amd")
     subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "cpp", "host_api_demo.cpp"),
-                    "-L", libdir, "-ljtx_mi", "-Wl,-rpath," + libdir], check=True)
+                    "-L", libdir, "-ljtx_mi", "-lpthread", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     kv = dict(zip(out[0::2], out[1::2]))
     assert kv["hash"] == "1af9ba89"
     assert kv["samples"] == "4" and kv["hit"] == "1" and kv["shadow"] == "0"
     assert abs(float(kv["t"]) - 9.0) < 1e-5 and abs(float(kv["radius"]) - 2 ** 0.5) < 1e-4
+    # DynamicCamera: same image as the static render; a restarted render equals a static one from the new camera
+    assert kv["dynhash"] == "1af9ba89" and kv["dynsamples"] == "4" and kv["restart_same"] == "1"
 
 
 @pytest.mark.parametrize("integrator", [1, 2, 3, 4])
@@ -467,3 +469,30 @@ def test_uncounted_render_axis_parallel_shadow_rays(gpu):
     assert cnt["n_any"] > 0
     assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
     assert (cam_g.img_ == img).all()
+
+
+def test_dynamic_camera_progressive_and_restart(gpu, cornell_pair):
+    """DynamicCamera (camera.cpp:130-255): non-blocking progressive render; the finished frame equals the
+    oracle's; a render() issued while a frame is in flight abandons it and the new frame is complete and exact."""
+    data, sc, osc = cornell_pair
+    dyn = gpu.DynamicCamera(96, 64, data.camera, 3, 2, 4, samplesPerPass=2)
+    try:
+        dyn.render(sc)
+        assert dyn.wait(120) and dyn.finished() and dyn.currentSample_ == 6
+        acc, img, _ = osc.render(data.camera_desc(96, 64, 3, 2, 4), count=False)
+        assert_same_f32(dyn.acc_, acc, "dynamic camera accumulation")
+        assert (dyn.img_ == img).all()
+        moved = dict(data.camera); moved["center"] = (250.0, 300.0, -760.0)
+        dyn.render(sc)                      # frame in flight ...
+        dyn.properties_ = moved
+        dyn.render(sc)                      # ... abandoned for the moved camera
+        assert dyn.wait(120) and dyn.finished()
+        ref = gpu.StaticCamera(96, 64, moved, 3, 2, 4)
+        ref.render(sc)
+        assert_same_f32(dyn.acc_, ref.acc_, "restarted frame")
+        assert (dyn.img_ == ref.img_).all()
+        dyn.resize(48, 32)
+        dyn.render(sc)
+        assert dyn.wait(120) and dyn.img_.shape == (32, 48, 3) and dyn.img_.any()
+    finally:
+        dyn.stopRender()
