@@ -137,10 +137,17 @@ def main():
     integrator = scene.info()["auto_integrator"]
     INTEG_NAMES = {1: "pixel-persistent", 2: "hbm-wavefront", 3: "wave-pool", 4: "pixel-persistent-fused"}
 
+    # per-frame exchange: compact own-pixel slabs gathered to rank 0 (default) or one sum-reduce of the full buffers
+    collective = os.environ.get("JTX_FRAME_COLLECTIVE", "gather")
+    gatherer = jtx.distributed.FrameGather(W, H, rank, world, dev) if (world > 1 and collective == "gather") else None
+
     def step(count=False, profile=False):
         jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count,
                                      integrator=integrator, profile_kernels=profile)
-        jtx.distributed.reduce_frame(acc, img, dst=0)
+        if gatherer is not None:
+            gatherer.collect(acc, img)
+        else:
+            jtx.distributed.reduce_frame(acc, img, dst=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -223,7 +230,7 @@ def main():
             "config": {"workload": args.workload, "scene_triangles": data.num_triangles, "width": W, "height": H,
                        "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
-                       "parallelism": f"pixel-tile shard x{world} + 1 reduce/frame" if world > 1 else "1 gpu",
+                       "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" if world > 1 else "1 gpu",
                        "scene_upload_ms": round(t_upload * 1e3, 2),
                        "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": scene.info()["lds_resident"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",

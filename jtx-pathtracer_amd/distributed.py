@@ -5,9 +5,13 @@ Every pixel-sample is an independent path whose RNG depends only on (row, col, s
 communication (camera.cpp:55-64).  Rank r owns the row-major 32x32 tiles k with k % world == r
 (interleaved, so sky-heavy and geometry-heavy regions spread over all GPUs) and accumulates ALL
 strata of its own pixels in the reference's sample order; the per-pixel float sums are therefore
-bit-identical to the 1-GPU result.  The scene is replicated.  The only collective is one reduce
-(sum) per frame of the accumulation buffer -- and of the RGB8 image -- in which non-owned pixels
-are exactly zero.
+bit-identical to the 1-GPU result.  The scene is replicated.  The only collective is one exchange per
+frame that brings the disjoint shards to rank 0, in one of two forms:
+  * FrameGather (default): every rank packs its OWN pixels (12 B accumulation + 3 B RGB8 each) into a
+    compact slab and one gather delivers the slabs to rank 0 -- xGMI is point-to-point, so the 7 slabs of an
+    8-GPU node travel on 7 different links at once and each link carries 1/8 of the frame;
+  * reduce_frame: one sum-reduce of the full-size buffers in which non-owned pixels are exactly zero
+    (a ring: every link carries ~7/8 of the frame).
 """
 import ctypes as C
 
@@ -58,3 +62,62 @@ def reduce_frame(acc, img=None, dst=0, group=None):
     dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
     if img is not None:
         dist.reduce(img, dst=dst, op=dist.ReduceOp.SUM, group=group)
+
+
+class FrameGather:
+    """Per-frame exchange by compact slabs: pack own pixels -> gather to `dst` -> scatter into the frame.
+
+    Built once per (width, height, world); `collect(acc, img)` is called after render_shard on the same
+    stream.  acc: H*W*3 float32, img: H*W*3 uint8 device (or CPU/gloo) tensors; on `dst` they hold the
+    whole frame afterwards, bit for bit what one rank renders alone.
+    """
+
+    def __init__(self, width, height, rank, world, device, dst=0, group=None):
+        import torch
+        self.rank, self.world, self.dst, self.group = rank, world, dst, group
+        self.npix = width * height
+        idx = [np.flatnonzero(tile_owner_mask(width, height, r, world).reshape(-1)) for r in range(world)]
+        self.count = [len(i) for i in idx]
+        self.nmax = max(1, max(self.count))
+        pad = lambda a: np.concatenate([a, np.full(self.nmax - len(a), a[-1] if len(a) else 0, np.int64)])
+        self.own = torch.from_numpy(pad(idx[rank]).astype(np.int64)).to(device)
+        self.slab = torch.zeros((self.nmax, 15), dtype=torch.uint8, device=device)
+        if rank == dst:
+            # padded entries repeat the rank's last own pixel (same bytes written twice); a rank without
+            # pixels is dropped from the scatter altogether
+            keep = [r for r in range(world) if self.count[r] > 0]
+            self.keep = torch.tensor(keep, dtype=torch.int64, device=device)
+            self.all_idx = torch.from_numpy(np.concatenate([pad(idx[r]) for r in keep]).astype(np.int64)).to(device) \
+                if keep else None
+            self.recv = torch.zeros((world, self.nmax, 15), dtype=torch.uint8, device=device)
+
+    def pack(self, acc, img):
+        """own pixels of (acc, img) -> self.slab [nmax, 15] uint8"""
+        import torch
+        a8 = acc.view(torch.uint8).view(self.npix, 12)
+        i8 = img.view(self.npix, 3)
+        self.slab[:, :12].copy_(a8.index_select(0, self.own))
+        self.slab[:, 12:].copy_(i8.index_select(0, self.own))
+        return self.slab
+
+    def scatter(self, acc, img):
+        """(dst only) self.recv [world, nmax, 15] -> the frame buffers"""
+        import torch
+        if self.all_idx is None:
+            return
+        a8 = acc.view(torch.uint8).view(self.npix, 12)
+        i8 = img.view(self.npix, 3)
+        got = self.recv.index_select(0, self.keep).view(-1, 15)
+        a8.index_copy_(0, self.all_idx, got[:, :12].contiguous())
+        i8.index_copy_(0, self.all_idx, got[:, 12:].contiguous())
+
+    def collect(self, acc, img):
+        import torch.distributed as dist
+        if self.world == 1 or not dist.is_initialized():
+            return
+        self.pack(acc, img)
+        if self.rank == self.dst:
+            dist.gather(self.slab, list(self.recv.unbind(0)), dst=self.dst, group=self.group)
+            self.scatter(acc, img)
+        else:
+            dist.gather(self.slab, None, dst=self.dst, group=self.group)

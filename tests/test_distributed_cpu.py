@@ -30,7 +30,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, w, h, out_dir):
+def _worker(rank, world, port, w, h, out_dir, mode="reduce"):
     import oracle_lib as ol
     import jtx_pathtracer_amd as jtx
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,7 +45,15 @@ def _worker(rank, world, port, w, h, out_dir):
             {(r // 32, c // 32) for r, c in zip(*np.nonzero(mask))})
         my_acc = torch.from_numpy(np.where(mask[..., None], acc, 0).astype(np.float32)).reshape(-1).clone()
         my_img = torch.from_numpy(np.where(mask[..., None], img, 0).astype(np.uint8)).reshape(-1).clone()
-        jtx.distributed.reduce_frame(my_acc, my_img, dst=0)
+        if mode == "reduce":
+            jtx.distributed.reduce_frame(my_acc, my_img, dst=0)
+        else:
+            # what is outside the own tiles must not matter to the gather: poison it
+            my_acc[torch.from_numpy(~np.repeat(mask.reshape(-1), 3))] = float("nan")
+            my_img[torch.from_numpy(~np.repeat(mask.reshape(-1), 3))] = 77
+            fg = jtx.distributed.FrameGather(w, h, rank, world, torch.device("cpu"))
+            fg.collect(my_acc, my_img)
+            fg.collect(my_acc, my_img)          # idempotent on the root, frame after frame
         if rank == 0:
             ok = np.array_equal(my_acc.numpy().view(np.uint32), acc.reshape(-1).view(np.uint32)) and \
                 np.array_equal(my_img.numpy(), img.reshape(-1))
@@ -59,6 +67,15 @@ def _worker(rank, world, port, w, h, out_dir):
 def test_tile_shard_reduce_gloo(world, w, h, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, w, h, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "result").read() == "ok"
+
+
+@pytest.mark.parametrize("world,w,h", [(2, 100, 70), (3, 65, 33), (3, 40, 20)])
+def test_tile_shard_gather_gloo(world, w, h, tmp_path):
+    """FrameGather (the default per-frame exchange): compact own-pixel slabs gathered to rank 0; (3, 40, 20) has
+    only two tiles, so one rank owns nothing."""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, w, h, str(tmp_path), "gather"), nprocs=world, join=True)
     assert open(tmp_path / "result").read() == "ok"
 
 

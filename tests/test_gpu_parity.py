@@ -496,3 +496,31 @@ def test_dynamic_camera_progressive_and_restart(gpu, cornell_pair):
         assert dyn.wait(120) and dyn.img_.shape == (32, 48, 3) and dyn.img_.any()
     finally:
         dyn.stopRender()
+
+
+def test_frame_gather_pack_scatter_on_device(gpu, cornell_pair):
+    """FrameGather's device side (the RCCL gather itself needs > 1 GPU): 5 shards rendered one after the other on
+    this GPU, packed to compact slabs, handed to rank 0's receive buffer and scattered -> the 1-GPU frame."""
+    import torch
+    data, sc, osc = cornell_pair
+    W, H, world = 250, 130, 5
+    cam = data.camera_desc(W, H, 2, 2, 4)
+    dev = torch.device("cuda", 0)
+    full_acc, full_img, _ = _frame_on_device(gpu, sc, cam, 1)
+    root = gpu.distributed.FrameGather(W, H, 0, world, dev)
+    acc0 = img0 = None
+    st = torch.cuda.Stream()            # a non-default stream: 0 would mean "the library's own stream"
+    with torch.cuda.stream(st):
+        for r in range(world):
+            acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+            img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+            gpu.distributed.render_shard(sc, cam, r, world, acc, img, stream=st.cuda_stream, integrator=1)
+            fg = root if r == 0 else gpu.distributed.FrameGather(W, H, r, world, dev)
+            root.recv[r].copy_(fg.pack(acc, img))
+            if r == 0:
+                acc0, img0 = acc, img
+        acc0 += 1.0                     # whatever rank 0 holds outside ... and inside its tiles is overwritten
+        root.scatter(acc0, img0)
+    torch.cuda.synchronize()
+    assert_same_f32(acc0.cpu().numpy().reshape(H, W, 3), full_acc, "gathered frame")
+    assert (img0.cpu().numpy().reshape(H, W, 3) == full_img).all()

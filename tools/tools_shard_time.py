@@ -22,3 +22,11 @@ for world in (1, 2, 4, 8):
     wall = (time.perf_counter() - t0) / 5 * 1e3
     lib.jtx_mi_kernel_time(sc.handle, C.byref(ms), C.byref(n))
     print(f"world {world}: rank-0 shard {ms.value / n.value:7.3f} ms GPU, {wall:7.3f} ms wall/step")
+# device-side cost of the per-frame exchange (FrameGather pack on every rank, scatter on rank 0), 8-rank geometry
+fg = jtx.distributed.FrameGather(W, H, 0, 8, dev)
+for name, fn in (("pack", lambda: fg.pack(acc, img)), ("scatter", lambda: fg.scatter(acc, img))):
+    for rep in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for rep in range(20): fn()
+    torch.cuda.synchronize()
+    print(f"FrameGather.{name} (world 8, 1080p): {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms")
