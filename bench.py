@@ -155,8 +155,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # counted pass: deterministic ray / node / triangle tallies of this rank's shard (untimed)
-    step(count=True)
+    # counted pass: deterministic ray / node / triangle tallies of this rank's shard (untimed).  It is also the first
+    # use of the exchange: if the slab gather is refused by this RCCL build, every rank falls back to the reduce.
+    try:
+        step(count=True)
+        ok = 1
+    except RuntimeError as e:
+        if gatherer is None:
+            raise
+        sys.stderr.write(f"[bench rank {rank}] FrameGather failed ({e}); falling back to reduce\n")
+        ok = 0
+    if gatherer is not None:
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            gatherer, collective = None, "reduce"
+            step(count=True)
     fence()
     cnt = jtx._capi.Counters()
     jtx._capi.check(lib.jtx_mi_get_counters(scene.handle, C.byref(cnt)))

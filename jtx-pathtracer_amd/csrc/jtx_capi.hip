@@ -112,6 +112,7 @@ constexpr int kMaxWideDepth = 11;          // 11 x 8 B x 256 lanes = 22 KB of LD
 struct WideBuilder {
     const std::vector<jtx_mi_bvh_node> &nodes;
     std::vector<uint4> &out;
+    std::vector<int> leaves;           // leaf count of every binary subtree
     int depth = 0;
     bool ok = true;
 
@@ -132,24 +133,57 @@ struct WideBuilder {
         out[at + 1] = make_uint4(fb(n.pmin[2]), fb(n.pmax[2]), (uint32_t) n.offset, (uint32_t) n.num_prims);
     }
 
+    static double area(const jtx_mi_bvh_node &n) {
+        const double dx = (double) n.pmax[0] - n.pmin[0], dy = (double) n.pmax[1] - n.pmin[1], dz = (double) n.pmax[2] - n.pmin[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
     void fill(int b, size_t at, int level) {
         if (!ok) return;
         if (level + 1 > depth) depth = level + 1;
         const jtx_mi_bvh_node &nb = nodes[b];
-        int child[8]; for (int &c : child) c = -1;
-        int a0 = nb.axis, a1[2] = {-1, -1}, a2[4] = {-1, -1, -1, -1};
-        const int c1[2] = {b + 1, nb.offset};
-        for (int i = 0; i < 2; ++i) {
-            if (leaf(c1[i])) { child[i << 2] = c1[i]; continue; }
-            a1[i] = nodes[c1[i]].axis;
-            const int c2[2] = {c1[i] + 1, nodes[c1[i]].offset};
-            for (int j = 0; j < 2; ++j) {
-                if (leaf(c2[j])) { child[(i << 2) | (j << 1)] = c2[j]; continue; }
-                a2[2 * i + j] = nodes[c2[j]].axis;
-                child[(i << 2) | (j << 1)] = c2[j] + 1;
-                child[(i << 2) | (j << 1) | 1] = nodes[c2[j]].offset;
+        // treelet: open the binary subtree below b, always at the child with the largest box, until 8 children stand
+        struct TNode { int node, left, right; };           // left/right: treelet indices, -1 = a child of the wide node
+        TNode t[15]; int nt = 0;
+        auto add = [&](int node) { t[nt] = {node, -1, -1}; return nt++; };
+        add(b);
+        t[0].left = add(b + 1); t[0].right = add(nb.offset);
+        int nchild = 2;
+        // 1. swallow whole subtrees that fit into the free slots, smallest first (a subtree of m leaves costs m - 1
+        //    slots and saves a wide node that would test only m boxes); 2. otherwise open the child with the largest box
+        while (nchild < 8) {
+            int best = -1, bestLeaves = 1 << 30;
+            for (int i = 1; i < nt; ++i)
+                if (t[i].left < 0 && !leaf(t[i].node) && leaves[t[i].node] - 1 <= 8 - nchild && leaves[t[i].node] < bestLeaves) {
+                    best = i; bestLeaves = leaves[t[i].node];
+                }
+            if (best >= 0) {
+                int st[16], sp = 0; st[sp++] = best;
+                while (sp) {
+                    const int i = st[--sp];
+                    if (leaf(t[i].node)) continue;
+                    const int l = add(t[i].node + 1), r = add(nodes[t[i].node].offset);
+                    t[i].left = l; t[i].right = r; ++nchild;
+                    st[sp++] = r; st[sp++] = l;
+                }
+                continue;
             }
+            double bestArea = -1.0;
+            for (int i = 1; i < nt; ++i)
+                if (t[i].left < 0 && !leaf(t[i].node) && area(nodes[t[i].node]) > bestArea) { best = i; bestArea = area(nodes[t[i].node]); }
+            if (best < 0) break;
+            const int l = add(t[best].node + 1), r = add(nodes[t[best].node].offset);
+            t[best].left = l; t[best].right = r;
+            ++nchild;
         }
+        // children left to right; slots: wide (interior) children first, then leaf records, each in that order
+        int order[8], n = 0;
+        { int st[16], sp = 0; st[sp++] = 0;
+          while (sp) { const int i = st[--sp]; if (t[i].left < 0) order[n++] = i; else { st[sp++] = t[i].right; st[sp++] = t[i].left; } } }
+        int slotOf[15]; for (int &v : slotOf) v = -1;
+        int child[8], ni = 0, nl = 0;
+        for (int k = 0; k < n; ++k) if (!leaf(t[order[k]].node)) { slotOf[order[k]] = ni; child[ni++] = t[order[k]].node; }
+        for (int k = 0; k < n; ++k) if (leaf(t[order[k]].node)) { slotOf[order[k]] = ni + nl; child[ni + nl] = t[order[k]].node; ++nl; }
         if (!finite3(nb.pmin) || !finite3(nb.pmax)) { ok = false; return; }
         // grid: origin = the node's min corner, cell = 2^e per axis with origin + 255 * 2^e >= max corner (exactly)
         uint32_t ebyte[3]; float cell[3];
@@ -161,12 +195,9 @@ struct WideBuilder {
             if (e > kWideMaxExp || std::fabs(nb.pmin[k]) > 1099511627776.0f || std::fabs(nb.pmax[k]) > 1099511627776.0f) { ok = false; return; }
             ebyte[k] = (uint32_t) (e + 127); cell[k] = std::ldexp(1.0f, e);
         }
-        uint32_t imask = 0, lmask = 0;
         uint8_t qlo[3][8] = {}, qhi[3][8] = {};
-        for (int s = 0; s < 8; ++s) {
-            if (child[s] < 0) continue;
+        for (int s = 0; s < ni + nl; ++s) {
             const jtx_mi_bvh_node &c = nodes[child[s]];
-            (leaf(child[s]) ? lmask : imask) |= 1u << s;
             for (int k = 0; k < 3; ++k) {
                 if (!(c.pmin[k] >= nb.pmin[k] && c.pmax[k] <= nb.pmax[k] && c.pmin[k] <= c.pmax[k])) { ok = false; return; }   // nesting is the premise
                 const float p = nb.pmin[k], sc = cell[k];
@@ -184,33 +215,41 @@ struct WideBuilder {
                 qhi[k][s] = (uint8_t) q;
             }
         }
-        // visiting order: which collapsed binary nodes go to their second child first, per octant
-        uint32_t order[2] = {0, 0};
+        // visiting order per octant: the reference's near-first rule (scene.cpp:40-46) applied inside the treelet
+        uint32_t perm[8];
         for (int o = 0; o < 8; ++o) {
-            auto neg = [&](int axis) { return axis >= 0 ? (uint32_t) ((o >> axis) & 1) : 0u; };
-            const uint32_t B = neg(a2[0]) | neg(a1[0]) << 1 | neg(a2[1]) << 2 | neg(a0) << 3 | neg(a2[2]) << 4 | neg(a1[1]) << 5 | neg(a2[3]) << 6;
-            order[o >> 2] |= B << (8 * (o & 3));
+            uint32_t pm = 0; int cnt = 0;
+            int st[16], sp = 0; st[sp++] = 0;
+            while (sp) {
+                const int i = st[--sp];
+                if (t[i].left < 0) { pm |= (uint32_t) slotOf[i] << (3 * cnt++); continue; }
+                const bool neg = (o >> nodes[t[i].node].axis) & 1;
+                st[sp++] = neg ? t[i].left : t[i].right;             // far child: after the near subtree
+                st[sp++] = neg ? t[i].right : t[i].left;
+            }
+            perm[o] = pm;
         }
-        const int ni = __builtin_popcount(imask), nl = __builtin_popcount(lmask);
         const size_t base = out.size();
-        out.resize(base + 5 * (size_t) ni + 2 * (size_t) nl);
-        if (base + 5 * (size_t) ni + 2 * (size_t) nl > 0xffffffffull) { ok = false; return; }
+        if (base + 6 * (size_t) ni + 2 * (size_t) nl >= (1ull << 28)) { ok = false; return; }
+        out.resize(base + 6 * (size_t) ni + 2 * (size_t) nl);
         auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
         auto pack = [](const uint8_t *q) { return (uint32_t) q[0] | (uint32_t) q[1] << 8 | (uint32_t) q[2] << 16 | (uint32_t) q[3] << 24; };
-        out[at + 0] = make_uint4(fb(nb.pmin[0]), fb(nb.pmin[1]), fb(nb.pmin[2]), ebyte[0] | ebyte[1] << 8 | ebyte[2] << 16);
-        out[at + 1] = make_uint4((uint32_t) base, imask | lmask << 8, order[0], order[1]);
-        out[at + 2] = make_uint4(pack(qlo[0]), pack(qlo[0] + 4), pack(qlo[1]), pack(qlo[1] + 4));
-        out[at + 3] = make_uint4(pack(qlo[2]), pack(qlo[2] + 4), pack(qhi[0]), pack(qhi[0] + 4));
-        out[at + 4] = make_uint4(pack(qhi[1]), pack(qhi[1] + 4), pack(qhi[2]), pack(qhi[2] + 4));
-        int ri = 0, rl = 0;
-        for (int s = 0; s < 8; ++s) {
-            if (child[s] < 0) continue;
-            if (leaf(child[s])) writeLeaf(base + 5 * (size_t) ni + 2 * (size_t) rl++, child[s]);
-            else ++ri;
+        // 24-bit orders of the 8 octants, packed back to back into 6 words
+        uint32_t pw[6] = {0, 0, 0, 0, 0, 0};
+        for (int o = 0; o < 8; ++o) {
+            const int bit = 24 * o, w = bit >> 5, sh = bit & 31;
+            pw[w] |= perm[o] << sh;
+            if (sh > 8) pw[w + 1] |= perm[o] >> (32 - sh);
         }
-        ri = 0;
-        for (int s = 0; s < 8; ++s)
-            if (child[s] >= 0 && !leaf(child[s])) fill(child[s], base + 5 * (size_t) ri++, level + 1);
+        out[at + 0] = make_uint4(fb(nb.pmin[0]), fb(nb.pmin[1]), fb(nb.pmin[2]),
+                                 ebyte[0] | ebyte[1] << 8 | ebyte[2] << 16 | (uint32_t) ni << 24 | (uint32_t) (ni + nl) << 28);
+        out[at + 1] = make_uint4(pack(qlo[0]), pack(qlo[0] + 4), pack(qlo[1]), pack(qlo[1] + 4));
+        out[at + 2] = make_uint4(pack(qlo[2]), pack(qlo[2] + 4), pack(qhi[0]), pack(qhi[0] + 4));
+        out[at + 3] = make_uint4(pack(qhi[1]), pack(qhi[1] + 4), pack(qhi[2]), pack(qhi[2] + 4));
+        out[at + 4] = make_uint4((uint32_t) base, pw[0], pw[1], pw[2]);
+        out[at + 5] = make_uint4(pw[3], pw[4], pw[5], 0u);
+        for (int s = ni; s < ni + nl; ++s) writeLeaf(base + 6 * (size_t) ni + 2 * (size_t) (s - ni), child[s]);
+        for (int s = 0; s < ni; ++s) fill(child[s], base + 6 * (size_t) s, level + 1);
     }
 };
 
@@ -218,7 +257,13 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
     out.clear(); depth = 0;
     if (nodes.size() < 2 || nodes[0].num_prims != 0) return false;      // a single leaf: nothing to collapse
     WideBuilder wb{nodes, out};
-    out.resize(5);
+    wb.leaves.assign(nodes.size(), 1);
+    for (size_t i = nodes.size(); i-- > 0;)
+        if (nodes[i].num_prims == 0) {
+            if ((size_t) nodes[i].offset >= nodes.size() || i + 1 >= nodes.size()) return false;
+            wb.leaves[i] = wb.leaves[i + 1] + wb.leaves[nodes[i].offset];
+        }
+    out.resize(6);
     wb.fill(0, 0, 0);
     depth = wb.depth;
     return wb.ok;
@@ -716,6 +761,13 @@ int jtx_mi_debug_util(jtx_mi_scene *s, unsigned long long *out3) {     // diagno
     if (!s || !s->counters.p) return 1;
     (void) hipDeviceSynchronize();
     return hipMemcpy(out3, s->counters.p + 20, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+#ifdef JTX_PROFILE_WIDE
+int jtx_mi_debug_wide(jtx_mi_scene *s, unsigned long long *out8) {     // diagnostic builds only
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out8, s->counters.p + 24, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
 #ifdef JTX_PROFILE_PHASES

@@ -207,6 +207,18 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         }
     }
     if (COUNT) waveAddCounters(p.counters, cnt);
+#ifdef JTX_PROFILE_WIDE
+    if (SRC == SRC_WIDE && p.counters) {   // diagnostic build: lane sums of the steps, lane 0's view of the wave iterations
+        const unsigned v[8] = {cnt.w_calls, cnt.w_node_iters, cnt.w_node_steps, cnt.w_leaf_iters, cnt.w_leaf_steps, cnt.w_tris, cnt.w_pops, cnt.w_fetch};
+        for (int i = 0; i < 8; ++i) {
+            const bool perWave = (i == 0 || i == 1 || i == 3);
+            unsigned long long sv = v[i];
+            if (perWave) { for (int off = 32; off > 0; off >>= 1) { unsigned long long o2 = __shfl_down(sv, off, 64); sv = sv > o2 ? sv : o2; } }
+            else for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
+            if ((threadIdx.x & 63) == 0 && sv) atomicAdd(&p.counters[24 + i], sv);
+        }
+    }
+#endif
 #ifdef JTX_PROFILE_UTIL
     if (COUNT) {
         // every lane of a wave sits through the same traversal-loop iterations, but lanes that left the

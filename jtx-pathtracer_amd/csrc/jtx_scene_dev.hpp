@@ -41,11 +41,19 @@ struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode
 #ifdef JTX_PROFILE_UTIL
     unsigned it_interior, it_leaf, it_calls;   // diagnostic: loop iterations this lane sat through (= wave iterations)
 #endif
+#ifdef JTX_PROFILE_WIDE
+    unsigned w_calls, w_node_iters, w_node_steps, w_leaf_iters, w_leaf_steps, w_tris, w_pops, w_fetch;   // diagnostic: wide traversal
+#endif
 };
 #ifdef JTX_PROFILE_UTIL
 #define UTIL(x) x
 #else
 #define UTIL(x)
+#endif
+#ifdef JTX_PROFILE_WIDE
+#define WSTAT(x) x
+#else
+#define WSTAT(x)
 #endif
 
 enum { SRC_GLOBAL = 0, SRC_LDS = 1, SRC_WIDE = 2 };
@@ -205,18 +213,19 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 // leaf's box against the current interval; if it passes, test its triangles.  Any structure that walks
 // the leaves in that order and only skips leaves whose box test would fail gives bit-identical hits.
 // The uncounted kernels use that freedom (the counted ones keep the reference's node visits):
-//   wide node (80 B = 5 x 16 B): the <= 8 descendants three binary levels below a node, slot = path
-//     bits (b2 b1 b0; 0 = first child i+1, 1 = second child), each with a box quantised OUTWARD to
-//     8 bits per plane on the node's own grid (plane = fma(q, 2^e, origin), checked on the host with
-//     the same fma), so a slab test on it can only pass more often than on the exact box.
-//       [origin.xyz | ex ey ez] [children base | imask lmask | order bytes oct 0-3 | oct 4-7]
-//       [lo.x x8 | lo.y x8] [lo.z x8 | hi.x x8] [hi.y x8 | hi.z x8]
-//     children block (16-B granules): interior children (5 granules each, slot order), then leaf
-//     records (2 granules each, slot order).  order byte of an octant: which of the 7 collapsed
-//     binary nodes visit their second child first (bits 0,2,4,6: level 3; 1,5: level 2; 3: level 1).
+//   wide node (96 B = 6 x 16 B): a treelet of the binary tree below a node, opened at the child with the
+//     largest box until 8 children stand; slots = its wide (interior) children first, then its leaves, each
+//     left to right; every child box quantised OUTWARD to 8 bits per plane on the node's own grid
+//     (plane = origin + q 2^e, checked in exact arithmetic on the host), so a slab test on it can only
+//     pass more often than on any exact box inside it.
+//       [origin.xyz | ex ey ez, #interior, #children] [lo.x x8 | lo.y x8] [lo.z x8 | hi.x x8] [hi.y x8 | hi.z x8]
+//       [children base | 8 visiting orders x 24 bit ...] [... | 0]
+//     children block (16-B granules): interior children (6 granules each), then leaf records (2 each).
+//     visiting order of an octant: the slots in the order the reference's near-first rule (dirIsNeg[axis],
+//     scene.cpp:40-46) walks the treelet, 3 bits per position.
 //   leaf record (32 B): the exact leaf box + primitivesOffset + numPrimitives, tested with slabRegular.
-// The per-lane stack holds one 64-bit entry per wide level {children base, imask, lmask, pending hits in
-// visiting order, order byte} in LDS.  A stale hit bit (t.max shrank since the node was tested) only
+// The per-lane stack holds one 64-bit entry per wide level {children base, #interior, visiting order,
+// pending positions} in LDS.  A stale hit bit (t.max shrank since the node was tested) only
 // costs a visit.  Irregular rays (a zero / non-finite direction component ...) take the exact binary path.
 #ifndef JTX_WIDE_LEAF_VOTE
 #define JTX_WIDE_LEAF_VOTE 4
@@ -235,37 +244,32 @@ JD float ubyteToFloat(unsigned v, int k) { return (float) ((v >> (8 * k)) & 0xff
 
 struct WideRay { f3 o, d, inv; float tmin, tmax; int negmask; };
 struct WideState {
-    unsigned gbase, gbits;       // current group: children base | imask, lmask, pending hits (visiting order), order byte
+    unsigned gbase, gbits;       // current group: children base (28 bits) | interior children (4) ; order list (24) | pending (8)
     int sp, pendLeaf;            // stack entries in use; granule of the leaf record the lane is parked on (-1: none)
     bool done, hitAnything;
-    // group = the children of one wide node still to visit; the start group is "the root"
-    JD void start() { gbase = 0u; gbits = 0x00010001u; sp = 0; pendLeaf = -1; done = false; hitAnything = false; }
+    // group = the children of one wide node still to visit; the start group is "the root": one interior child at granule 0
+    JD void start() { gbase = 1u << 28; gbits = 1u; sp = 0; pendLeaf = -1; done = false; hitAnything = false; }
     JD bool walking() const { return pendLeaf < 0 && !done; }
 };
 
 // One interior step of a walking lane: take the next child of the current group (popping the stack when the
 // group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
 JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws) {
-    if ((ws.gbits & 0x00ff0000u) == 0u) {                    // group exhausted: pop
+    if ((ws.gbits & 0xffu) == 0u) {                          // group exhausted: pop
         if (ws.sp == 0) { ws.done = true; return; }
         --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
     }
-    const unsigned pending = (ws.gbits >> 16) & 0xffu;
-    const int k = __builtin_ctz(pending);
-    ws.gbits &= ~(0x10000u << k);
-    const unsigned B = ws.gbits >> 24;
-    const unsigned b2 = ((unsigned) k >> 2) ^ ((B >> 3) & 1u);
-    const unsigned b1 = (((unsigned) k >> 1) & 1u) ^ ((B >> (1u + 4u * b2)) & 1u);
-    const unsigned b0 = ((unsigned) k & 1u) ^ ((B >> (4u * b2 + 2u * b1)) & 1u);
-    const unsigned bit = 1u << (4u * b2 + 2u * b1 + b0), below = bit - 1u;
-    const unsigned imask = ws.gbits & 0xffu, lmask = (ws.gbits >> 8) & 0xffu;
-    if (!(imask & bit)) {
-        ws.pendLeaf = (int) (ws.gbase + 5u * (unsigned) __popc(imask) + 2u * (unsigned) __popc(lmask & below));
-        return;
-    }
-    const unsigned a = ws.gbase + 5u * (unsigned) __popc(imask & below);
-    if (ws.gbits & 0x00ff0000u) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
-    const uint4 n0 = wide[a], n1 = wide[a + 1], n2 = wide[a + 2], n3 = wide[a + 3], n4 = wide[a + 4];
+    const int k = __builtin_ctz(ws.gbits & 0xffu);           // next position in visiting order
+    ws.gbits &= ~(1u << k);
+    const unsigned slot = (ws.gbits >> (8 + 3 * k)) & 7u;
+    const unsigned ni = ws.gbase >> 28, base = ws.gbase & 0x0fffffffu;
+    if (slot >= ni) { ws.pendLeaf = (int) (base + 6u * ni + 2u * (slot - ni)); return; }
+    const unsigned a = base + 6u * slot;
+    if (ws.gbits & 0xffu) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
+    const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
+    const unsigned *tail = (const unsigned *) (wide + a + 4);   // [children base][8 x 24-bit visiting orders][0]
+    const int pbit = 24 * r.negmask;
+    const unsigned cbase = tail[0], plo = tail[1 + (pbit >> 5)], phi = tail[2 + (pbit >> 5)];
     const f3 o = r.o, inv = r.inv;
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     // per axis: t(q) = q * a + b with a = cell / d (exact: a power-of-two scaling), b = (origin - o) / d,
@@ -291,15 +295,15 @@ JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, con
                                fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), r.tmax));
         hits |= (t0 <= t1 ? 1u : 0u) << s;
     }
-    hits &= (n1.y | (n1.y >> 8)) & 0xffu;
-    // slot space -> visiting order of this ray's octant
-    const unsigned ob = ((r.negmask & 4 ? n1.w : n1.z) >> ((r.negmask & 3) * 8)) & 0xffu;
-    const unsigned e2 = ob & 0x55u, e1 = ((ob >> 1) & 0x11u) * 3u, e0 = (ob & 8u) ? 0x0fu : 0u;
-    unsigned t = ((hits >> 1) ^ hits) & e2; hits ^= t | (t << 1);
-    t = ((hits >> 2) ^ hits) & e1; hits ^= t | (t << 2);
-    t = ((hits >> 4) ^ hits) & e0; hits ^= t | (t << 4);
-    ws.gbase = n1.x;
-    ws.gbits = (n1.y & 0xffffu) | (hits << 16) | (ob << 24);
+    // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first)
+    const unsigned perm = __funnelshift_r(plo, phi, pbit & 31) & 0x00ffffffu;
+    const unsigned nchild = n0.w >> 28;
+    unsigned pend = 0u;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) pend |= ((hits >> ((perm >> (3 * k2)) & 7u)) & 1u) << k2;
+    pend &= (1u << nchild) - 1u;
+    ws.gbase = cbase | (((n0.w >> 24) & 0xfu) << 28);
+    ws.gbits = pend | (perm << 8);
 }
 
 // The leaf a lane is parked on: AABB::hit on the exact box, then the leaf's triangles (mesh.hpp:106-192)
@@ -326,20 +330,28 @@ JD void wideLeafStep(const uint4 *__restrict__ wide, const Src &src, bool any, W
 
 template <bool ANY, class Src>
 JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk, int stride, f3 o, f3 d, f3 inv,
-                     int negmask, float tmin, float tmax, HitRec &rec) {
+                     int negmask, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     WideRay r; r.o = o; r.d = d; r.inv = inv; r.tmin = tmin; r.tmax = tmax; r.negmask = negmask;
     WideState ws; ws.start();
+    WSTAT(cnt.w_calls++;)
     while (true) {
         while (true) {
 #pragma unroll
-            for (int rep = 0; rep < JTX_WIDE_STEPS; ++rep)
-                if (ws.walking()) wideNodeStep(wide, stk, stride, r, ws);
+            for (int rep = 0; rep < JTX_WIDE_STEPS; ++rep) {
+                WSTAT(cnt.w_node_iters++;)
+                if (ws.walking()) {
+                    WSTAT(cnt.w_node_steps++; const int leafBefore = ws.pendLeaf; const bool doneBefore = ws.done;)
+                    wideNodeStep(wide, stk, stride, r, ws);
+                    WSTAT(if (ws.pendLeaf < 0 && !ws.done) cnt.w_fetch++; (void) leafBefore; (void) doneBefore;)
+                }
+            }
             const unsigned long long walking = __ballot(ws.walking());
             const unsigned long long parked = __ballot(ws.pendLeaf >= 0);
             if (walking == 0ull || __popcll(parked) >= JTX_WIDE_LEAF_VOTE) break;
         }
         if (__ballot(ws.pendLeaf >= 0) == 0ull) break;          // wave-uniform: every lane is done
-        if (ws.pendLeaf >= 0) wideLeafStep(wide, src, ANY, r, ws, rec);
+        WSTAT(cnt.w_leaf_iters++;)
+        if (ws.pendLeaf >= 0) { WSTAT(cnt.w_leaf_steps++;) wideLeafStep(wide, src, ANY, r, ws, rec); }
     }
     return ws.hitAnything;
 }
@@ -376,7 +388,7 @@ JD bool traverseNoStack(const WideSrc &src, int num_nodes, f3 o, f3 d, float tmi
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
     if (__builtin_expect(__ballot(!wideRayOk(o, inv, tmin, tmax)) == 0ull, 1))
-        return traverseWide<ANY>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec);
+        return traverseWide<ANY>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
     return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
 }
 

@@ -1,0 +1,21 @@
+# diagnostic: lane utilisation of the wide (8-ary) traversal of integrator 1 (build with -DJTX_PROFILE_WIDE)
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import jtx_pathtracer_amd as jtx
+lib = jtx._capi.load()
+which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
+data = jtx.scenes.atrium() if which == "atrium" else jtx.scenes.mixed()
+sc = jtx.Scene(data); sc.buildBVH()
+W, H, xs, ys = 960, 540, 4, 4
+cam = jtx.StaticCamera(W, H, data.camera, xs, ys, 8)
+cam.render(sc, count_rays=True, integrator=1)        # allocates + zeroes the counter block; binary records
+c = cam.counters
+cam.render(sc, count_rays=False, integrator=1)       # wide nodes; the diagnostic counters accumulate
+f = lib.jtx_mi_debug_wide; f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+o = (C.c_uint64 * 8)(); assert f(sc.handle, o) == 0
+calls, nit, nst, lit, lst, tris, pops, fetch = [int(x) for x in o]
+rays = c["n_closest"] + c["n_any"]
+print(f"rays {rays}, wave traverse calls {calls} -> ray slots used {rays / (64.0 * calls):.3f}")
+print(f"node phase: {nit / calls:.1f} wave iterations/call, lane steps/ray {nst / rays:.2f} (fetches {fetch / rays:.2f}), utilisation {nst / (64.0 * nit):.3f}")
+print(f"leaf phase: {lit / calls:.1f} wave iterations/call, lane steps/ray {lst / rays:.2f}, utilisation {lst / (64.0 * lit):.3f}")
+print(f"binary node visits/ray {(c['n_nodes_closest'] + c['n_nodes_any']) / rays:.1f}, tri tests/ray {(c['n_tri_closest'] + c['n_tri_any']) / rays:.2f}")
