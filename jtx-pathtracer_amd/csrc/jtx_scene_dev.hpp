@@ -254,12 +254,14 @@ struct WideState {
 
 // One interior step of a walking lane: take the next child of the current group (popping the stack when the
 // group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
+// ORDERED = false (anyHit: the answer does not depend on the order): children are taken in slot order.
+template <bool ORDERED>
 JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws) {
     if ((ws.gbits & 0xffu) == 0u) {                          // group exhausted: pop
         if (ws.sp == 0) { ws.done = true; return; }
         --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
     }
-    const int k = __builtin_ctz(ws.gbits & 0xffu);           // next position in visiting order
+    const int k = ORDERED ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);   // next position in visiting order (anyHit: leaves first)
     ws.gbits &= ~(1u << k);
     const unsigned slot = (ws.gbits >> (8 + 3 * k)) & 7u;
     const unsigned ni = ws.gbase >> 28, base = ws.gbase & 0x0fffffffu;
@@ -269,7 +271,9 @@ JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, con
     const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
     const unsigned *tail = (const unsigned *) (wide + a + 4);   // [children base][8 x 24-bit visiting orders][0]
     const int pbit = 24 * r.negmask;
-    const unsigned cbase = tail[0], plo = tail[1 + (pbit >> 5)], phi = tail[2 + (pbit >> 5)];
+    const unsigned cbase = tail[0];
+    unsigned plo = 0u, phi = 0u;
+    if (ORDERED) { plo = tail[1 + (pbit >> 5)]; phi = tail[2 + (pbit >> 5)]; }
     const f3 o = r.o, inv = r.inv;
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     // per axis: t(q) = q * a + b with a = cell / d (exact: a power-of-two scaling), b = (origin - o) / d,
@@ -296,11 +300,13 @@ JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, con
         hits |= (t0 <= t1 ? 1u : 0u) << s;
     }
     // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first)
-    const unsigned perm = __funnelshift_r(plo, phi, pbit & 31) & 0x00ffffffu;
+    const unsigned perm = ORDERED ? (__funnelshift_r(plo, phi, pbit & 31) & 0x00ffffffu) : 0x00fac688u;   // identity: slot k at position k
     const unsigned nchild = n0.w >> 28;
     unsigned pend = 0u;
+    if (ORDERED) {
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) pend |= ((hits >> ((perm >> (3 * k2)) & 7u)) & 1u) << k2;
+        for (int k2 = 0; k2 < 8; ++k2) pend |= ((hits >> ((perm >> (3 * k2)) & 7u)) & 1u) << k2;
+    } else pend = hits;
     pend &= (1u << nchild) - 1u;
     ws.gbase = cbase | (((n0.w >> 24) & 0xfu) << 28);
     ws.gbits = pend | (perm << 8);
@@ -341,7 +347,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
                 WSTAT(cnt.w_node_iters++;)
                 if (ws.walking()) {
                     WSTAT(cnt.w_node_steps++; const int leafBefore = ws.pendLeaf; const bool doneBefore = ws.done;)
-                    wideNodeStep(wide, stk, stride, r, ws);
+                    wideNodeStep<!ANY>(wide, stk, stride, r, ws);
                     WSTAT(if (ws.pendLeaf < 0 && !ws.done) cnt.w_fetch++; (void) leafBefore; (void) doneBefore;)
                 }
             }
