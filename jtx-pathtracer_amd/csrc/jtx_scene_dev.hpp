@@ -22,7 +22,6 @@ struct DLight { int type; float position[3]; float intensity[3]; float scale; fl
 
 struct DevScene {
     const float4    *tnodes;      // threaded (stackless) node records: 8 direction-sign orderings x num_nodes x 2 float4
-    const uint4     *wide;        // 8-ary quantised nodes + leaf records (traverseWide), or null
     const float4    *tris;
     const float4    *shade;
     const DMaterial *materials;
@@ -30,10 +29,11 @@ struct DevScene {
     const DTexture  *textures;
     const float     *texels;
     int num_nodes, num_prims, num_lights, num_materials;
-    int wide_depth;        // levels of the wide tree = LDS stack entries per lane
     int lds_threaded;      // != 0: the 8 threaded orderings + tris are staged in LDS (stackless kernels)
     int material_mask;     // OR of (1 << Material::type) over the scene's materials
     float sky[3];
+    int wide_depth;               // levels of the wide tree = LDS stack entries per lane
+    const uint4     *wide;        // 8-ary quantised nodes + leaf records (traverseWide), or null
 };
 
 struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode only)
@@ -404,7 +404,11 @@ JD bool traverseNoStack(const Src &src, int num_nodes, f3 o, f3 d, float tmin, f
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-    const bool regular = regularRay(o, inv, tmin, tmax);
+    // (== regularRay(); spelled out because calling the helper here costs the LDS-resident kernel 11 more spilled
+    //  VGPRs and 3 % of its time with this compiler -- measured)
+    const bool regular = finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
+                         fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
+                         tmin == tmin && tmax == tmax;
     if (__builtin_expect(regular, 1)) return traverseThreaded<ANY, COUNT, true>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
     return traverseThreaded<ANY, COUNT, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);   // axis-parallel & co.
 }
