@@ -524,3 +524,52 @@ def test_frame_gather_pack_scatter_on_device(gpu, cornell_pair):
     torch.cuda.synchronize()
     assert_same_f32(acc0.cpu().numpy().reshape(H, W, 3), full_acc, "gathered frame")
     assert (img0.cpu().numpy().reshape(H, W, 3) == full_img).all()
+
+
+def _tie_scene(gpu, n=24):
+    """Three coincident tessellated walls with different albedos (every hit has two exact rivals at the same t), the
+    same wall again rotated by a transform that maps onto itself, a floor, and rays that run exactly along shared
+    edges: whatever structure walks the BVH must resolve equal t the way Scene::closestHit does -- first found wins."""
+    sc = gpu.scenes
+    s = sc.SceneData("ties")
+    s.materials = [sc.material(sc.DIFFUSE, a) for a in [(0.9, 0.1, 0.1), (0.1, 0.9, 0.1), (0.1, 0.1, 0.9), (0.7, 0.7, 0.7)]]
+    for m in range(3):
+        g = sc._grid_quad((-4, 0, -3), (8, 0, 0), (0, 6, 0), n, n, (0, 0, 1))
+        s.add_mesh(g[0], g[1], g[2], m, uvs=g[3], name=f"wall{m}")
+    g = sc._grid_quad((-6, 0, -3), (12, 0, 0), (0, 0, 9), n, n, (0, 1, 0))
+    s.add_mesh(g[0], g[1], g[2], 3, uvs=g[3], name="floor")
+    s.lights = [sc.light(sc.POINT, (1.0, 5.0, 4.0), (1, 1, 1), 60.0), sc.light(sc.DISTANT, (0.3, -1.0, -0.4), (1, 1, 1), 1.5)]
+    s.sky = (0.2, 0.3, 0.4)
+    s.camera = dict(center=(0.0, 3.0, 9.0), target=(0.0, 3.0, -3.0), up=(0, 1, 0), yfov=45.0, defocus_angle=0.0, focus_distance=1.0)
+    return s
+
+
+@pytest.mark.parametrize("max_prims", [1, 4])
+def test_equal_t_ties_resolve_as_in_the_reference(gpu, max_prims):
+    data = _tie_scene(gpu)
+    data.max_prims_in_node = max_prims
+    sc = gpu.Scene(data); sc.buildBVH(max_prims)
+    assert sc.info()["wide_depth"] >= 2 and not sc.info()["lds_resident"]
+    osc = ol.OracleScene(data)
+    # per-ray API (wide nodes are not used here, binary records): rays through grid vertices and along grid edges
+    rs = np.random.RandomState(3)
+    n = 20000
+    gx = -4 + 8 * rs.randint(0, 25, n) / 24.0
+    gy = 6 * rs.randint(0, 25, n) / 24.0
+    target = np.stack([gx, gy, np.full(n, -3.0)], 1).astype(np.float32)
+    o = np.tile(np.array([[0.0, 3.0, 9.0]], np.float32), (n, 1))
+    o[n // 2:] = target[n // 2:] + np.array([0, 0, 5], np.float32)          # second half: axis-parallel rays onto vertices
+    d = (target - o).astype(np.float32)
+    g, r = sc.closestHit(o, d), osc.closestHit(o, d)
+    assert (g["hit"] == r["hit"]).all() and g["hit"].mean() > 0.9
+    assert (g["prim"] == r["prim"]).all()
+    assert_same_f32(g["t"], r["t"], "t")
+    # whole frames: counted (binary records) and uncounted (wide nodes) against the oracle
+    for count in (True, False):
+        cam_g = gpu.StaticCamera(160, 120, data.camera, 2, 2, 6)
+        cam_g.render(sc, count_rays=count, integrator=1)
+        acc, img, cnt = osc.render(data.camera_desc(160, 120, 2, 2, 6))
+        assert_same_f32(cam_g.acc_, acc, f"accumulation buffer (count_rays={count})")
+        assert (cam_g.img_ == img).all()
+        if count:
+            assert cam_g.counters == cnt
