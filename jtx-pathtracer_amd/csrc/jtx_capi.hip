@@ -762,12 +762,22 @@ int jtx_mi_debug_util(jtx_mi_scene *s, unsigned long long *out3) {     // diagno
     (void) hipDeviceSynchronize();
     return hipMemcpy(out3, s->counters.p + 20, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
+int jtx_mi_debug_util_hist(jtx_mi_scene *s, unsigned long long *out7) {
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out7, s->counters.p + 24, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
 #endif
 #ifdef JTX_PROFILE_WIDE
 int jtx_mi_debug_wide(jtx_mi_scene *s, unsigned long long *out8) {     // diagnostic builds only
     if (!s || !s->counters.p) return 1;
     (void) hipDeviceSynchronize();
     return hipMemcpy(out8, s->counters.p + 24, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
 #ifdef JTX_PROFILE_PHASES

@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
             else for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
             if ((threadIdx.x & 63) == 0 && sv) atomicAdd(&p.counters[24 + i], sv);
         }
+        if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[9 + i], (unsigned long long) cnt.w_hist[i]);
     }
 #endif
 #ifdef JTX_PROFILE_UTIL
@@ -225,7 +226,8 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         // pixel loop early stop counting: take the wave maximum
         unsigned a = cnt.it_interior, b = cnt.it_leaf, c = cnt.it_calls;
         for (int off = 32; off > 0; off >>= 1) { a = max(a, __shfl_down(a, off, 64)); b = max(b, __shfl_down(b, off, 64)); c = max(c, __shfl_down(c, off, 64)); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&p.counters[20], (unsigned long long) a); atomicAdd(&p.counters[21], (unsigned long long) b); atomicAdd(&p.counters[22], (unsigned long long) c); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&p.counters[20], (unsigned long long) a); atomicAdd(&p.counters[21], (unsigned long long) b); atomicAdd(&p.counters[22], (unsigned long long) c);
+                                       for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[24 + i], (unsigned long long) cnt.it_hist[i]); }
     }
 #endif
 }

@@ -40,9 +40,11 @@ struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode
     unsigned n_camera, n_closest, n_any, n_nodes_closest, n_tri_closest, n_accept, n_nodes_any, n_tri_any, n_shade;
 #ifdef JTX_PROFILE_UTIL
     unsigned it_interior, it_leaf, it_calls;   // diagnostic: loop iterations this lane sat through (= wave iterations)
+    unsigned it_hist[7];   // interior iterations by number of walking lanes: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
 #endif
 #ifdef JTX_PROFILE_WIDE
     unsigned w_calls, w_node_iters, w_node_steps, w_leaf_iters, w_leaf_steps, w_tris, w_pops, w_fetch;   // diagnostic: wide traversal
+    unsigned w_hist[7];    // node iterations by number of walking lanes: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
 #endif
 };
 #ifdef JTX_PROFILE_UTIL
@@ -143,6 +145,9 @@ JD bool finiteNonZero(float x) { return fabsf(x) < __builtin_inff() && x != 0.0f
 #ifndef JTX_LEAF_VOTE
 #define JTX_LEAF_VOTE 12      // lanes parked on a leaf that end the interior phase of a wave
 #endif
+#ifndef JTX_FEW_WALKERS
+#define JTX_FEW_WALKERS 12    // ... or any parked lane once so few lanes are still walking (C2: 47.3 -> 45.6 ms)
+#endif
 
 // ---- threaded (stackless) traversal -------------------------------------------------------------------
 // In Scene::closestHit / anyHit the child visited first depends only on the SIGN of the ray direction
@@ -167,7 +172,8 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
         while (true) {
 #pragma unroll
             for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
-                UTIL(if (COUNT) cnt.it_interior++;)
+                UTIL(if (COUNT) { cnt.it_interior++; const int na = __popcll(__ballot(leafW == 0 && cur >= 0));
+                                  cnt.it_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++; })
                 if (leafW == 0 && cur >= 0) {
                     const float4 na = src.tnode(cur, 0);
                     const float4 nb = src.tnode(cur, 1);
@@ -181,6 +187,7 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
             const unsigned long long walking = __ballot(leafW == 0 && cur >= 0);
             const unsigned long long parked = __ballot(leafW != 0);
             if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE) break;
+            if (parked != 0ull && __popcll(walking) <= JTX_FEW_WALKERS) break;      // do not let a few long walks hold the parked lanes
         }
         if (__ballot(leafW != 0) == 0ull) break;            // wave-uniform: every lane is done
         UTIL(if (COUNT) cnt.it_leaf++;)
@@ -344,7 +351,9 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
         while (true) {
 #pragma unroll
             for (int rep = 0; rep < JTX_WIDE_STEPS; ++rep) {
-                WSTAT(cnt.w_node_iters++;)
+                WSTAT(cnt.w_node_iters++;
+                      { const int na = __popcll(__ballot(ws.walking()));
+                        cnt.w_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++; })
                 if (ws.walking()) {
                     WSTAT(cnt.w_node_steps++; const int leafBefore = ws.pendLeaf; const bool doneBefore = ws.done;)
                     wideNodeStep<!ANY>(wide, stk, stride, r, ws);

@@ -288,6 +288,7 @@ def _frame_on_device(gpu, sc, cam, integrator, **kw):
     acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
     st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())      # the fills above ran on the default stream
     with torch.cuda.stream(st):
         gpu.distributed.render_shard(sc, cam, kw.get("rank", 0), kw.get("world", 1), acc, img, stream=st.cuda_stream,
                                      integrator=integrator, count_rays=kw.get("count", False))
@@ -413,6 +414,7 @@ def test_shard_buffers_are_zeroed_every_frame(gpu, cornell_pair):
     acc = torch.full((70 * 100 * 3,), 7.0, dtype=torch.float32, device=dev)
     img = torch.full((70 * 100 * 3,), 9, dtype=torch.uint8, device=dev)
     st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())      # the fills above ran on the default stream
     with torch.cuda.stream(st):
         gpu.distributed.render_shard(sc, cam, 1, 3, acc, img, stream=st.cuda_stream)
     torch.cuda.synchronize()
@@ -510,6 +512,7 @@ def test_frame_gather_pack_scatter_on_device(gpu, cornell_pair):
     root = gpu.distributed.FrameGather(W, H, 0, world, dev)
     acc0 = img0 = None
     st = torch.cuda.Stream()            # a non-default stream: 0 would mean "the library's own stream"
+    st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         for r in range(world):
             acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)

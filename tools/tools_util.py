@@ -16,3 +16,7 @@ print("wave leaf phases", it_leaf, "lane tri tests", tris, "utilisation(approx, 
 print("wave traverse calls", calls, "lane rays", rays, "utilisation %.3f" % (rays / (64.0 * calls)))
 print("interior iterations per call %.1f, leaf phases per call %.2f" % (it_int / calls, it_leaf / calls))
 print("mean node visits/ray %.1f" % (nodes / rays))
+h = lib.jtx_mi_debug_util_hist; h.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+hv = (C.c_uint64 * 7)(); assert h(sc.handle, hv) == 0
+tot = sum(int(x) for x in hv)
+print("interior iterations by walking lanes  1-2 3-4 5-8 9-16 17-32 33-48 49-64:", " ".join(f"{int(x) / tot:.3f}" for x in hv))

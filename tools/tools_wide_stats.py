@@ -19,3 +19,7 @@ print(f"rays {rays}, wave traverse calls {calls} -> ray slots used {rays / (64.0
 print(f"node phase: {nit / calls:.1f} wave iterations/call, lane steps/ray {nst / rays:.2f} (fetches {fetch / rays:.2f}), utilisation {nst / (64.0 * nit):.3f}")
 print(f"leaf phase: {lit / calls:.1f} wave iterations/call, lane steps/ray {lst / rays:.2f}, utilisation {lst / (64.0 * lit):.3f}")
 print(f"binary node visits/ray {(c['n_nodes_closest'] + c['n_nodes_any']) / rays:.1f}, tri tests/ray {(c['n_tri_closest'] + c['n_tri_any']) / rays:.2f}")
+h = lib.jtx_mi_debug_wide_hist; h.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+hv = (C.c_uint64 * 7)(); assert h(sc.handle, hv) == 0
+tot = sum(int(x) for x in hv)
+print("node iterations by walking lanes  1-2 3-4 5-8 9-16 17-32 33-48 49-64:", " ".join(f"{int(x) / tot:.3f}" for x in hv))
