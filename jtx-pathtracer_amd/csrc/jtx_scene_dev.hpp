@@ -237,6 +237,9 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 #ifndef JTX_WIDE_LEAF_VOTE
 #define JTX_WIDE_LEAF_VOTE 4
 #endif
+#ifndef JTX_WIDE_FEW_WALKERS
+#define JTX_WIDE_FEW_WALKERS 8
+#endif
 #ifndef JTX_WIDE_STEPS
 #define JTX_WIDE_STEPS 1
 #endif
@@ -363,6 +366,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
             const unsigned long long walking = __ballot(ws.walking());
             const unsigned long long parked = __ballot(ws.pendLeaf >= 0);
             if (walking == 0ull || __popcll(parked) >= JTX_WIDE_LEAF_VOTE) break;
+            if (parked != 0ull && __popcll(walking) <= JTX_WIDE_FEW_WALKERS) break;
         }
         if (__ballot(ws.pendLeaf >= 0) == 0ull) break;          // wave-uniform: every lane is done
         WSTAT(cnt.w_leaf_iters++;)
