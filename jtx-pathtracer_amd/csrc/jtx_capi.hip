@@ -595,7 +595,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         // kept in one lane; 1/2 .. 1/8 shards and small frames are 7 .. 55 % faster split 32 ways.
         const long waves = (long) owned * 16;
         int groups = 1;
-        { const char *e = getenv("JTX_STRATA_GROUPS"); if (e) groups = atoi(e); else if (waves < (long) s.num_cus * 96) groups = 32; }
+        { const char *e = getenv("JTX_STRATA_GROUPS"); if (e) groups = atoi(e); else if (waves < (long) s.num_cus * 24) groups = 64; else if (waves < (long) s.num_cus * 96) groups = 32; }
         if (groups < 1) groups = 1;
         if (groups > se - sb) groups = se - sb;
         if (groups > 1) {
