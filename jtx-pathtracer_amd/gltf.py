@@ -1,0 +1,392 @@
+"""glTF 2.0 / GLB ingestion with the semantics of the reference's Assimp import.
+
+`loadScene` (src/loader.cpp:13-225) reads a file through Assimp with
+`aiProcess_Triangulate | aiProcess_FlipUVs | aiProcess_GenNormals | aiProcess_PreTransformVertices`
+(loader.cpp:21) and `createScene` (src/scene.cpp:176-209) wraps it with a default camera and a
+background colour.  Assimp is not available here, so this module restates what that pipeline does to a
+glTF file, as far as the hot path can see it:
+
+  * one Mesh per glTF primitive, in scene-graph traversal order, node transforms baked into positions
+    (point transform) and normals (inverse-transpose, re-normalised) -- PreTransformVertices;
+  * v -> 1 - v on TEXCOORD_0 -- FlipUVs;
+  * flat face normals when a primitive has no NORMAL -- GenNormals (vertices are not shared then);
+  * one Triangle ref {index, meshIndex} per face, mesh by mesh (loader.cpp:216-222);
+  * materials (loader.cpp:104-150): every glTF material carries metallic / roughness factors, so it is
+    METALLIC_ROUGHNESS with albedo WHITE, alphaX = metallicFactor, alphaY = roughnessFactor (the
+    reference stores the two factors in the alpha fields, loader.cpp:136-137), albedo texture =
+    baseColorTexture, metallic-roughness texture = metallicRoughnessTexture; baseColorFactor, emission,
+    normal and occlusion maps are ignored exactly as the reference ignores them; a primitive without a
+    material gets DIFFUSE (1, 0.3, 0.5) (loader.cpp:206-209);
+  * textures (src/image.cpp:59-101 -> stbi_loadf): 8-bit samples become float pow(x / 255, 2.2) per
+    colour channel, alpha stays x / 255 (ext/stb/stb_image.h ldr_to_hdr); the file's own channel count
+    is kept.  PNG (8/16-bit, grey/RGB/palette, +alpha, non-interlaced) is decoded here with zlib; JPEG
+    needs a codec this package does not have: `allow_missing_textures=True` loads the scene without
+    those maps (texture id -1), otherwise a ValueError says which image it was.
+
+Parity of this step cannot be pinned (no Assimp, no stb in the image): it is host-side data preparation,
+covered by round-trip tests against this module's own writer and by structural checks on the
+reference's helmet.glb where that file is present.
+"""
+import json
+import os
+import struct
+import zlib
+
+import numpy as np
+
+from . import scenes
+
+_COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+# ------------------------------------------------------------------------------------------------
+# PNG (decode for textures, encode for the test writer)
+# ------------------------------------------------------------------------------------------------
+def decode_png(data):
+    """PNG bytes -> uint8 array (H, W, C), C = 1 (grey), 2 (grey+alpha), 3 (RGB / palette) or 4 (RGBA / palette+tRNS).
+    16-bit samples keep their high byte, as stb_image's 8-bit path does."""
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG")
+    pos, idat, plte, trns, hdr = 8, [], None, None, None
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if kind == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"PLTE":
+            plte = np.frombuffer(body, np.uint8).reshape(-1, 3)
+        elif kind == b"tRNS":
+            trns = np.frombuffer(body, np.uint8)
+        elif kind == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    if interlace:
+        raise ValueError("interlaced PNG not supported")
+    if depth not in (8, 16) and not (ctype == 3 and depth in (1, 2, 4, 8)) and not (ctype == 0 and depth in (1, 2, 4)):
+        raise ValueError("unsupported PNG bit depth")
+    nch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, nch * depth // 8)
+    stride = (w * nch * depth + 7) // 8
+    raw = zlib.decompress(b"".join(idat))
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    p = 0
+    for y in range(h):
+        ft = raw[p]
+        line = np.frombuffer(raw, np.uint8, stride, p + 1).astype(np.int32)
+        p += 1 + stride
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, np.int32)
+            for x in range(stride):                       # sub / average / paeth depend on the decoded left pixel
+                a = cur[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                if ft == 1:
+                    pr = a
+                elif ft == 3:
+                    pr = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[x] = (line[x] + pr) & 255
+        out[y] = cur
+        prev = cur
+    if depth == 16:
+        px = out.reshape(h, w, nch, 2)[..., 0]
+    elif depth == 8:
+        px = out.reshape(h, w, nch)
+    else:                                                 # packed grey / palette indices
+        bits = np.unpackbits(out, axis=1)[:, : w * depth].reshape(h, w, depth)
+        px = (bits * (1 << np.arange(depth - 1, -1, -1))).sum(-1).astype(np.uint8)[..., None]
+        if ctype == 0:
+            px = (px.astype(np.int32) * 255 // ((1 << depth) - 1)).astype(np.uint8)
+    if ctype == 3:
+        idx = px[..., 0]
+        rgb = plte[idx]
+        if trns is not None:
+            alpha = np.full(256, 255, np.uint8)
+            alpha[: len(trns)] = trns
+            return np.concatenate([rgb, alpha[idx][..., None]], -1)
+        return rgb
+    return np.ascontiguousarray(px)
+
+
+def encode_png(img):
+    """uint8 (H, W, C) -> PNG bytes (filter 0, C in 1..4)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, c = img.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) + \
+        chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+def ldr_to_float(px):
+    """stbi_loadf on an 8-bit image: pow(x / 255, 2.2) per colour channel, alpha (2nd of 2, 4th of 4) linear."""
+    px = np.asarray(px, np.uint8)
+    c = px.shape[-1]
+    out = np.empty(px.shape, np.float32)
+    ncol = c if c in (1, 3) else c - 1
+    out[..., :ncol] = np.power(px[..., :ncol].astype(np.float32) / np.float32(255.0), 2.2).astype(np.float32)
+    if ncol < c:
+        out[..., ncol:] = px[..., ncol:].astype(np.float32) / np.float32(255.0)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# reader
+# ------------------------------------------------------------------------------------------------
+def _read_container(path):
+    with open(path, "rb") as f:
+        blob = f.read()
+    base = os.path.dirname(os.path.abspath(path))
+    if blob[:4] == b"glTF":
+        _, _, total = struct.unpack("<4sII", blob[:12])
+        pos, doc, bin_chunk = 12, None, None
+        while pos < total:
+            n, kind = struct.unpack("<II", blob[pos:pos + 8])
+            body = blob[pos + 8:pos + 8 + n]
+            pos += 8 + n
+            if kind == 0x4E4F534A:
+                doc = json.loads(body.decode("utf-8"))
+            elif kind == 0x004E4942 and bin_chunk is None:
+                bin_chunk = body
+        return doc, bin_chunk, base
+    return json.loads(blob.decode("utf-8")), None, base
+
+
+def _buffers(doc, bin_chunk, base):
+    import base64
+    out = []
+    for b in doc.get("buffers", []):
+        uri = b.get("uri")
+        if uri is None:
+            out.append(bin_chunk)
+        elif uri.startswith("data:"):
+            out.append(base64.b64decode(uri.split(",", 1)[1]))
+        else:
+            with open(os.path.join(base, uri), "rb") as f:
+                out.append(f.read())
+    return out
+
+
+def _accessor(doc, bufs, i):
+    a = doc["accessors"][i]
+    dt, nc = np.dtype(_COMP[a["componentType"]]), _NCOMP[a["type"]]
+    count = a["count"]
+    if "bufferView" not in a:
+        arr = np.zeros((count, nc), dt)
+    else:
+        v = doc["bufferViews"][a["bufferView"]]
+        start = v.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = v.get("byteStride", 0) or dt.itemsize * nc
+        buf = bufs[v["buffer"]]
+        if stride == dt.itemsize * nc:
+            arr = np.frombuffer(buf, dt, count * nc, start).reshape(count, nc)
+        else:
+            arr = np.stack([np.frombuffer(buf, dt, nc, start + k * stride) for k in range(count)])
+    if a.get("normalized") and dt.kind in "ui":
+        info = np.iinfo(dt)
+        arr = np.maximum(arr.astype(np.float32) / np.float32(info.max), -1.0)
+    return arr
+
+
+def _node_matrix(n):
+    if "matrix" in n:
+        return np.array(n["matrix"], np.float64).reshape(4, 4).T          # glTF stores column-major
+    t = np.array(n.get("translation", (0, 0, 0)), np.float64)
+    x, y, z, w = n.get("rotation", (0, 0, 0, 1))
+    s = np.array(n.get("scale", (1, 1, 1)), np.float64)
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], np.float64)
+    m = np.eye(4)
+    m[:3, :3] = r * s[None, :]
+    m[:3, 3] = t
+    return m
+
+
+def _image_bytes(doc, bufs, base, img):
+    if "bufferView" in img:
+        v = doc["bufferViews"][img["bufferView"]]
+        s = v.get("byteOffset", 0)
+        return bytes(bufs[v["buffer"]][s:s + v["byteLength"]]), img.get("mimeType", "")
+    uri = img["uri"]
+    if uri.startswith("data:"):
+        import base64
+        return base64.b64decode(uri.split(",", 1)[1]), uri[5:uri.index(";")]
+    with open(os.path.join(base, uri), "rb") as f:
+        return f.read(), img.get("mimeType", "")
+
+
+def load_gltf(path, background=scenes.SKY_BLUE, allow_missing_textures=False):
+    """createScene(path, identity, background) (src/scene.cpp:176-209) for a .glb / .gltf file -> SceneData."""
+    doc, bin_chunk, base = _read_container(path)
+    bufs = _buffers(doc, bin_chunk, base)
+    s = scenes.SceneData("File scene")
+    s.sky = tuple(background)
+    s.camera = dict(center=(0, 0, 8), target=(0, 0, 0), up=(0, 1, 0), yfov=20.0, defocus_angle=0.0, focus_distance=1.0)
+
+    tex_of_image = {}
+
+    def texture_id(texinfo):
+        if texinfo is None:
+            return -1
+        src = doc["textures"][texinfo["index"]].get("source")
+        if src is None:
+            return -1
+        if src in tex_of_image:
+            return tex_of_image[src]
+        data, mime = _image_bytes(doc, bufs, base, doc["images"][src])
+        if data[:8] == b"\x89PNG\r\n\x1a\n":
+            px = decode_png(data)
+            if px.shape[-1] < 3:
+                raise ValueError(f"image {src}: {px.shape[-1]}-channel texture; getTexel (image.hpp:140-153) reads 3 channels")
+            s.textures.append(ldr_to_float(px))
+            tex_of_image[src] = len(s.textures) - 1
+        elif allow_missing_textures:
+            tex_of_image[src] = -1
+        else:
+            raise ValueError(f"image {src} ({mime or 'unknown type'}): only PNG can be decoded here "
+                             "(pass allow_missing_textures=True to load the scene without it)")
+        return tex_of_image[src]
+
+    mat_index = {}
+    for i, m in enumerate(doc.get("materials", [])):                    # loader.cpp:104-150
+        name = m.get("name", "")
+        if name in mat_index:
+            continue                                                     # materialMap.contains(matName)
+        pbr = m.get("pbrMetallicRoughness", {})
+        s.materials.append(scenes.material(scenes.METALLIC_ROUGHNESS, (1.0, 1.0, 1.0),
+                                           alpha_x=float(pbr.get("metallicFactor", 1.0)),
+                                           alpha_y=float(pbr.get("roughnessFactor", 1.0)),
+                                           albedo_tex=texture_id(pbr.get("baseColorTexture")),
+                                           mr_tex=texture_id(pbr.get("metallicRoughnessTexture"))))
+        mat_index[name] = len(s.materials) - 1
+
+    def visit(ni, parent):
+        n = doc["nodes"][ni]
+        m = parent @ _node_matrix(n)
+        if "mesh" in n:
+            for prim in doc["meshes"][n["mesh"]]["primitives"]:
+                if prim.get("mode", 4) != 4:
+                    continue                                             # points / lines: dropped by Triangulate + face check
+                att = prim["attributes"]
+                pos = _accessor(doc, bufs, att["POSITION"]).astype(np.float64)
+                idx = _accessor(doc, bufs, prim["indices"]).reshape(-1).astype(np.int64) if "indices" in prim \
+                    else np.arange(len(pos), dtype=np.int64)
+                idx = idx[: len(idx) // 3 * 3].reshape(-1, 3)
+                uv = _accessor(doc, bufs, att["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in att else None
+                nrm = _accessor(doc, bufs, att["NORMAL"]).astype(np.float64) if "NORMAL" in att else None
+                if nrm is None:                                          # GenNormals: flat, vertices un-shared
+                    pos = pos[idx.reshape(-1)]
+                    if uv is not None:
+                        uv = uv[idx.reshape(-1)]
+                    idx = np.arange(len(pos), dtype=np.int64).reshape(-1, 3)
+                    fn = np.cross(pos[1::3] - pos[0::3], pos[2::3] - pos[0::3])
+                    ln = np.linalg.norm(fn, axis=1, keepdims=True)
+                    fn = np.where(ln > 0, fn / np.where(ln > 0, ln, 1), 0)
+                    nrm = np.repeat(fn, 3, axis=0)
+                wp = (pos @ m[:3, :3].T + m[:3, 3]).astype(np.float32)   # PreTransformVertices
+                nm = np.linalg.inv(m[:3, :3]).T
+                wn = nrm @ nm.T
+                ln = np.linalg.norm(wn, axis=1, keepdims=True)
+                wn = np.where(ln > 0, wn / np.where(ln > 0, ln, 1), wn).astype(np.float32)
+                if uv is not None:
+                    uv = np.stack([uv[:, 0], np.float32(1.0) - uv[:, 1]], 1).astype(np.float32)   # FlipUVs
+                if "material" in prim:
+                    mat = mat_index[doc["materials"][prim["material"]].get("name", "")]
+                else:
+                    s.materials.append(scenes.material(scenes.DIFFUSE, (1.0, 0.3, 0.5)))         # loader.cpp:206-209
+                    mat = len(s.materials) - 1
+                s.add_mesh(idx.astype(np.int32), wp, wn, mat, uvs=uv, name=doc["meshes"][n["mesh"]].get("name", f"mesh_{len(s.meshes)}"))
+        for c in n.get("children", []):
+            visit(c, m)
+
+    scene_def = doc["scenes"][doc.get("scene", 0)]
+    for root in scene_def["nodes"]:
+        visit(root, np.eye(4))
+    return s
+
+
+# ------------------------------------------------------------------------------------------------
+# writer (tests; also a way to hand a procedural scene to other tools)
+# ------------------------------------------------------------------------------------------------
+def write_glb(path, data, textures_u8=None, node_matrices=None):
+    """SceneData -> .glb.  Geometry is written as given (node matrix = `node_matrices[i]` or identity; mesh
+    transforms must be identity); METALLIC_ROUGHNESS / other materials become pbrMetallicRoughness with
+    metallicFactor = alpha_x, roughnessFactor = alpha_y; `textures_u8[i]` (H, W, C uint8) is embedded as PNG for
+    scene texture i.  v is stored un-flipped (1 - v), so that load_gltf(write_glb(s)) gives s.uvs back."""
+    bin_parts, views, accessors = [], [], []
+
+    def add_view(raw, target=None):
+        while sum(len(p) for p in bin_parts) % 4:
+            bin_parts.append(b"\x00")
+        off = sum(len(p) for p in bin_parts)
+        bin_parts.append(raw)
+        v = {"buffer": 0, "byteOffset": off, "byteLength": len(raw)}
+        if target:
+            v["target"] = target
+        views.append(v)
+        return len(views) - 1
+
+    def add_acc(arr, ctype, kind, target, minmax=False):
+        arr = np.ascontiguousarray(arr)
+        a = {"bufferView": add_view(arr.tobytes(), target), "componentType": ctype, "count": int(arr.shape[0]), "type": kind}
+        if minmax:
+            a["min"] = [float(x) for x in arr.min(0)]
+            a["max"] = [float(x) for x in arr.max(0)]
+        accessors.append(a)
+        return len(accessors) - 1
+
+    images, textures = [], []
+    for t in (textures_u8 or []):
+        images.append({"bufferView": add_view(encode_png(t)), "mimeType": "image/png"})
+        textures.append({"source": len(images) - 1})
+    materials = []
+    for i, m in enumerate(data.materials):
+        pbr = {"metallicFactor": float(m["alpha_x"]), "roughnessFactor": float(m["alpha_y"])}
+        if m["albedo_tex"] >= 0:
+            pbr["baseColorTexture"] = {"index": int(m["albedo_tex"])}
+        if m["mr_tex"] >= 0:
+            pbr["metallicRoughnessTexture"] = {"index": int(m["mr_tex"])}
+        materials.append({"name": f"material_{i}", "pbrMetallicRoughness": pbr})
+    meshes, nodes = [], []
+    for i, m in enumerate(data.meshes):
+        att = {"POSITION": add_acc(m["vertices"].astype(np.float32), 5126, "VEC3", 34962, True),
+               "NORMAL": add_acc(m["normals"].astype(np.float32), 5126, "VEC3", 34962)}
+        if m["uvs"] is not None:
+            uv = np.stack([m["uvs"][:, 0], np.float32(1.0) - m["uvs"][:, 1]], 1).astype(np.float32)
+            att["TEXCOORD_0"] = add_acc(uv, 5126, "VEC2", 34962)
+        prim = {"attributes": att, "indices": add_acc(m["indices"].reshape(-1).astype(np.uint32), 5125, "SCALAR", 34963),
+                "material": int(m["material"]), "mode": 4}
+        meshes.append({"name": m["name"] or f"mesh_{i}", "primitives": [prim]})
+        node = {"mesh": i}
+        if node_matrices is not None and node_matrices[i] is not None:
+            node["matrix"] = [float(x) for x in np.asarray(node_matrices[i], np.float64).T.reshape(-1)]
+        nodes.append(node)
+    bin_blob = b"".join(bin_parts)
+    bin_blob += b"\x00" * (-len(bin_blob) % 4)
+    doc = {"asset": {"version": "2.0", "generator": "jtx-mi"}, "scene": 0, "scenes": [{"nodes": list(range(len(nodes)))}],
+           "nodes": nodes, "meshes": meshes, "materials": materials, "accessors": accessors, "bufferViews": views,
+           "buffers": [{"byteLength": len(bin_blob)}]}
+    if images:
+        doc["images"], doc["textures"] = images, textures
+    js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
+    js += b" " * (-len(js) % 4)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(bin_blob)))
+        f.write(struct.pack("<II", len(js), 0x4E4F534A) + js)
+        f.write(struct.pack("<II", len(bin_blob), 0x004E4942) + bin_blob)
