@@ -111,11 +111,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU fallback)")
+    # JTX_DIST_BACKEND=gloo + JTX_ALL_RANKS_ON_DEVICE=0: rehearsal of the N > 1 code path on a one-GPU box (every
+    # rank renders its shard on the same card, the exchange is staged through the host); never a measurement
+    backend = os.environ.get("JTX_DIST_BACKEND", "nccl")
+    if os.environ.get("JTX_ALL_RANKS_ON_DEVICE") is not None:
+        local_rank = int(os.environ["JTX_ALL_RANKS_ON_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     jtx._capi.check(jtx._capi.load().jtx_mi_set_device(local_rank))
 
     factory, W, H, xs, ys, depth = WORKLOADS[args.workload]
@@ -244,7 +252,7 @@ def main():
             "config": {"workload": args.workload, "scene_triangles": data.num_triangles, "width": W, "height": H,
                        "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
-                       "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" if world > 1 else "1 gpu",
+                       "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu",
                        "scene_upload_ms": round(t_upload * 1e3, 2),
                        "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": scene.info()["lds_resident"],
                        "wide_bvh_bytes": scene.info()["wide_bytes"]},

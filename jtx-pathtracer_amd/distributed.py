@@ -54,14 +54,27 @@ def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count
                                         C.c_void_p(stream) if stream else None))
 
 
+def _gloo_with_device_tensors(t, group=None):
+    """gloo (CPU rehearsals of the N > 1 path on a one-GPU box) has no reduce / gather for device tensors"""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def reduce_frame(acc, img=None, dst=0, group=None):
     """The per-frame collective: sum the disjoint shards onto rank `dst` (RCCL ring over xGMI)."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    if img is not None:
-        dist.reduce(img, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    for t in (acc, img):
+        if t is None:
+            continue
+        if _gloo_with_device_tensors(t, group):
+            h = t.cpu()
+            dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            if dist.get_rank(group) == dst:
+                t.copy_(h)
+        else:
+            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
 
 
 class FrameGather:
@@ -116,6 +129,17 @@ class FrameGather:
         if self.world == 1 or not dist.is_initialized():
             return
         self.pack(acc, img)
+        if _gloo_with_device_tensors(self.slab, self.group):             # rehearsal only: stage through the host
+            slab = self.slab.cpu()
+            if self.rank == self.dst:
+                recv = [slab.new_empty(slab.shape) for _ in range(self.world)]
+                dist.gather(slab, recv, dst=self.dst, group=self.group)
+                for r in range(self.world):
+                    self.recv[r].copy_(recv[r])
+                self.scatter(acc, img)
+            else:
+                dist.gather(slab, None, dst=self.dst, group=self.group)
+            return
         if self.rank == self.dst:
             dist.gather(self.slab, list(self.recv.unbind(0)), dst=self.dst, group=self.group)
             self.scatter(acc, img)
