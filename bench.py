@@ -240,8 +240,12 @@ def main():
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("workload") == args.workload and world == 1:
-                    traffic = j.get("hbm_bytes_per_launch")
+                if world == 1:
+                    w = j.get("workloads", {}).get(args.workload)
+                    if w is not None:
+                        traffic = w.get("hbm_bytes_per_launch")
+                    elif j.get("workload") == args.workload:
+                        traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
