@@ -217,3 +217,38 @@ def test_wide_build_small_and_degenerate_inputs():
     assert depth == 0 and len(w) == 0
     w, depth = api.wide_build_host(nodes[:0])
     assert depth == 0 and len(w) == 0
+
+
+@pytest.mark.parametrize("max_prims,seed", [(1, 1), (4, 2), (8, 3)])
+def test_wide_walk_on_random_triangle_soups(max_prims, seed):
+    """no structure to lean on: random overlapping triangles of very different sizes, leaves with several primitives;
+    the wide walk still reaches the reference's leaves in the reference's order, for every octant"""
+    rs = np.random.RandomState(seed)
+    n = 700
+    c = rs.uniform(-10, 10, (n, 3))
+    size = np.exp(rs.uniform(np.log(0.02), np.log(6.0), (n, 1, 1)))
+    tri = (c[:, None, :] + rs.normal(size=(n, 3, 3)) * size).astype(np.float32)
+    s = scenes.SceneData("soup")
+    s.materials = [scenes.material(scenes.DIFFUSE, (0.5, 0.5, 0.5))]
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (3 * n, 1))
+    s.add_mesh(np.arange(3 * n, dtype=np.int32).reshape(-1, 3), tri.reshape(-1, 3), nrm, 0)
+    s.max_prims_in_node = max_prims
+    nodes, _, depth = api.bvh_build_host(s)
+    w, wdepth = api.wide_build_host(nodes)
+    assert wdepth >= 2
+    if max_prims > 1:
+        assert nodes["num_prims"].max() > 1
+    lo, hi = nodes[0]["pmin"], nodes[0]["pmax"]
+    checked = 0
+    for i in range(192):
+        o = (lo + (hi - lo) * rs.uniform(-0.2, 1.2, 3)).astype(np.float32)
+        d = rs.normal(size=3).astype(np.float32)
+        d *= np.float32(-1.0 if (i >> 3) & 1 else 1.0)          # all octants get their turn
+        inv = (f32(1.0) / d).astype(np.float32)
+        neg = [int(inv[k] < 0) for k in range(3)]
+        tmax = f32(np.inf) if i % 2 else f32(rs.uniform(2.0, 25.0))
+        a = binary_leaves(nodes, o, inv, neg, f32(0.001), tmax)
+        b = wide_leaves(w, o, inv, neg, f32(0.001), tmax)
+        assert a == b, f"ray {i}"
+        checked += len(a)
+    assert checked > 120
