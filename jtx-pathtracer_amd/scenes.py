@@ -536,3 +536,63 @@ def write_obj(scene, path):
             for t in m["indices"]:
                 f.write("f " + " ".join(f"{vbase + int(i)}//{vbase + int(i)}" for i in t) + "\n")
             vbase += len(m["vertices"])
+
+
+# ------------------------------------------------------------------------------------------------
+# The reference's file-scene factories (src/scene.cpp:176-298).  The asset is passed in: the reference reads
+# "assets/scenes/..." next to its binary; nothing of it ships with this package.
+# ------------------------------------------------------------------------------------------------
+def create_scene(path, transform=None, background=SKY_BLUE):
+    """createScene(path, Mat4, background) (scene.cpp:176-209): loadScene + the default camera (0,0,8) -> origin,
+    yfov 20; `transform` (4x4) is applied to the vertices and normals of meshes[0] ONLY, as the reference does
+    (scene.cpp:203-206).  Every material of an OBJ import is DIFFUSE WHITE (loader.cpp:139-144: Kd is ignored)."""
+    white = material(DIFFUSE, (1.0, 1.0, 1.0))
+    if path.lower().endswith((".glb", ".gltf")):
+        from . import gltf
+        s = gltf.load_gltf(path, background=background, allow_missing_textures=True)
+    else:
+        s = load_obj(path, default_material=white)
+        # one Material per distinct usemtl name, as materialMap does (loader.cpp:105-149); load_obj shares one dict
+        s.sky = tuple(background)
+    s.name = "File scene"
+    s.sky = tuple(background)
+    s.camera = dict(center=(0, 0, 8), target=(0, 0, 0), up=(0, 1, 0), yfov=20.0, defocus_angle=0.0, focus_distance=1.0)
+    if transform is not None and s.meshes:
+        m = np.asarray(transform, np.float32)
+        v = s.meshes[0]["vertices"]
+        s.meshes[0]["vertices"] = (v @ m[:3, :3].T + m[:3, 3]).astype(np.float32)            # Transform::applyToPoint
+        s.meshes[0]["normals"] = (s.meshes[0]["normals"] @ m[:3, :3].T).astype(np.float32)   # applyToNormal: upper 3x3
+    return s
+
+
+def _set_mesh_material(s, mesh_index, mat):
+    s.materials.append(mat)
+    s.meshes[mesh_index]["material"] = len(s.materials) - 1
+
+
+def knob_scene(path):
+    """createKnobScene (scene.cpp:272-298): knob.obj with mesh 0 dull yellow Lambert, meshes 1-2 gold, mesh 3 rough glass."""
+    s = create_scene(path)
+    if len(s.meshes) < 4:
+        raise ValueError("createKnobScene addresses meshes[0..3]")
+    s.camera.update(center=(0, 3, 8), target=(0, 0, 0), yfov=15.0)
+    _set_mesh_material(s, 0, material(DIFFUSE, (0.3, 0.3, 0.0)))
+    gold = material(CONDUCTOR, ior=GOLD_IOR, k=GOLD_K, alpha_x=0.05, alpha_y=0.05)
+    _set_mesh_material(s, 1, gold)
+    s.meshes[2]["material"] = s.meshes[1]["material"]
+    _set_mesh_material(s, 3, material(DIELECTRIC, ior=(1.5, 1.5, 1.5), alpha_x=0.3, alpha_y=0.3))
+    return s
+
+
+def shaderball_scene(path, with_light=False):
+    """createShaderBallScene / createShaderBallSceneWithLight (scene.cpp:211-270): mesh 3 gold; the lit variant adds
+    one DISTANT light straight down (0,-1,0), scale 10 -- every shadow ray of that scene is axis-parallel."""
+    s = create_scene(path)
+    if len(s.meshes) < 4:
+        raise ValueError("createShaderBallScene addresses meshes[3]")
+    s.camera.update(center=(2.5, 16, 12), target=(0, 3, 0), yfov=40.0)
+    s.sky = SKY_BLUE if with_light else (0.7, 0.8, 1.0)
+    if with_light:
+        s.lights.append(light(DISTANT, (0.0, -1.0, 0.0), (1, 1, 1), 10.0))
+    _set_mesh_material(s, 3, material(CONDUCTOR, ior=GOLD_IOR, k=GOLD_K, alpha_x=0.05, alpha_y=0.05))
+    return s

@@ -170,3 +170,40 @@ def test_reference_helmet_glb_structure():
     assert uv is not None and np.isfinite(uv).all() and uv.shape == (14556, 2)      # v wraps (the file stores v in [1, 2])
     nodes, _, depth = jtx.api.bvh_build_host(s)
     assert len(nodes) > s.num_triangles and depth > 10
+
+
+REF_SCENES = "/root/reference/src/assets/scenes"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SCENES), reason="reference assets are only present in the build container")
+def test_reference_file_scene_factories():
+    """createKnobScene / createShaderBallScene[WithLight] (scene.cpp:211-298) on the reference's own OBJ files:
+    mesh count, hard-coded cameras / materials / light, a valid BVH and a finite oracle frame."""
+    import oracle_lib as ol
+    knob = scenes.knob_scene(os.path.join(REF_SCENES, "knob.obj"))
+    assert [m["name"] for m in knob.meshes][:4] == ["background", "inner", "logo", "outer"]
+    assert knob.num_triangles == 11970 and knob.camera["yfov"] == 15.0
+    kinds = [knob.materials[m["material"]]["type"] for m in knob.meshes[:4]]
+    assert kinds == [scenes.DIFFUSE, scenes.CONDUCTOR, scenes.CONDUCTOR, scenes.DIELECTRIC]
+    ball = scenes.shaderball_scene(os.path.join(REF_SCENES, "shaderball", "shaderball.obj"), with_light=True)
+    assert len(ball.meshes) >= 4 and ball.materials[ball.meshes[3]["material"]]["type"] == scenes.CONDUCTOR
+    assert len(ball.lights) == 1 and ball.lights[0]["type"] == scenes.DISTANT and tuple(ball.lights[0]["position"]) == (0.0, -1.0, 0.0)
+    for s in (knob, ball):
+        nodes, _, depth = jtx.api.bvh_build_host(s)
+        assert len(nodes) > s.num_triangles
+        acc, img, cnt = ol.OracleScene(s).render(s.camera_desc(48, 32, 1, 1, 4), threads=4)
+        assert np.isfinite(acc).all() and cnt["n_closest"] >= 48 * 32 and img.any()
+    helmet = scenes.create_scene(os.path.join(REF_SCENES, "helmet.glb"), background=(0, 0, 0))
+    assert helmet.sky == (0, 0, 0) and helmet.num_triangles == 15452
+
+
+def test_create_scene_transform_applies_to_first_mesh_only(tmp_path):
+    src, _ = _source_scene()
+    for m in src.materials:
+        m["albedo_tex"] = m["mr_tex"] = -1
+    path = str(tmp_path / "two.glb")
+    gltf.write_glb(path, src)
+    t = np.eye(4, dtype=np.float32); t[:3, 3] = (1.0, 2.0, 3.0); t[0, 0] = 2.0
+    s = scenes.create_scene(path, transform=t, background=(0.1, 0.1, 0.1))
+    assert np.array_equal(s.meshes[0]["vertices"], (src.meshes[0]["vertices"] * np.float32([2, 1, 1]) + np.float32([1, 2, 3])).astype(np.float32))
+    assert np.array_equal(s.meshes[1]["vertices"], src.meshes[1]["vertices"])          # scene.cpp:203-206 touches meshes[0] only
