@@ -260,7 +260,8 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
     wb.leaves.assign(nodes.size(), 1);
     for (size_t i = nodes.size(); i-- > 0;)
         if (nodes[i].num_prims == 0) {
-            if ((size_t) nodes[i].offset >= nodes.size() || i + 1 >= nodes.size()) return false;
+            // depth-first layout: first child at i + 1, second child behind the first subtree -- also rules out cycles
+            if (nodes[i].offset <= (int) i + 1 || (size_t) nodes[i].offset >= nodes.size()) return false;
             wb.leaves[i] = wb.leaves[i + 1] + wb.leaves[nodes[i].offset];
         }
     out.resize(6);

@@ -217,6 +217,10 @@ def test_wide_build_small_and_degenerate_inputs():
     assert depth == 0 and len(w) == 0
     w, depth = api.wide_build_host(nodes[:0])
     assert depth == 0 and len(w) == 0
+    bad, _, _ = api.bvh_build_host(scenes.cornell())          # a malformed tree (child link pointing backwards) is refused
+    bad = bad.copy(); bad["offset"][0] = 0
+    w, depth = api.wide_build_host(bad)
+    assert depth == 0 and len(w) == 0
 
 
 @pytest.mark.parametrize("max_prims,seed", [(1, 1), (4, 2), (8, 3)])
