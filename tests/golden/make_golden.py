@@ -36,6 +36,71 @@ def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
 
 
+def kernel_inputs():
+    """seeded inputs of the per-function known answers (SURVEY.md 8c ii, iii, vii); shared with the tests"""
+    rs = np.random.RandomState(77)
+    n = 4096
+    # (ii) AABB::hit: random boxes / rays, a quarter axis-parallel (zero direction components), some starting on a face
+    lo = rs.uniform(-5, 5, (n, 3)).astype(np.float32)
+    hi = (lo + rs.uniform(0, 4, (n, 3)).astype(np.float32)).astype(np.float32)
+    o = rs.uniform(-8, 8, (n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32)
+    aim = (lo + (hi - lo) * rs.uniform(-0.2, 1.2, (n, 3)).astype(np.float32) - o).astype(np.float32)
+    d[n // 2:] = aim[n // 2:]                                            # half the rays are aimed at (or just past) their box
+    z = rs.randint(0, 3, n)
+    d[np.arange(n)[: n // 4], z[: n // 4]] = 0.0
+    d[np.arange(n)[: n // 8], (z[: n // 8] + 1) % 3] = -0.0
+    o[n // 16: n // 8, 0] = lo[n // 16: n // 8, 0]                       # origin exactly on the min-x plane
+    t1 = rs.uniform(0.5, 30, n).astype(np.float32)
+    # (iii) ray-triangle: Cornell rays aimed at triangle vertices, edge midpoints and interiors (grazers included)
+    return dict(lo=lo, hi=hi, o=o, d=d, t1=t1)
+
+
+def tri_rays(data):
+    rs = np.random.RandomState(78)
+    V = []
+    for m in data.meshes:
+        v = m["vertices"][m["indices"]]                                   # (F, 3, 3)
+        V.append(v)
+    v = np.concatenate(V)
+    pts = np.concatenate([v.reshape(-1, 3), (v[:, 0] + v[:, 1]) / 2, (v[:, 1] + v[:, 2]) / 2, v.mean(1)]).astype(np.float32)
+    pts = np.repeat(pts, 8, axis=0)
+    o = (np.array([[278.0, 273.0, -800.0]], np.float32) + rs.uniform(-250, 250, (len(pts), 3)).astype(np.float32) *
+         np.array([[1, 1, 0]], np.float32)).astype(np.float32)
+    o[::2] = np.array([278.0, 273.0, 279.5], np.float32) + rs.uniform(-200, 200, (len(o[::2]), 3)).astype(np.float32)
+    return o, (pts - o).astype(np.float32)
+
+
+def kernel_vectors(scenes):
+    k = kernel_inputs()
+    lib = ol.load()
+    import ctypes as C
+    hits = np.zeros(len(k["lo"]), np.uint8)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    lib.ora_aabb_hit.restype = C.c_int
+    for i in range(len(hits)):
+        lo, hi, o, d = (np.ascontiguousarray(k[x][i]) for x in ("lo", "hi", "o", "d"))
+        hits[i] = lib.ora_aabb_hit(fp(lo), fp(hi), fp(o), fp(d), C.c_float(0.001), C.c_float(float(k["t1"][i])))
+    out = {"aabb_hit_crc32": crc(hits), "aabb_hit_count": int(hits.sum())}
+    cor = ol.OracleScene(scenes["cornell"])
+    o, d = tri_rays(scenes["cornell"])
+    r = cor.closestHit(o, d)
+    out["cornell_closest"] = {"rays": len(o), "hits": int(r["hit"].sum()),
+                              "crc32": crc(np.concatenate([r["hit"].astype(np.float32), r["t"], r["prim"].astype(np.float32), r["b1"], r["b2"],
+                                                           r["point"].reshape(-1), r["normal"].reshape(-1), r["uv"].reshape(-1)]))}
+    a = cor.anyHit(o, d, 0.0, np.full(len(o), 0.9999, np.float32))
+    out["cornell_any"] = {"hits": int(a.sum()), "crc32": crc(a)}
+    nodes, refs = cor.bvh()
+    out["cornell_bvh_crc32"] = crc(nodes.tobytes() + refs.tobytes())
+    # (vii) per-sample radiance: 256 fixed pixels x 16 samples, Cornell 512x512, 4x4 strata, depth 4 (config C1)
+    rs = np.random.RandomState(79)
+    row = np.repeat(rs.randint(0, 512, 256), 16).astype(np.int32); col = np.repeat(rs.randint(0, 512, 256), 16).astype(np.int32)
+    smp = np.tile(np.arange(16), 256).astype(np.int32)
+    rgb = cor.radiance_samples(scenes["cornell"].camera_desc(512, 512, 4, 4, 4), row, col, smp)
+    out["cornell_radiance_samples_crc32"] = crc(rgb)
+    return out
+
+
 def main():
     out = {"reference_probe": REFERENCE_PROBE, "rng": {}, "sincos": {}, "renders": {}, "bxdf": {}}
     for seed in [(0, 0, 1), (1, 2, 3), (511, 17, 16), (1079, 1919, 64)]:
@@ -67,6 +132,7 @@ def main():
         out["bxdf"]["materials"][str(m)] = {
             "sample_crc32": crc(np.concatenate([sm["ok"].astype(np.float32), sm["f"].reshape(-1), sm["wi"].reshape(-1), sm["pdf"]])),
             "eval_crc32": crc(o.evalBxdf(m, nrm, wo, wi, uv)), "pdf_crc32": crc(o.pdfBxdf(m, nrm, wo, wi, uv))}
+    out["kernels"] = kernel_vectors(scenes)
     with open(os.path.join(HERE, "oracle_golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote oracle_golden.json")

@@ -610,3 +610,30 @@ def test_gltf_scene_renders_like_the_oracle(gpu, tmp_path):
         if count:
             assert cam_g.counters == cnt
     assert len(np.unique(cam_g.img_.reshape(-1, 3), axis=0)) > 200          # textured, lit, not flat
+
+
+def test_kernel_known_answers_gpu(gpu, cornell_pair):
+    """the committed known answers (tests/golden: ray-triangle grazers through vertices and edge midpoints, shadow rays,
+    the Cornell LinearBVHNode array, 256 pixels x 16 per-sample radiances of config C1) straight from the GPU"""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(root, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    gold = json.load(open(os.path.join(root, "tests", "golden", "oracle_golden.json")))["kernels"]
+    data, sc, osc = cornell_pair
+    o, d = mg.tri_rays(data)
+    r = sc.closestHit(o, d)
+    got = mg.crc(np.concatenate([r["hit"].astype(np.float32), r["t"], r["prim"].astype(np.float32), r["b1"], r["b2"],
+                                 r["point"].reshape(-1), r["normal"].reshape(-1), r["uv"].reshape(-1)]))
+    assert got == gold["cornell_closest"]["crc32"] and int(r["hit"].sum()) == gold["cornell_closest"]["hits"]
+    a = sc.anyHit(o, d, 0.0, np.full(len(o), 0.9999, np.float32))
+    assert mg.crc(a) == gold["cornell_any"]["crc32"]
+    nodes, refs = sc.bvh()
+    assert mg.crc(nodes.tobytes() + refs.tobytes()) == gold["cornell_bvh_crc32"]
+    rs = np.random.RandomState(79)
+    row = np.repeat(rs.randint(0, 512, 256), 16).astype(np.int32); col = np.repeat(rs.randint(0, 512, 256), 16).astype(np.int32)
+    smp = np.tile(np.arange(16), 256).astype(np.int32)
+    rgb = gpu.api.radiance_samples(sc, data.camera_desc(512, 512, 4, 4, 4), row, col, smp)
+    assert mg.crc(rgb) == gold["cornell_radiance_samples_crc32"]

@@ -401,3 +401,27 @@ def test_restated_cornell_equals_reference_asset():
         assert a["vertices"].tobytes() == b["vertices"].tobytes(), a["name"]
         assert a["normals"].tobytes() == b["normals"].tobytes(), a["name"]
         assert a["indices"].tobytes() == b["indices"].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel-level known answers (AABB::hit pairs, ray-triangle grazers, the Cornell BVH, per-sample radiance)
+# ------------------------------------------------------------------------------------------------
+def _golden_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_kernel_known_answers_oracle():
+    mg = _golden_module()
+    scn = {"cornell": jtx.scenes.cornell()}
+    assert mg.kernel_vectors(scn) == GOLD["kernels"]
+    # the AABB vector once more with the independent numpy restatement of aabb.hpp:66-81
+    k = mg.kernel_inputs()
+    hits = np.array([np_aabb_hit(k["lo"][i], k["hi"][i], k["o"][i], k["d"][i], 0.001, float(k["t1"][i])) for i in range(len(k["lo"]))], np.uint8)
+    assert mg.crc(hits) == GOLD["kernels"]["aabb_hit_crc32"] and int(hits.sum()) == GOLD["kernels"]["aabb_hit_count"]
+    assert 1000 < hits.sum() < 3000
+    # the ray set really contains grazers: rays through triangle vertices / edge midpoints that still hit
+    assert GOLD["kernels"]["cornell_closest"]["hits"] > 0.9 * GOLD["kernels"]["cornell_closest"]["rays"]
