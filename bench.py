@@ -149,7 +149,16 @@ def main():
     collective = os.environ.get("JTX_FRAME_COLLECTIVE", "gather")
     gatherer = jtx.distributed.FrameGather(W, H, rank, world, dev) if (world > 1 and collective == "gather") else None
 
+    # N > 1: the exchange of frame i runs on a side stream while frame i + 1 renders into the other pair of shard
+    # buffers (rank 0 assembles frames in buffers of their own); every frame is complete before the closing fence
+    pipe = None
+    if gatherer is not None and os.environ.get("JTX_PIPELINE_EXCHANGE", "1") != "0":
+        pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, gatherer, integrator=integrator)
+
     def step(count=False, profile=False):
+        if pipe is not None and gatherer is not None and not count and not profile:
+            pipe.step(tstream)
+            return
         jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count,
                                      integrator=integrator, profile_kernels=profile)
         if gatherer is not None:
@@ -256,7 +265,7 @@ def main():
             "config": {"workload": args.workload, "scene_triangles": data.num_triangles, "width": W, "height": H,
                        "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
-                       "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu",
+                       "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu",
                        "scene_upload_ms": round(t_upload * 1e3, 2),
                        "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": scene.info()["lds_resident"],
                        "wide_bvh_bytes": scene.info()["wide_bytes"]},

@@ -114,7 +114,7 @@ class FrameGather:
         return self.slab
 
     def scatter(self, acc, img):
-        """(dst only) self.recv [world, nmax, 15] -> the frame buffers"""
+        """(dst only) self.recv [world, nmax, 15] -> the frame buffers (the shard buffers themselves, or separate ones)"""
         import torch
         if self.all_idx is None:
             return
@@ -124,11 +124,16 @@ class FrameGather:
         a8.index_copy_(0, self.all_idx, got[:, :12].contiguous())
         i8.index_copy_(0, self.all_idx, got[:, 12:].contiguous())
 
-    def collect(self, acc, img):
+    def collect(self, acc, img, out_acc=None, out_img=None):
+        """pack -> gather -> scatter.  On `dst` the frame lands in (out_acc, out_img) if given, else in place in
+        (acc, img).  Everything is enqueued on the CURRENT torch stream, so a caller may run it on a side stream
+        while the next frame renders into another pair of shard buffers."""
         import torch.distributed as dist
         if self.world == 1 or not dist.is_initialized():
             return
         self.pack(acc, img)
+        if out_acc is not None:
+            acc, img = out_acc, out_img
         if _gloo_with_device_tensors(self.slab, self.group):             # rehearsal only: stage through the host
             slab = self.slab.cpu()
             if self.rank == self.dst:
@@ -145,3 +150,38 @@ class FrameGather:
             self.scatter(acc, img)
         else:
             dist.gather(self.slab, None, dst=self.dst, group=self.group)
+
+
+class ShardPipeline:
+    """Frame loop of one rank with the exchange overlapped: frame i is gathered on a side stream while frame i + 1
+    renders into the other pair of shard buffers; on `dst` frames are assembled in buffers of their own
+    (`frame_acc`, `frame_img`).  `step()` only enqueues; `torch.cuda.synchronize()` (or the events) completes it."""
+
+    def __init__(self, scene, cam_desc, rank, world, device, gatherer, integrator=0):
+        import torch
+        self.scene, self.cam, self.rank, self.world, self.integrator = scene, cam_desc, rank, world, integrator
+        self.gatherer = gatherer
+        n = cam_desc.width * cam_desc.height * 3
+        self.accs = [torch.zeros(n, dtype=torch.float32, device=device) for _ in range(2)]
+        self.imgs = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(2)]
+        on_dst = rank == gatherer.dst
+        self.frame_acc = torch.zeros(n, dtype=torch.float32, device=device) if on_dst else None
+        self.frame_img = torch.zeros(n, dtype=torch.uint8, device=device) if on_dst else None
+        self.xstream = torch.cuda.Stream(device=device)
+        self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
+        self.exchanged = [torch.cuda.Event(), torch.cuda.Event()]
+        self.n = 0
+
+    def step(self, render_stream):
+        """`render_stream`: a non-default torch.cuda.Stream the shard kernel is launched on"""
+        import torch
+        b = self.n % 2
+        self.n += 1
+        render_stream.wait_event(self.exchanged[b])          # the exchange two frames back has read this pair
+        render_shard(self.scene, self.cam, self.rank, self.world, self.accs[b], self.imgs[b],
+                     stream=render_stream.cuda_stream, integrator=self.integrator)
+        self.rendered[b].record(render_stream)
+        with torch.cuda.stream(self.xstream):
+            self.xstream.wait_event(self.rendered[b])
+            self.gatherer.collect(self.accs[b], self.imgs[b], self.frame_acc, self.frame_img)
+            self.exchanged[b].record(self.xstream)
