@@ -685,3 +685,25 @@ def test_shard_pipeline_two_rank_rehearsal(gpu, tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "result").read() == "ok"
+
+
+@pytest.mark.parametrize("lightdir", [(1e-6, -1.0, 3e-7), (-2e-9, -1.0, 1e-10), (0.3, -1e-5, -0.9)])
+def test_wide_bvh_nearly_axis_parallel_rays(gpu, lightdir):
+    """stress of the wide-node error budget: shadow rays with |1/d| up to 1e10 (inside the
+    2^40 range, so they DO take the quantised nodes; b = (origin - o)/d gets huge) and a camera 2000 units away"""
+    data = gpu.scenes.atrium(target_tris=20000)
+    for l in data.lights:
+        if l["type"] == 1:
+            l["position"] = lightdir
+    cam = dict(data.camera); c = np.array(cam["center"], np.float64); t = np.array(cam["target"], np.float64)
+    cam["center"] = tuple(t + (c - t) / np.linalg.norm(c - t) * 2000.0); cam["yfov"] = 1.6
+    sc = gpu.Scene(data); sc.buildBVH()
+    assert sc.info()["wide_depth"] >= 3
+    osc = ol.OracleScene(data)
+    cam_g = gpu.StaticCamera(120, 80, cam, 2, 2, 6)
+    cam_g.render(sc, count_rays=False, integrator=1)
+    data.camera = cam
+    acc, img, cnt = osc.render(data.camera_desc(120, 80, 2, 2, 6))
+    assert cnt["n_any"] > 1000 and cnt["n_accept"] > 1000
+    assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
+    assert (cam_g.img_ == img).all()
