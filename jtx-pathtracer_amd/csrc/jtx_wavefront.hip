@@ -141,8 +141,11 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_generate(WfParams p, int s0, int 
 // a leaf (leafN > 0) or FINISHED (cur < 0), plus one PREFETCHED ray (pslot >= 0) whose o/d loads were
 // issued an outer iteration earlier: a lane that finishes switches to its prefetched ray without
 // waiting on HBM, and the wave never blocks on a refill.
-template <int ANY, bool COUNT, bool LDS_SCENE>
+// WIDE: HBM-resident scene, uncounted: the rays walk the 8-ary quantised nodes (traverseWide's steps, per-lane stack
+// in LDS behind the scan scratch); rays those nodes cannot take are traced on the binary records when activated.
+template <int ANY, bool COUNT, bool LDS_SCENE, bool WIDE>
 __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
+    static_assert(!WIDE || (!COUNT && !LDS_SCENE), "wide nodes: uncounted kernels of HBM-resident scenes only");
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
     // LDS: [wave scratch: WBLOCK ints][8 threaded node orderings][tris]  -- the traversal is stackless
@@ -158,9 +161,12 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
     const float4 *tnodes = LDS_SCENE ? lds_tnodes : sc.tnodes;
     const float4 *tris = LDS_SCENE ? lds_tris : sc.tris;
     int *scratch = scratchAll + (threadIdx.x & ~63);
+    uint2 *stk = (uint2 *) (scratchAll + WBLOCK) + threadIdx.x;       // WIDE: this lane's stack column (stride WBLOCK)
     const int *flags = ANY ? p.b.sflags : p.b.flags;
     const int want = ANY ? WF_SH_PENDING : WF_LIVE;
     const float tmin = ANY ? 0.0f : 0.001f;
+    WideRay wr; WideState ws; ws.start(); ws.done = true;
+    wr.o = mk3(0.0f); wr.d = mk3(1.0f); wr.inv = mk3(1.0f); wr.tmin = tmin; wr.tmax = 0.0f; wr.negmask = 0;
 
     Counters9 cnt = {};
     if (sc.num_nodes == 0) {
@@ -196,12 +202,14 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
                                  fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
                                  tmax == tmax;
             cur = negmask * sc.num_nodes; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
-            if (!regular) {
+            if (WIDE) { wr.o = o; wr.d = d; wr.inv = inv; wr.tmin = tmin; wr.tmax = tmax; wr.negmask = negmask; ws.start(); }
+            if (!regular || (WIDE && !wideRayOk(o, inv, tmin, tmax))) {
                 // axis-parallel / non-finite rays: the exact slab test, traced to the end right here
                 // (rare; keeps the main loop on the min/max form only)
                 GlobalSrc src; src.tnodes = tnodes; src.tris = tris;
                 hitAny = traverseThreaded<ANY != 0, COUNT, false>(src, sc.num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
                 cur = -1;
+                if (WIDE) { ws.done = true; ws.hitAnything = hitAny; }
             } else if (COUNT) { if (ANY) cnt.n_any++; else cnt.n_closest++; }
         }
         // ---- B. prefetch the next ray of lanes that hold none ----
@@ -223,42 +231,60 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
             continue;                                        // go activate what was just fetched
         }
 
+        if constexpr (WIDE) {
+            // ---- C/D (wide nodes): node steps until enough lanes are parked on a leaf or finished; then the leaves ----
+            while (true) {
+                if (slot >= 0 && ws.walking()) wideNodeStep<ANY == 0>(sc.wide, stk, WBLOCK, wr, ws);
+                const unsigned long long walking = __ballot(slot >= 0 && ws.walking());
+                const unsigned long long parked = __ballot(slot >= 0 && ws.pendLeaf >= 0);
+                const unsigned long long finished = __ballot(slot >= 0 && ws.done && ws.pendLeaf < 0);
+                if (walking == 0ull || __popcll(parked) >= JTX_WIDE_LEAF_VOTE || __popcll(finished) >= JTX_RETIRE_VOTE) break;
+                if (parked != 0ull && __popcll(walking) <= JTX_WIDE_FEW_WALKERS) break;
+            }
+            if (slot >= 0 && ws.pendLeaf >= 0) {
+                GlobalSrc src; src.tnodes = tnodes; src.tris = tris;
+                wideLeafStep(sc.wide, src, ANY != 0, wr, ws, rec);
+            }
+            if (slot >= 0 && ws.done && ws.pendLeaf < 0) { cur = -1; leafN = 0; hitAny = ws.hitAnything; }
+            else if (slot >= 0) cur = 0;                                  // still under way
+        } else {
         // ---- C. interior phase: one node per walking lane per iteration ----
-        while (true) {
+            while (true) {
 #pragma unroll
-            for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
-                if (slot >= 0 && leafN == 0 && cur >= 0) {
-                    const float4 na = tnodes[2 * cur], nb = tnodes[2 * cur + 1];
-                    if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
-                    const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
-                    const int w = __float_as_int(nb.w), z = __float_as_int(nb.z);
-                    if (boxHit && w != 0) { leafN = w; leafOff = z; }                    // park on the leaf
-                    else cur = (boxHit || w != 0) ? (w < 0 ? -1 : cur + 1) : z;          // next record / skip link
+                for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
+                    if (slot >= 0 && leafN == 0 && cur >= 0) {
+                        const float4 na = tnodes[2 * cur], nb = tnodes[2 * cur + 1];
+                        if (COUNT) { if (ANY) cnt.n_nodes_any++; else cnt.n_nodes_closest++; }
+                        const bool boxHit = slabRegular(na, nb, o, inv, tmin, tmax);
+                        const int w = __float_as_int(nb.w), z = __float_as_int(nb.z);
+                        if (boxHit && w != 0) { leafN = w; leafOff = z; }                    // park on the leaf
+                        else cur = (boxHit || w != 0) ? (w < 0 ? -1 : cur + 1) : z;          // next record / skip link
+                    }
                 }
+                const unsigned long long walking = __ballot(slot >= 0 && leafN == 0 && cur >= 0);
+                const unsigned long long parked = __ballot(leafN != 0);
+                const unsigned long long finished = __ballot(slot >= 0 && leafN == 0 && cur < 0);
+                if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE || __popcll(finished) >= JTX_RETIRE_VOTE) break;
             }
-            const unsigned long long walking = __ballot(slot >= 0 && leafN == 0 && cur >= 0);
-            const unsigned long long parked = __ballot(leafN != 0);
-            const unsigned long long finished = __ballot(slot >= 0 && leafN == 0 && cur < 0);
-            if (walking == 0ull || __popcll(parked) >= JTX_LEAF_VOTE || __popcll(finished) >= JTX_RETIRE_VOTE) break;
-        }
 
-        // ---- D. leaf phase ----
-        if (leafN != 0) {
-            GlobalSrc src; src.tris = tris;
-            const int n = leafN & 0xffff;
-            for (int i = 0; i < n; ++i) {
-                const int prim = leafOff + i;
-                if (COUNT) { if (ANY) cnt.n_tri_any++; else cnt.n_tri_closest++; }
-                float b1, b2, root;
-                if (!triTest(src, prim, o, d, tmin, tmax, b1, b2, root)) continue;
-                hitAny = true;
-                if (ANY) break;
-                tmax = root;
-                rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
-                if (COUNT) cnt.n_accept++;
+            // ---- D. leaf phase ----
+            if (leafN != 0) {
+                GlobalSrc src; src.tris = tris;
+                const int n = leafN & 0xffff;
+                for (int i = 0; i < n; ++i) {
+                    const int prim = leafOff + i;
+                    if (COUNT) { if (ANY) cnt.n_tri_any++; else cnt.n_tri_closest++; }
+                    float b1, b2, root;
+                    if (!triTest(src, prim, o, d, tmin, tmax, b1, b2, root)) continue;
+                    hitAny = true;
+                    if (ANY) break;
+                    tmax = root;
+                    rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+                    if (COUNT) cnt.n_accept++;
+                }
+                cur = ((ANY && hitAny) || leafN < 0) ? -1 : cur + 1;
+                leafN = 0;
             }
-            cur = ((ANY && hitAny) || leafN < 0) ? -1 : cur + 1;
-            leafN = 0;
         }
 
         // ---- E. retire finished rays: one store, nothing to wait for ----
@@ -419,9 +445,10 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_resolve(WfParams p, int s0, int n
 
 using namespace jtx;
 
-static size_t wfTraceLds(const DevScene &sc, bool lds) {
+static size_t wfTraceLds(const DevScene &sc, bool lds, bool wide) {
     size_t b = WBLOCK * sizeof(int);
     if (lds) b += ((size_t) 2 * 8 * sc.num_nodes + (size_t) 3 * sc.num_prims) * sizeof(float4);
+    if (wide) b += (size_t) sc.wide_depth * WBLOCK * sizeof(uint2);
     return b;
 }
 
@@ -431,9 +458,15 @@ hipError_t jtx_wf_generate(const WfParams &p, int s0, int nstrata, hipStream_t s
 }
 hipError_t jtx_wf_trace(const WfParams &p, int any, int grid, bool count, hipStream_t st) {
     const bool lds = p.scene.lds_threaded != 0;
-    const size_t sh = wfTraceLds(p.scene, lds);
+    const bool wide = !lds && !count && p.scene.wide != nullptr;
+    const size_t sh = wfTraceLds(p.scene, lds, wide);
     const dim3 g(grid), b(WBLOCK);
-#define LT(A, C, L) hipLaunchKernelGGL((k_wf_trace<A, C, L>), g, b, sh, st, p)
+    if (wide) {
+        if (any) hipLaunchKernelGGL((k_wf_trace<1, false, false, true>), g, b, sh, st, p);
+        else hipLaunchKernelGGL((k_wf_trace<0, false, false, true>), g, b, sh, st, p);
+        return hipGetLastError();
+    }
+#define LT(A, C, L) hipLaunchKernelGGL((k_wf_trace<A, C, L, false>), g, b, sh, st, p)
     if (any) { if (count) { if (lds) LT(1, true, true); else LT(1, true, false); } else { if (lds) LT(1, false, true); else LT(1, false, false); } }
     else     { if (count) { if (lds) LT(0, true, true); else LT(0, true, false); } else { if (lds) LT(0, false, true); else LT(0, false, false); } }
 #undef LT

@@ -442,6 +442,25 @@ def test_uncounted_render_mixed(gpu, mixed_pair, integrator):
     assert (cam_g.img_ == img).all()
 
 
+@pytest.mark.parametrize("integrator", [2])
+def test_uncounted_wavefront_atrium_and_axis_parallel(gpu, integrator):
+    """the wavefront trace kernels walk the wide nodes too (uncounted, HBM-resident scenes); second scene: every shadow
+    ray axis-parallel, i.e. traced on the binary records at activation"""
+    for overhead in (False, True):
+        data = gpu.scenes.atrium(target_tris=20000)
+        if overhead:
+            for l in data.lights:
+                if l["type"] == 1:
+                    l["position"] = (0.0, -1.0, 0.0)
+        sc = gpu.Scene(data); sc.buildBVH()
+        osc = ol.OracleScene(data)
+        cam_g = gpu.StaticCamera(160, 90, data.camera, 2, 2, 8)
+        cam_g.render(sc, count_rays=False, integrator=integrator)
+        acc, img, _ = osc.render(data.camera_desc(160, 90, 2, 2, 8), count=False)
+        assert_same_f32(cam_g.acc_, acc, f"accumulation buffer (overhead light: {overhead})")
+        assert (cam_g.img_ == img).all()
+
+
 @pytest.mark.parametrize("tris,prims", [(20000, 1), (60000, 1), (20000, 4)])
 def test_uncounted_render_atrium(gpu, tris, prims):
     data = gpu.scenes.atrium(target_tris=tris)
