@@ -143,8 +143,11 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_generate(WfParams p, int s0, int 
 // waiting on HBM, and the wave never blocks on a refill.
 // WIDE: HBM-resident scene, uncounted: the rays walk the 8-ary quantised nodes (traverseWide's steps, per-lane stack
 // in LDS behind the scan scratch); rays those nodes cannot take are traced on the binary records when activated.
+#ifndef JTX_WF_WIDE_OCC
+#define JTX_WF_WIDE_OCC 1
+#endif
 template <int ANY, bool COUNT, bool LDS_SCENE, bool WIDE>
-__global__ void __launch_bounds__(WBLOCK) k_wf_trace(WfParams p) {
+__global__ void __launch_bounds__(WBLOCK, WIDE ? JTX_WF_WIDE_OCC : 1) k_wf_trace(WfParams p) {
     static_assert(!WIDE || (!COUNT && !LDS_SCENE), "wide nodes: uncounted kernels of HBM-resident scenes only");
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const DevScene &sc = p.scene;
