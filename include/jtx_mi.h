@@ -106,7 +106,10 @@ typedef struct {
     int32_t tile_world;       /*   k % tile_world == tile_rank (0/0 or 0/1 => whole frame) */
     int32_t integrator;       /* 0 auto: 1 for all-Lambert scenes whose BVH fits LDS, else 2 (env JTX_INTEGRATOR overrides);
                                * 1 pixel-persistent, 2 HBM-queued wavefront, 3 wave-pool (LDS-queued wavefront) */
-    int32_t count_rays;       /* != 0: accumulate jtx_mi_counters on the device (slower) */
+    int32_t count_rays;       /* != 0: accumulate jtx_mi_counters on the device (slower); the counting kernels walk the
+                               * reference's binary BVH node by node, so the counters are Scene::closestHit / anyHit's own.
+                               * 0: same film bit for bit; scenes that do not fit LDS walk an 8-ary quantised BVH instead
+                               * (same leaves, same order, same hits: DESIGN.md section 3) */
     int32_t samples_per_tick; /* progress callback granularity for jtx_mi_render; <= 0 => all */
     int32_t reserved;         /* bit 0: time every wavefront kernel with its own HIP events (jtx_mi_kernel_time_by_kind) */
 } jtx_mi_render_opts;
