@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--atrium-tris", type=int, default=262144)
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's peer-to-peer needs on this driver
     import torch
     import torch.distributed as dist
     import jtx_pathtracer_amd as jtx
