@@ -107,7 +107,8 @@ void validate(const jtx_mi_scene_desc &d) {
 
 // ---- wide-node builder (layout + proof sketch: traverseWide in jtx_scene_dev.hpp) ----
 constexpr int kWideMinExp = -60, kWideMaxExp = 40;   // cell = 2^e; with |1/d| in [2^-40, 2^40] (WIDE_RANGE) cell / d is exact
-constexpr int kMaxWideDepth = 11;          // 11 x 8 B x 256 lanes = 22 KB of LDS stack per workgroup (7 workgroups / CU)
+constexpr int kMaxWideDepth = 24;          // stack = depth x 8 B x 256 lanes of LDS per workgroup: 11 levels (22 KB) still run 7 workgroups / CU,
+                                           // 24 levels (48 KB) 3; deeper trees (degenerate input) keep the binary records
 
 struct WideBuilder {
     const std::vector<jtx_mi_bvh_node> &nodes;

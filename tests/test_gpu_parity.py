@@ -726,3 +726,35 @@ def test_wide_bvh_nearly_axis_parallel_rays(gpu, lightdir):
     assert cnt["n_any"] > 1000 and cnt["n_accept"] > 1000
     assert_same_f32(cam_g.acc_, acc, "accumulation buffer")
     assert (cam_g.img_ == img).all()
+
+
+def test_wide_bvh_on_a_deep_degenerate_tree(gpu):
+    """triangles of geometrically growing size nested in one corner: the SAH peels a few triangles per level, the
+    binary tree is a chain and the wide tree stays deep (14 levels: a long per-lane LDS stack, fewer workgroups per
+    CU); the film still equals the oracle's"""
+    sc_ = gpu.scenes
+    s = sc_.SceneData("deep")
+    s.materials = [sc_.material(sc_.DIFFUSE, (0.7, 0.6, 0.5))]
+    v = []
+    for k in range(160):
+        e = np.float32(1.12) ** k * np.float32(0.01)
+        v += [(0, 0, -k * 1e-3), (e, 0, -k * 1e-3), (0, e, -k * 1e-3)]
+    v = np.array(v, np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (len(v), 1))
+    s.add_mesh(np.arange(len(v), dtype=np.int32).reshape(-1, 3), v, nrm, 0)
+    s.lights = [sc_.light(sc_.POINT, (20.0, 30.0, 40.0), (1, 1, 1), 3000.0)]
+    s.sky = (0.3, 0.4, 0.5)
+    s.camera = dict(center=(6.0, 5.0, 30.0), target=(3.0, 3.0, 0.0), up=(0, 1, 0), yfov=50.0, defocus_angle=0.0, focus_distance=1.0)
+    sc = gpu.Scene(s); sc.buildBVH()
+    info = sc.info()
+    assert not info["lds_resident"] and info["max_depth"] >= 15
+    assert 12 <= info["wide_depth"] <= 24
+    osc = ol.OracleScene(s)
+    cam_g = gpu.StaticCamera(128, 96, s.camera, 2, 2, 5)
+    cam_g.render(sc, count_rays=False, integrator=1)
+    acc, img, cnt = osc.render(s.camera_desc(128, 96, 2, 2, 5))
+    assert cnt["n_accept"] > 10000
+    assert_same_f32(cam_g.acc_, acc, "deep tree")
+    assert (cam_g.img_ == img).all()
+    cam_g.render(sc, count_rays=False, integrator=2)                  # the wavefront trace kernels use the same stack
+    assert_same_f32(cam_g.acc_, acc, "deep tree, wavefront")
