@@ -230,7 +230,7 @@ def main():
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
         my_bytes = algorithmic_bytes(mine)               # rank 0's launch
-        kernel_name = {1: "k_render_pixels", 3: "k_render_wavepool", 4: "k_render_fused"}.get(integrator)
+        kernel_name = {1: "k_render_paths", 3: "k_render_wavepool", 4: "k_render_fused"}.get(integrator)
         launches_per_frame = 1
         if integrator == 2:
             # dominant stage of the pipeline; its algorithmic bytes are the SURVEY 8d terms of that stage

@@ -48,6 +48,8 @@ struct jtx_mi_scene {
     DevBuf<float> texels;
     DevBuf<unsigned long long> counters;
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
+    DevBuf<unsigned> block_cost;     // cost-ordered launch: per pixel block duration of the estimation pass
+    DevBuf<int> block_order;
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;
     DevScene dev{};
@@ -584,11 +586,15 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         if (!s.counters.p) s.counters.alloc(32);
         HIPCHK(hipMemsetAsync(s.counters.p, 0, 32 * sizeof(unsigned long long), stream));
     }
+#ifdef JTX_PROFILE_TIMELINE
+    if (s.counters.n < 64 + 2 * 65536) { s.counters.alloc(64 + 2 * 65536); HIPCHK(hipMemsetAsync(s.counters.p, 0, (64 + 2 * 65536) * sizeof(unsigned long long), stream)); }
+#endif
     p.counters = s.counters.p;
     if (o.integrator < 0 || o.integrator > 4) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront), 3 (wave-pool) or 4 (pixel-persistent, fused rays)");
     int integ = o.integrator;
     if (integ == 0) integ = autoIntegrator(s);
     auto ev = takeEvents(s);
+    bool evClosed = false;
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) {
         // strata-split: when the shard has too few 8x8 pixel blocks to fill the GPU a few times over (small frames,
@@ -600,7 +606,28 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         { const char *e = getenv("JTX_STRATA_GROUPS"); if (e) groups = atoi(e); else if (waves < (long) s.num_cus * 24) groups = 64; else if (waves < (long) s.num_cus * 96) groups = 32; }
         if (groups < 1) groups = 1;
         if (groups > se - sb) groups = se - sb;
-        if (groups > 1) {
+        // mode of the uncounted launches: 2 = dynamic path assignment (k_render_paths: a wave hands the paths of its
+        // pixel block x strata range to whichever lane is free), 1 = one lane per pixel with a cost-ordered launch,
+        // 0 = one lane per pixel in tile order.  The counting launches always use 0.
+        static const int mode = [] { const char *e = getenv("JTX_DYNAMIC_PATHS"); return e ? atoi(e) : 2; }();
+        if (mode == 2 && !count) {
+            // waves of ~1000 paths drain evenly (C2: 43.0 ms unsplit, 39.4 ms with the 64 strata in 4 groups; 1/8 shard:
+            // 5.5 ms in 16 groups): the smallest power of two that gives >= 100 k waves, with >= 4 strata per group
+            if (!getenv("JTX_STRATA_GROUPS")) {
+                groups = 1;
+                const int cap = (se - sb) / 4 > 1 ? (se - sb) / 4 : 1;
+                while ((long) groups * waves < 100000 && groups * 2 <= cap) groups *= 2;
+            }
+            p.strata_per_group = (se - sb + groups - 1) / groups;
+            p.rad_stride = owned * 1024;
+            const size_t need = (size_t) p.rad_stride * (size_t) (se - sb);
+            if (s.rad.n < need) s.rad.alloc(need);
+            p.rad = s.rad.p;
+            HIPCHK(jtx_launch_render_paths(p, owned, stream));
+            HIPCHK(hipEventRecord(ev.second, stream));                 // jtx_mi_kernel_time = the dominant kernel alone
+            evClosed = true;
+            HIPCHK(jtx_launch_resolve_samples(p, owned, stream));
+        } else if (groups > 1) {
             p.strata_per_group = (se - sb + groups - 1) / groups;
             p.rad_stride = owned * 1024;
             const size_t need = (size_t) p.rad_stride * (size_t) (se - sb);
@@ -609,13 +636,27 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
             HIPCHK(jtx_launch_resolve_samples(p, owned, stream));
         } else {
-            HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
+            // Cost-ordered launch (mode 1): pixel blocks differ 3x and more in duration, so a frame of enough strata first
+            // renders ONE stratum while timing every block, sorts the blocks longest-first and lets the rest of the
+            // strata run in that order.  Sums are unaffected: the second pass resumes each pixel's accumulation.
+            const int nblocks = owned * (int) (1024 / JTX_RP_BLOCK);
+            if (mode == 1 && !count && se - sb >= 16 && nblocks >= s.num_cus * 8) {
+                if (s.block_cost.n < (size_t) nblocks) { s.block_cost.alloc(nblocks); s.block_order.alloc(nblocks); }
+                HIPCHK(hipMemsetAsync(s.block_cost.p, 0, nblocks * sizeof(unsigned), stream));
+                RenderParams a = p; a.sample_end = sb + 1; a.cost = s.block_cost.p; a.img = nullptr;
+                HIPCHK(jtx_launch_render_pixels(a, owned, false, stream));
+                HIPCHK(jtx_launch_sort_blocks(s.block_cost.p, s.block_order.p, nblocks, stream));
+                RenderParams b = p; b.sample_begin = sb + 1; b.order = s.block_order.p;
+                HIPCHK(jtx_launch_render_pixels(b, owned, false, stream));
+            } else {
+                HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
+            }
         }
     }
     else if (integ == 3) HIPCHK(jtx_launch_render_wavepool(p, owned, count, stream));
     else if (integ == 4) HIPCHK(jtx_launch_render_fused(p, owned, count, stream));
     else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
-    HIPCHK(hipEventRecord(ev.second, stream));
+    if (!evClosed) HIPCHK(hipEventRecord(ev.second, stream));
     s.pending.push_back(ev);
 }
 
@@ -780,6 +821,13 @@ int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
     if (!s || !s->counters.p) return 1;
     (void) hipDeviceSynchronize();
     return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+#ifdef JTX_PROFILE_TIMELINE
+int jtx_mi_debug_timeline(jtx_mi_scene *s, unsigned long long *out, int n) {   // diagnostic builds only: (start, end) wall clocks per wave
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out, s->counters.p + 64, (size_t) 2 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
 #ifdef JTX_PROFILE_PHASES

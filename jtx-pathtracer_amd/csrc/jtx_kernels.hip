@@ -145,9 +145,14 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 
     // work mapping: block = 4 waves = 4 consecutive 8x8 sub-blocks of one owned 32x32 tile
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int owned = blockIdx.x / BLOCKS_PER_TILE;                    // index into this rank's tiles
+    const int bid = p.order ? p.order[blockIdx.x] : (int) blockIdx.x;  // pixel block of this workgroup (cost-ordered launch)
+    const int owned = bid / BLOCKS_PER_TILE;                           // index into this rank's tiles
     const int tile = p.tile_rank + owned * p.tile_world;               // global 32x32 tile id, row-major (camera.cpp:55-64)
-    const int sub = (blockIdx.x % BLOCKS_PER_TILE) * WAVES_PER_BLOCK + wave;   // 0..15 sub-block inside the tile
+    const int sub = (bid % BLOCKS_PER_TILE) * WAVES_PER_BLOCK + wave;  // 0..15 sub-block inside the tile
+    const long long t_begin = p.cost ? clock64() : 0;
+#ifdef JTX_PROFILE_TIMELINE
+    const long long tl0 = wall_clock64();
+#endif
     const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
     const int row = trow * 32 + (sub >> 2) * 8 + (lane >> 3);
     const int col = tcol * 32 + (sub & 3) * 8 + (lane & 7);
@@ -206,6 +211,13 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         }
         }
     }
+#ifdef JTX_PROFILE_TIMELINE
+    if (!COUNT && p.counters && lane == 0 && p.sample_end - p.sample_begin > 1) {      // diagnostic: wave life span, indexed by pixel block
+        const int wid = ((int) blockIdx.y * (int) gridDim.x + bid) * WAVES_PER_BLOCK + wave;
+        if (wid < 65536) { p.counters[64 + 2 * wid] = (unsigned long long) tl0; p.counters[64 + 2 * wid + 1] = (unsigned long long) wall_clock64(); }
+    }
+#endif
+    if (p.cost && lane == 0) atomicMax(&p.cost[bid], (unsigned) min((long long) 0xffffffffu, clock64() - t_begin));
     if (COUNT) waveAddCounters(p.counters, cnt);
 #ifdef JTX_PROFILE_WIDE
     if (SRC == SRC_WIDE && p.counters) {   // diagnostic build: lane sums of the steps, lane 0's view of the wave iterations
@@ -228,6 +240,100 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         for (int off = 32; off > 0; off >>= 1) { a = max(a, __shfl_down(a, off, 64)); b = max(b, __shfl_down(b, off, 64)); c = max(c, __shfl_down(c, off, 64)); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(&p.counters[20], (unsigned long long) a); atomicAdd(&p.counters[21], (unsigned long long) b); atomicAdd(&p.counters[22], (unsigned long long) c);
                                        for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[24 + i], (unsigned long long) cnt.it_hist[i]); }
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_render_paths: pixel block x strata range with DYNAMIC PATH ASSIGNMENT (uncounted kernels).
+// In k_render_pixels a lane owns one pixel and a wave ends when its most expensive pixel does: wave timelines of the
+// C2 launch show ~30 % of the lane time idle at the end of the waves (pixel costs differ 3x inside an 8x8 block), and
+// halving the strata per lane raises the total wave time by 17 %.  Here the unit of work is ONE PATH: a wave owns
+// the (sEnd - sBegin) x 64 paths of an 8x8 pixel block and hands them out from a wave-local counter (a ballot and a
+// prefix count: no atomics) -- stratum-major, so the 64 lanes start with the 64 coherent camera rays of one stratum
+// and a lane whose path ends takes the next path, whatever pixel it belongs to.  Every path writes its clamped
+// radiance (camera.cpp:110-112) to rad[stratum][pixel] and k_resolve_samples adds them to the film in sample order,
+// so the sums are those of AccumulationBuffer::updatePixel bit for bit.  Costs 32 B of HBM traffic per path.
+// ------------------------------------------------------------------------------------------------
+template <int SRC, int MASK>
+__global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) k_render_paths(RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    constexpr bool LDS_SCENE = SRC == SRC_LDS;
+    const DevScene &sc = p.scene;
+    float4 *lds_tnodes = (float4 *) smem;
+    float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
+    if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bid = p.order ? p.order[blockIdx.x] : (int) blockIdx.x;
+    const int owned = bid / BLOCKS_PER_TILE;
+    const int tile = p.tile_rank + owned * p.tile_world;
+    const int sub = (bid % BLOCKS_PER_TILE) * WAVES_PER_BLOCK + wave;
+    const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
+    const int row0 = trow * 32 + (sub >> 2) * 8, col0 = tcol * 32 + (sub & 3) * 8;
+    const int sBegin = p.sample_begin + (int) blockIdx.y * p.strata_per_group;
+    const int sEnd = sBegin + p.strata_per_group < p.sample_end ? sBegin + p.strata_per_group : p.sample_end;
+    const int slot0 = owned * 1024 + sub * 64;
+    const int nunits = (sEnd > sBegin && row0 < p.height && col0 < p.width) ? (sEnd - sBegin) * 64 : 0;
+    const long long t_begin = p.cost ? clock64() : 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#ifdef JTX_PROFILE_TIMELINE
+    const long long tl0 = wall_clock64();
+    unsigned tl_iters = 0, tl_active = 0;
+#endif
+
+    Counters9 cnt = {};
+    PathState ps;
+    int next = 0;                                   // wave-uniform: first path not handed out yet
+    int s = 0, pl = 0;                              // this lane's current path: stratum, pixel of the block
+    bool alive = false, need = true;
+    while (true) {
+        // ---- hand out paths to the lanes that need one (everybody takes part: `next` must stay uniform) ----
+        while (true) {
+            const unsigned long long mask = __ballot(need);
+            if (mask == 0ull || next >= nunits) break;
+            const int u = next + __popcll(mask & below);
+            next += __popcll(mask);
+            if (need && u < nunits) {
+                s = sBegin + (u >> 6); pl = u & 63;
+                const int row = row0 + (pl >> 3), col = col0 + (pl & 7);
+                if (row < p.height && col < p.width) { startPath(p.cam, row, col, s, ps); alive = true; need = false; }
+            }
+        }
+        need = false;
+        if (__ballot(alive) == 0ull) break;
+#ifdef JTX_PROFILE_TIMELINE
+        tl_iters++; tl_active += alive ? 1 : 0;
+#endif
+        // ---- one bounce of every live path ----
+        if (alive) {
+            bool done;
+            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris;
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
+            else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                                  src.stk = (uint2 *) smem + threadIdx.x; src.stride = BLOCK;
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
+            else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
+            if (done) {
+                f3 c = ps.radiance;                                    // camera.cpp:110-112
+                if (c.x > 1.0f) c.x = 1.0f;
+                if (c.y > 1.0f) c.y = 1.0f;
+                if (c.z > 1.0f) c.z = 1.0f;
+                p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot0 + pl] = make_float4(c.x, c.y, c.z, 0.0f);
+                alive = false; need = true;
+            }
+        }
+    }
+    if (p.cost && lane == 0) atomicMax(&p.cost[bid], (unsigned) min((long long) 0xffffffffu, clock64() - t_begin));
+#ifdef JTX_PROFILE_TIMELINE
+    if (p.counters) {
+        unsigned long long a = tl_active;
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) {
+            const int wid = ((int) blockIdx.y * (int) gridDim.x + bid) * WAVES_PER_BLOCK + wave;
+            if (wid < 65536) { p.counters[64 + 2 * wid] = (unsigned long long) tl0; p.counters[64 + 2 * wid + 1] = (unsigned long long) wall_clock64(); }
+            atomicAdd(&p.counters[40], (unsigned long long) tl_iters); atomicAdd(&p.counters[41], a);
+        }
     }
 #endif
 }
@@ -397,6 +503,48 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
     }
 }
 } // namespace jtx
+
+// Longest-first launch order: a counting sort of the pixel blocks by the cost a one-stratum pass measured.  One
+// workgroup; 1024 cost classes between the minimum and the maximum are plenty for list scheduling.
+namespace jtx {
+__global__ void __launch_bounds__(1024) k_sort_blocks(const unsigned *cost, int *order, int n) {
+    __shared__ unsigned hist[1024];
+    __shared__ unsigned lo, hi;
+    if (threadIdx.x == 0) { lo = 0xffffffffu; hi = 0u; }
+    hist[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) { atomicMin(&lo, cost[i]); atomicMax(&hi, cost[i]); }
+    __syncthreads();
+    const float scale = hi > lo ? 1023.0f / (float) (hi - lo) : 0.0f;
+    auto cls = [&](unsigned c) { return 1023 - (int) ((float) (c - lo) * scale); };      // class 0 = most expensive
+    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&hist[cls(cost[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned run = 0; for (int k = 0; k < 1024; ++k) { const unsigned c = hist[k]; hist[k] = run; run += c; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&hist[cls(cost[i])], 1u)] = i;
+}
+} // namespace jtx
+
+hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, hipStream_t stream) {
+    if (num_owned_tiles <= 0) return hipSuccess;
+    const bool lds = p.scene.lds_threaded != 0;
+    const bool wide = !lds && p.scene.wide != nullptr;
+    const size_t shmem = wide ? (size_t) p.scene.wide_depth * BLOCK * sizeof(uint2) : ldsBytes(p.scene, lds);
+    const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
+    const int groups = (p.sample_end - p.sample_begin + p.strata_per_group - 1) / p.strata_per_group;
+    const dim3 grid((unsigned) num_owned_tiles * (unsigned) BLOCKS_PER_TILE, (unsigned) groups), block(BLOCK);
+#define LAUNCH_PA(L, M) hipLaunchKernelGGL((k_render_paths<L, M>), grid, block, shmem, stream, p)
+    if (lambert) { if (lds) LAUNCH_PA(SRC_LDS, MAT_DIFFUSE_ONLY); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_DIFFUSE_ONLY); else LAUNCH_PA(SRC_GLOBAL, MAT_DIFFUSE_ONLY); }
+    else         { if (lds) LAUNCH_PA(SRC_LDS, MAT_ALL); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_ALL); else LAUNCH_PA(SRC_GLOBAL, MAT_ALL); }
+#undef LAUNCH_PA
+    return hipGetLastError();
+}
+
+hipError_t jtx_launch_sort_blocks(const unsigned *cost, int *order, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_blocks, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    return hipGetLastError();
+}
 
 hipError_t jtx_launch_resolve_samples(const RenderParams &p, int num_owned_tiles, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
