@@ -48,8 +48,6 @@ struct jtx_mi_scene {
     DevBuf<float> texels;
     DevBuf<unsigned long long> counters;
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
-    DevBuf<unsigned> block_cost;     // cost-ordered launch: per pixel block duration of the estimation pass
-    DevBuf<int> block_order;
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;
     DevScene dev{};
@@ -597,20 +595,18 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     bool evClosed = false;
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) {
-        // strata-split: when the shard has too few 8x8 pixel blocks to fill the GPU a few times over (small frames,
-        // 1/8 of a frame per rank), split each block's strata over several waves; sums are re-done in sample order
-        // Measured (C2 shards on one MI355X): a full 1080p frame (32640 waves) is 10 % faster with the strata of a pixel
-        // kept in one lane; 1/2 .. 1/8 shards and small frames are 7 .. 55 % faster split 32 ways.
+        // strata groups: the strata of a pixel block are spread over `groups` waves (gridDim.y); every path's clamped
+        // radiance goes to rad[stratum][pixel] and k_resolve_samples adds them to the film in sample order.
+        // One-lane-per-pixel launches (counting, JTX_DYNAMIC_PATHS=0) split only small shards / frames: 32 or 64 ways.
         const long waves = (long) owned * 16;
         int groups = 1;
         { const char *e = getenv("JTX_STRATA_GROUPS"); if (e) groups = atoi(e); else if (waves < (long) s.num_cus * 24) groups = 64; else if (waves < (long) s.num_cus * 96) groups = 32; }
         if (groups < 1) groups = 1;
         if (groups > se - sb) groups = se - sb;
-        // mode of the uncounted launches: 2 = dynamic path assignment (k_render_paths: a wave hands the paths of its
-        // pixel block x strata range to whichever lane is free), 1 = one lane per pixel with a cost-ordered launch,
-        // 0 = one lane per pixel in tile order.  The counting launches always use 0.
-        static const int mode = [] { const char *e = getenv("JTX_DYNAMIC_PATHS"); return e ? atoi(e) : 2; }();
-        if (mode == 2 && !count) {
+        // uncounted launches: dynamic path assignment (k_render_paths: a wave hands the paths of its pixel block x strata
+        // range to whichever lane is free); JTX_DYNAMIC_PATHS=0 and the counting launches: one lane per pixel
+        static const int dynamicPaths = [] { const char *e = getenv("JTX_DYNAMIC_PATHS"); return e ? atoi(e) : 1; }();
+        if (dynamicPaths && !count) {
             // waves of ~1000 paths drain evenly (C2: 43.0 ms unsplit, 39.4 ms with the 64 strata in 4 groups; 1/8 shard:
             // 5.5 ms in 16 groups): the smallest power of two that gives >= 100 k waves, with >= 4 strata per group
             if (!getenv("JTX_STRATA_GROUPS")) {
@@ -636,21 +632,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
             HIPCHK(jtx_launch_resolve_samples(p, owned, stream));
         } else {
-            // Cost-ordered launch (mode 1): pixel blocks differ 3x and more in duration, so a frame of enough strata first
-            // renders ONE stratum while timing every block, sorts the blocks longest-first and lets the rest of the
-            // strata run in that order.  Sums are unaffected: the second pass resumes each pixel's accumulation.
-            const int nblocks = owned * (int) (1024 / JTX_RP_BLOCK);
-            if (mode == 1 && !count && se - sb >= 16 && nblocks >= s.num_cus * 8) {
-                if (s.block_cost.n < (size_t) nblocks) { s.block_cost.alloc(nblocks); s.block_order.alloc(nblocks); }
-                HIPCHK(hipMemsetAsync(s.block_cost.p, 0, nblocks * sizeof(unsigned), stream));
-                RenderParams a = p; a.sample_end = sb + 1; a.cost = s.block_cost.p; a.img = nullptr;
-                HIPCHK(jtx_launch_render_pixels(a, owned, false, stream));
-                HIPCHK(jtx_launch_sort_blocks(s.block_cost.p, s.block_order.p, nblocks, stream));
-                RenderParams b = p; b.sample_begin = sb + 1; b.order = s.block_order.p;
-                HIPCHK(jtx_launch_render_pixels(b, owned, false, stream));
-            } else {
-                HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
-            }
+            HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
         }
     }
     else if (integ == 3) HIPCHK(jtx_launch_render_wavepool(p, owned, count, stream));

@@ -21,7 +21,7 @@ namespace jtx {
 #define JTX_RP_OCC 7
 #endif
 #ifndef JTX_WIDE_OCC
-#define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
+#define JTX_WIDE_OCC 7          // waves per SIMD of the wide-traversal instances
 #endif
 constexpr int BLOCK = JTX_RP_BLOCK;          // threads per workgroup of the render / batch kernels
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
@@ -145,11 +145,10 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 
     // work mapping: block = 4 waves = 4 consecutive 8x8 sub-blocks of one owned 32x32 tile
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bid = p.order ? p.order[blockIdx.x] : (int) blockIdx.x;  // pixel block of this workgroup (cost-ordered launch)
+    const int bid = (int) blockIdx.x;
     const int owned = bid / BLOCKS_PER_TILE;                           // index into this rank's tiles
     const int tile = p.tile_rank + owned * p.tile_world;               // global 32x32 tile id, row-major (camera.cpp:55-64)
     const int sub = (bid % BLOCKS_PER_TILE) * WAVES_PER_BLOCK + wave;  // 0..15 sub-block inside the tile
-    const long long t_begin = p.cost ? clock64() : 0;
 #ifdef JTX_PROFILE_TIMELINE
     const long long tl0 = wall_clock64();
 #endif
@@ -217,7 +216,6 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         if (wid < 65536) { p.counters[64 + 2 * wid] = (unsigned long long) tl0; p.counters[64 + 2 * wid + 1] = (unsigned long long) wall_clock64(); }
     }
 #endif
-    if (p.cost && lane == 0) atomicMax(&p.cost[bid], (unsigned) min((long long) 0xffffffffu, clock64() - t_begin));
     if (COUNT) waveAddCounters(p.counters, cnt);
 #ifdef JTX_PROFILE_WIDE
     if (SRC == SRC_WIDE && p.counters) {   // diagnostic build: lane sums of the steps, lane 0's view of the wave iterations
@@ -268,7 +266,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
     if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bid = p.order ? p.order[blockIdx.x] : (int) blockIdx.x;
+    const int bid = (int) blockIdx.x;
     const int owned = bid / BPT;
     const int tile = p.tile_rank + owned * p.tile_world;
     const int sub = (bid % BPT) * WPB + wave;
@@ -278,7 +276,6 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     const int sEnd = sBegin + p.strata_per_group < p.sample_end ? sBegin + p.strata_per_group : p.sample_end;
     const int slot0 = owned * 1024 + sub * 64;
     const int nunits = (sEnd > sBegin && row0 < p.height && col0 < p.width) ? (sEnd - sBegin) * 64 : 0;
-    const long long t_begin = p.cost ? clock64() : 0;
     const unsigned long long below = (1ull << lane) - 1ull;
 #ifdef JTX_PROFILE_TIMELINE
     const long long tl0 = wall_clock64();
@@ -328,7 +325,6 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             }
         }
     }
-    if (p.cost && lane == 0) atomicMax(&p.cost[bid], (unsigned) min((long long) 0xffffffffu, clock64() - t_begin));
 #ifdef JTX_PROFILE_TIMELINE
     if (p.counters) {
         unsigned long long a = tl_active;
@@ -508,27 +504,6 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
 }
 } // namespace jtx
 
-// Longest-first launch order: a counting sort of the pixel blocks by the cost a one-stratum pass measured.  One
-// workgroup; 1024 cost classes between the minimum and the maximum are plenty for list scheduling.
-namespace jtx {
-__global__ void __launch_bounds__(1024) k_sort_blocks(const unsigned *cost, int *order, int n) {
-    __shared__ unsigned hist[1024];
-    __shared__ unsigned lo, hi;
-    if (threadIdx.x == 0) { lo = 0xffffffffu; hi = 0u; }
-    hist[threadIdx.x] = 0u;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) { atomicMin(&lo, cost[i]); atomicMax(&hi, cost[i]); }
-    __syncthreads();
-    const float scale = hi > lo ? 1023.0f / (float) (hi - lo) : 0.0f;
-    auto cls = [&](unsigned c) { return 1023 - (int) ((float) (c - lo) * scale); };      // class 0 = most expensive
-    for (int i = threadIdx.x; i < n; i += 1024) atomicAdd(&hist[cls(cost[i])], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) { unsigned run = 0; for (int k = 0; k < 1024; ++k) { const unsigned c = hist[k]; hist[k] = run; run += c; } }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&hist[cls(cost[i])], 1u)] = i;
-}
-} // namespace jtx
-
 hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const bool lds = p.scene.lds_threaded != 0;
@@ -543,12 +518,6 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, h
     if (lambert) { if (lds) LAUNCH_PA(SRC_LDS, MAT_DIFFUSE_ONLY, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_DIFFUSE_ONLY, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_DIFFUSE_ONLY, SMALL); }
     else         { if (lds) LAUNCH_PA(SRC_LDS, MAT_ALL, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_ALL, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_ALL, SMALL); }
 #undef LAUNCH_PA
-    return hipGetLastError();
-}
-
-hipError_t jtx_launch_sort_blocks(const unsigned *cost, int *order, int n, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sort_blocks, dim3(1), dim3(1024), 0, stream, cost, order, n);
     return hipGetLastError();
 }
 

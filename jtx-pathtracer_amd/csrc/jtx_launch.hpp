@@ -22,9 +22,6 @@ struct RenderParams {
     // clamped per-sample radiance to rad[(s - sample_begin) * rad_stride + owned pixel slot]; k_resolve_samples
     // then adds them to the film in sample order
     float4 *rad; int strata_per_group; int rad_stride;
-    // cost-ordered launch (k_render_pixels): workgroup i of the grid takes pixel block order[i] (null: i); a pass with
-    // `cost` set records every pixel block's duration there (max over its waves, clock64 ticks)
-    const int *order; unsigned *cost;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
@@ -67,7 +64,6 @@ hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, hipStream_t stream);
-hipError_t jtx_launch_sort_blocks(const unsigned *cost, int *order, int n, hipStream_t stream);
 hipError_t jtx_launch_resolve_samples(const jtx::RenderParams &p, int num_owned_tiles, hipStream_t stream);
 hipError_t jtx_launch_render_fused(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_wavepool(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
