@@ -34,6 +34,7 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+constexpr size_t kMaxRadBytes = (size_t) 8 << 30;   // per-path radiance buffer of one pass (k_render_paths); env JTX_MAX_RAD_MB overrides
 constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + tris staged in LDS when they fit this (8 blocks/CU)
 
 } // namespace
@@ -614,15 +615,25 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 const int cap = (se - sb) / 4 > 1 ? (se - sb) / 4 : 1;
                 while ((long) groups * waves < 100000 && groups * 2 <= cap) groups *= 2;
             }
-            p.strata_per_group = (se - sb + groups - 1) / groups;
             p.rad_stride = owned * 1024;
-            const size_t need = (size_t) p.rad_stride * (size_t) (se - sb);
+            // the per-path radiance buffer holds (strata of a pass) x (owned pixels) x 16 B: a frame that would need more
+            // than kMaxRadBytes goes in several passes of consecutive strata (the resolve continues the sums in order)
+            size_t maxRad = kMaxRadBytes;
+            { const char *e = getenv("JTX_MAX_RAD_MB"); if (e && atol(e) > 0) maxRad = (size_t) atol(e) << 20; }
+            const long perPass = (long) (maxRad / ((size_t) p.rad_stride * sizeof(float4)));
+            const int chunk = perPass >= se - sb ? se - sb : (perPass > 1 ? (int) perPass : 1);
+            const size_t need = (size_t) p.rad_stride * (size_t) chunk;
             if (s.rad.n < need) s.rad.alloc(need);
             p.rad = s.rad.p;
-            HIPCHK(jtx_launch_render_paths(p, owned, stream));
-            HIPCHK(hipEventRecord(ev.second, stream));                 // jtx_mi_kernel_time = the dominant kernel alone
-            evClosed = true;
-            HIPCHK(jtx_launch_resolve_samples(p, owned, stream));
+            for (int b0 = sb; b0 < se; b0 += chunk) {
+                RenderParams q = p;
+                q.sample_begin = b0; q.sample_end = b0 + chunk < se ? b0 + chunk : se;
+                int g = groups; if (g > q.sample_end - q.sample_begin) g = q.sample_end - q.sample_begin;
+                q.strata_per_group = (q.sample_end - q.sample_begin + g - 1) / g;
+                HIPCHK(jtx_launch_render_paths(q, owned, stream));
+                if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
+                HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
+            }
         } else if (groups > 1) {
             p.strata_per_group = (se - sb + groups - 1) / groups;
             p.rad_stride = owned * 1024;

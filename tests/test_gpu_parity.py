@@ -758,3 +758,18 @@ def test_wide_bvh_on_a_deep_degenerate_tree(gpu):
     assert (cam_g.img_ == img).all()
     cam_g.render(sc, count_rays=False, integrator=2)                  # the wavefront trace kernels use the same stack
     assert_same_f32(cam_g.acc_, acc, "deep tree, wavefront")
+
+
+def test_radiance_buffer_cap_renders_in_passes(gpu, cornell_pair, monkeypatch):
+    """k_render_paths keeps one 16-byte record per path of a pass; frames whose records would not fit the cap go in
+    several passes of consecutive strata (here: 1 MB -> 2 of 16 strata per pass), the resolve continuing the sums"""
+    data, sc, osc = cornell_pair
+    monkeypatch.setenv("JTX_MAX_RAD_MB", "1")
+    cam_g = gpu.StaticCamera(200, 120, data.camera, 4, 4, 4)
+    cam_g.render(sc, count_rays=False, integrator=1)
+    acc, img, _ = osc.render(data.camera_desc(200, 120, 4, 4, 4), count=False)
+    assert_same_f32(cam_g.acc_, acc, "multi-pass frame")
+    assert (cam_g.img_ == img).all()
+    cam_g.render(sc, count_rays=False, integrator=1, sample_begin=0, sample_end=7)      # and a partial range, odd length
+    cam_g.render(sc, count_rays=False, integrator=1, sample_begin=7, sample_end=16)
+    assert_same_f32(cam_g.acc_, acc, "multi-pass frame, resumed")
