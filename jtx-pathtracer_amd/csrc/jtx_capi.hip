@@ -612,7 +612,8 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             // 5.5 ms in 16 groups): the smallest power of two that gives >= 100 k waves, with >= 4 strata per group
             if (!getenv("JTX_STRATA_GROUPS")) {
                 groups = 1;
-                const int cap = (se - sb) / 4 > 1 ? (se - sb) / 4 : 1;
+                int cap = (se - sb) / 4 > 1 ? (se - sb) / 4 : 1;
+                if ((long) cap * waves < 50000) cap = se - sb;          // small frames (C1: 512^2 x 16 spp): one stratum per wave if need be
                 while ((long) groups * waves < 100000 && groups * 2 <= cap) groups *= 2;
             }
             p.rad_stride = owned * 1024;
