@@ -49,6 +49,7 @@ struct jtx_mi_scene {
     DevBuf<float> texels;
     DevBuf<unsigned long long> counters;
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
+    DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;
     DevScene dev{};
@@ -594,6 +595,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     if (integ == 0) integ = autoIntegrator(s);
     auto ev = takeEvents(s);
     bool evClosed = false;
+    static unsigned workSlot = 0;
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) {
         // strata groups: the strata of a pixel block are spread over `groups` waves (gridDim.y); every path's clamped
@@ -608,13 +610,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         // range to whichever lane is free); JTX_DYNAMIC_PATHS=0 and the counting launches: one lane per pixel
         static const int dynamicPaths = [] { const char *e = getenv("JTX_DYNAMIC_PATHS"); return e ? atoi(e) : 1; }();
         if (dynamicPaths && !count) {
-            // waves of ~1000 paths drain evenly (C2: 43.0 ms unsplit, 39.4 ms with the 64 strata in 4 groups; 1/8 shard:
-            // 5.5 ms in 16 groups): the smallest power of two that gives >= 100 k waves, with >= 4 strata per group
+            // chunk = (8x8 pixel block, strata group) = 64 x strata paths, fetched by persistent waves: ~250 k chunks per
+            // launch keep the end of the launch short at every shard size (C2: 1 group 44.2 ms, 8 groups 38.1 ms;
+            // 1/8 shard: 64 groups 5.5 ms): the smallest power of two that gives that many, at most one group per stratum
             if (!getenv("JTX_STRATA_GROUPS")) {
                 groups = 1;
-                int cap = (se - sb) / 4 > 1 ? (se - sb) / 4 : 1;
-                if ((long) cap * waves < 50000) cap = se - sb;          // small frames (C1: 512^2 x 16 spp): one stratum per wave if need be
-                while ((long) groups * waves < 100000 && groups * 2 <= cap) groups *= 2;
+                while ((long) groups * waves < 250000 && groups * 2 <= se - sb) groups *= 2;
             }
             p.rad_stride = owned * 1024;
             // the per-path radiance buffer holds (strata of a pass) x (owned pixels) x 16 B: a frame that would need more
@@ -631,7 +632,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.sample_begin = b0; q.sample_end = b0 + chunk < se ? b0 + chunk : se;
                 int g = groups; if (g > q.sample_end - q.sample_begin) g = q.sample_end - q.sample_begin;
                 q.strata_per_group = (q.sample_end - q.sample_begin + g - 1) / g;
-                HIPCHK(jtx_launch_render_paths(q, owned, stream));
+                q.num_groups = (q.sample_end - q.sample_begin + q.strata_per_group - 1) / q.strata_per_group;
+                q.num_subblocks = owned * 16;
+                if (!s.work.p) s.work.alloc(64);
+                q.work = s.work.p + (workSlot++ & 63);                 // one counter per launch in flight
+                HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
+                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }

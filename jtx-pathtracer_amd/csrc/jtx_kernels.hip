@@ -253,30 +253,23 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 // radiance (camera.cpp:110-112) to rad[stratum][pixel] and k_resolve_samples adds them to the film in sample order,
 // so the sums are those of AccumulationBuffer::updatePixel bit for bit.  Costs 32 B of HBM traffic per path.
 // ------------------------------------------------------------------------------------------------
-// BS = workgroup size: 256 when the scene is staged in LDS (one copy per 4 waves), 64 otherwise -- single-wave workgroups
-// start as soon as one wave slot is free (C3 414 -> 394 ms, C5 372 -> 344 ms).
+// BS = workgroup size: 256 when the scene is staged in LDS (one copy per 4 waves), 64 otherwise.
+// The grid is PERSISTENT: as many workgroups as fit the GPU; a wave whose chunk -- one 8x8 pixel block x one strata
+// group, 64 x strata paths, handed out stratum-major -- runs dry takes the next chunk from a global counter at once,
+// while its other lanes are still finishing paths of the previous chunk: no wave ever drains except at the very end
+// of the launch (a wave of 4 paths per lane lost ~12 % to its own drain), and the scene is staged once per workgroup.
 template <int SRC, int MASK, int BS>
 __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) k_render_paths(RenderParams p) {
     static_assert(SRC != SRC_LDS || BS == BLOCK, "stageScene strides by BLOCK");
-    constexpr int WPB = BS / 64, BPT = 16 / WPB;          // waves per workgroup, workgroups per 32x32 tile
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr bool LDS_SCENE = SRC == SRC_LDS;
     const DevScene &sc = p.scene;
     float4 *lds_tnodes = (float4 *) smem;
     float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
     if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bid = (int) blockIdx.x;
-    const int owned = bid / BPT;
-    const int tile = p.tile_rank + owned * p.tile_world;
-    const int sub = (bid % BPT) * WPB + wave;
-    const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
-    const int row0 = trow * 32 + (sub >> 2) * 8, col0 = tcol * 32 + (sub & 3) * 8;
-    const int sBegin = p.sample_begin + (int) blockIdx.y * p.strata_per_group;
-    const int sEnd = sBegin + p.strata_per_group < p.sample_end ? sBegin + p.strata_per_group : p.sample_end;
-    const int slot0 = owned * 1024 + sub * 64;
-    const int nunits = (sEnd > sBegin && row0 < p.height && col0 < p.width) ? (sEnd - sBegin) * 64 : 0;
+    const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
+    const int nchunks = p.num_subblocks * p.num_groups;
 #ifdef JTX_PROFILE_TIMELINE
     const long long tl0 = wall_clock64();
     unsigned tl_iters = 0, tl_active = 0;
@@ -284,20 +277,45 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
 
     Counters9 cnt = {};
     PathState ps;
-    int next = 0;                                   // wave-uniform: first path not handed out yet
-    int s = 0, pl = 0;                              // this lane's current path: stratum, pixel of the block
+    // the wave's current chunk (all wave-uniform)
+    int next = 0, nunits = 0;                      // paths handed out / in the chunk
+    int row0 = 0, col0 = 0, slot0 = 0, sBegin = 0;
+    bool exhausted = false;
+    int s = 0, slot = 0;                           // this lane's current path: stratum, pixel slot in the rank's frame
     bool alive = false, need = true;
     while (true) {
-        // ---- hand out paths to the lanes that need one (everybody takes part: `next` must stay uniform) ----
+        // ---- hand out paths to the lanes that need one ----
         while (true) {
             const unsigned long long mask = __ballot(need);
-            if (mask == 0ull || next >= nunits) break;
+            if (mask == 0ull) break;
+            if (next >= nunits) {                                        // chunk used up: fetch the next one
+                if (exhausted) { need = false; break; }
+                int c = 0;
+                if (lane == 0) c = (int) atomicAdd(p.work, 1u);
+                c = __shfl(c, 0, 64);
+                if (c >= nchunks) { exhausted = true; need = false; break; }
+                // chunk c: strata group-major, so that the whole frame advances stratum range by stratum range
+                const int grp = c / p.num_subblocks, sb8 = c - grp * p.num_subblocks;      // 8x8 block index of this rank
+                const int owned = sb8 >> 4, sub = sb8 & 15;
+                const int tile = p.tile_rank + owned * p.tile_world;
+                const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
+                row0 = trow * 32 + (sub >> 2) * 8; col0 = tcol * 32 + (sub & 3) * 8;
+                slot0 = owned * 1024 + sub * 64;
+                sBegin = p.sample_begin + grp * p.strata_per_group;
+                const int sEnd = sBegin + p.strata_per_group < p.sample_end ? sBegin + p.strata_per_group : p.sample_end;
+                nunits = (sEnd > sBegin && row0 < p.height && col0 < p.width) ? (sEnd - sBegin) * 64 : 0;
+                next = 0;
+                continue;
+            }
             const int u = next + __popcll(mask & below);
             next += __popcll(mask);
             if (need && u < nunits) {
-                s = sBegin + (u >> 6); pl = u & 63;
+                const int pl = u & 63;
                 const int row = row0 + (pl >> 3), col = col0 + (pl & 7);
-                if (row < p.height && col < p.width) { startPath(p.cam, row, col, s, ps); alive = true; need = false; }
+                if (row < p.height && col < p.width) {
+                    s = sBegin + (u >> 6); slot = slot0 + pl;
+                    startPath(p.cam, row, col, s, ps); alive = true; need = false;
+                }
             }
         }
         need = false;
@@ -320,7 +338,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                 if (c.x > 1.0f) c.x = 1.0f;
                 if (c.y > 1.0f) c.y = 1.0f;
                 if (c.z > 1.0f) c.z = 1.0f;
-                p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot0 + pl] = make_float4(c.x, c.y, c.z, 0.0f);
+                p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot] = make_float4(c.x, c.y, c.z, 0.0f);
                 alive = false; need = true;
             }
         }
@@ -330,7 +348,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
         unsigned long long a = tl_active;
         for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
         if (lane == 0) {
-            const int wid = ((int) blockIdx.y * (int) gridDim.x + bid) * WPB + wave;
+            const int wid = (int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6);
             if (wid < 65536) { p.counters[64 + 2 * wid] = (unsigned long long) tl0; p.counters[64 + 2 * wid + 1] = (unsigned long long) wall_clock64(); }
             atomicAdd(&p.counters[40], (unsigned long long) tl_iters); atomicAdd(&p.counters[41], a);
         }
@@ -504,7 +522,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
 }
 } // namespace jtx
 
-hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, hipStream_t stream) {
+hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const bool lds = p.scene.lds_threaded != 0;
     const bool wide = !lds && p.scene.wide != nullptr;
@@ -512,8 +530,12 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, h
     const int bs = lds ? BLOCK : SMALL;
     const size_t shmem = wide ? (size_t) p.scene.wide_depth * bs * sizeof(uint2) : ldsBytes(p.scene, lds);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
-    const int groups = (p.sample_end - p.sample_begin + p.strata_per_group - 1) / p.strata_per_group;
-    const dim3 grid((unsigned) num_owned_tiles * (unsigned) (1024 / bs), (unsigned) groups), block(bs);
+    // persistent grid: the waves the GPU can hold (occupancy of the launch bounds), no more than there are chunks
+    const int occ = wide ? JTX_WIDE_OCC : JTX_RP_OCC;
+    long waves = (long) num_cus * 4 * occ;
+    const long chunks = (long) p.num_subblocks * p.num_groups;
+    if (waves > chunks) waves = chunks;
+    const dim3 grid((unsigned) ((waves * 64 + bs - 1) / bs)), block(bs);
 #define LAUNCH_PA(L, M, B) hipLaunchKernelGGL((k_render_paths<L, M, B>), grid, block, shmem, stream, p)
     if (lambert) { if (lds) LAUNCH_PA(SRC_LDS, MAT_DIFFUSE_ONLY, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_DIFFUSE_ONLY, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_DIFFUSE_ONLY, SMALL); }
     else         { if (lds) LAUNCH_PA(SRC_LDS, MAT_ALL, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_ALL, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_ALL, SMALL); }

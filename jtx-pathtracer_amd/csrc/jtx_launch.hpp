@@ -22,6 +22,8 @@ struct RenderParams {
     // clamped per-sample radiance to rad[(s - sample_begin) * rad_stride + owned pixel slot]; k_resolve_samples
     // then adds them to the film in sample order
     float4 *rad; int strata_per_group; int rad_stride;
+    // k_render_paths: persistent waves take (8x8 pixel block, strata group) chunks from this counter (zeroed per launch)
+    unsigned *work; int num_subblocks; int num_groups;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
@@ -63,7 +65,7 @@ hipError_t jtx_wf_shade(const jtx::WfParams &p, int grid, bool count, int typeCo
 hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write_img, hipStream_t st);
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
-hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, hipStream_t stream);
+hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
 hipError_t jtx_launch_resolve_samples(const jtx::RenderParams &p, int num_owned_tiles, hipStream_t stream);
 hipError_t jtx_launch_render_fused(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_wavepool(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
