@@ -243,13 +243,13 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_render_paths: pixel block x strata range with DYNAMIC PATH ASSIGNMENT (uncounted kernels).
+// k_render_paths: DYNAMIC PATH ASSIGNMENT (uncounted kernels).
 // In k_render_pixels a lane owns one pixel and a wave ends when its most expensive pixel does: wave timelines of the
 // C2 launch show ~30 % of the lane time idle at the end of the waves (pixel costs differ 3x inside an 8x8 block), and
-// halving the strata per lane raises the total wave time by 17 %.  Here the unit of work is ONE PATH: a wave owns
-// the (sEnd - sBegin) x 64 paths of an 8x8 pixel block and hands them out from a wave-local counter (a ballot and a
-// prefix count: no atomics) -- stratum-major, so the 64 lanes start with the 64 coherent camera rays of one stratum
-// and a lane whose path ends takes the next path, whatever pixel it belongs to.  Every path writes its clamped
+// halving the strata per lane raises the total wave time by 17 %.  Here the unit of work is ONE PATH: a wave holds
+// a chunk = the strata-group x 64 paths of an 8x8 pixel block and hands them out from a wave-local counter (a ballot
+// and a prefix count) -- stratum-major, so 64 lanes start with the 64 coherent camera rays of one stratum and a
+// lane whose path ends takes the next path, whatever pixel it belongs to.  Every path writes its clamped
 // radiance (camera.cpp:110-112) to rad[stratum][pixel] and k_resolve_samples adds them to the film in sample order,
 // so the sums are those of AccumulationBuffer::updatePixel bit for bit.  Costs 32 B of HBM traffic per path.
 // ------------------------------------------------------------------------------------------------
