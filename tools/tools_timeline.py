@@ -8,7 +8,7 @@ data = jtx.scenes.cornell(); sc = jtx.Scene(data); sc.buildBVH()
 cam = jtx.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
 cam.render(sc, count_rays=False, integrator=1)
 cam.render(sc, count_rays=False, integrator=1)
-n = int(os.environ.get('TL_WAVES', '32640'))
+n = int(os.environ.get('TL_WAVES', '7168'))    # persistent grid of k_render_paths; 32640 with JTX_DYNAMIC_PATHS=0 (one wave per pixel block)
 buf = (C.c_uint64 * (2 * n))()
 f = lib.jtx_mi_debug_timeline; f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
 assert f(sc.handle, buf, n) == 0
@@ -24,8 +24,9 @@ print("resident waves over time (40 bins):", " ".join(str(int(x)) for x in occ))
 work = dur.sum()
 print(f"wave-ms of work {work:.0f}; at 7168 resident waves that is {work / 7168:.2f} ms -> schedule efficiency {work / 7168 / total:.3f}")
 # by tile row: where the long waves are
-rows = ((np.arange(n) % 32640) // 16) // 60
-print("mean wave duration by tile row (34 rows, bottom to top):", " ".join(f"{dur[rows == r].mean():.1f}" for r in range(34)))
+if n == 32640:
+    rows = (np.arange(n) // 16) // 60
+    print("mean wave duration by tile row (34 rows, bottom to top):", " ".join(f"{dur[rows == r].mean():.1f}" for r in range(34)))
 late = t[:, 1] > 0.85 * t[:, 1].max()
 print(f"waves ending in the last 15 % of the launch: {late.sum()}; their start (ms) p10/p50/p90 = "
       + "/".join(f"{np.percentile(t[late, 0] * tick, q):.1f}" for q in (10, 50, 90))
