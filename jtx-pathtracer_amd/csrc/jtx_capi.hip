@@ -49,7 +49,8 @@ struct jtx_mi_scene {
     DevBuf<float> texels;
     DevBuf<unsigned long long> counters;
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
-    DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches
+    DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (64, used round-robin)
+    unsigned work_slot = 0;
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;
     DevScene dev{};
@@ -595,7 +596,6 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     if (integ == 0) integ = autoIntegrator(s);
     auto ev = takeEvents(s);
     bool evClosed = false;
-    static unsigned workSlot = 0;
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) {
         // strata groups: the strata of a pixel block are spread over `groups` waves (gridDim.y); every path's clamped
@@ -635,7 +635,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.num_groups = (q.sample_end - q.sample_begin + q.strata_per_group - 1) / q.strata_per_group;
                 q.num_subblocks = owned * 16;
                 if (!s.work.p) s.work.alloc(64);
-                q.work = s.work.p + (workSlot++ & 63);                 // one counter per launch in flight
+                q.work = s.work.p + (s.work_slot++ & 63);                 // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
                 HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
