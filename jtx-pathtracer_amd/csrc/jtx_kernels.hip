@@ -6,6 +6,10 @@
 //                      atomics and no resolve pass; a lane whose path ends starts its next stratum
 //                      at once (in-lane path regeneration), which keeps all 64 lanes of a wave busy
 //                      although path lengths differ.  One wave = one 8x8 pixel block.
+//                      Used by the counting launches (and JTX_DYNAMIC_PATHS=0).
+//  k_render_paths    : the timed kernel.  Persistent waves fetch (8x8 pixel block, strata group) chunks and hand
+//                      their paths to whichever lane is free; per-path radiance -> rad[stratum][pixel].
+//  k_resolve_samples : adds the per-path radiances to the film in sample order (same float sums).
 //  k_*_batch         : per-ray / per-sample entry points used by the parity tests.
 //
 // Compiled with -ffp-contract=off: results must equal the CPU oracle bit for bit.
