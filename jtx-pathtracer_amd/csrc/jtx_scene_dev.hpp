@@ -235,10 +235,10 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 // pending positions} in LDS.  A stale hit bit (t.max shrank since the node was tested) only
 // costs a visit.  Irregular rays (a zero / non-finite direction component ...) take the exact binary path.
 #ifndef JTX_WIDE_LEAF_VOTE
-#define JTX_WIDE_LEAF_VOTE 4
+#define JTX_WIDE_LEAF_VOTE 16
 #endif
 #ifndef JTX_WIDE_FEW_WALKERS
-#define JTX_WIDE_FEW_WALKERS 8
+#define JTX_WIDE_FEW_WALKERS 16
 #endif
 #ifndef JTX_WIDE_STEPS
 #define JTX_WIDE_STEPS 1
