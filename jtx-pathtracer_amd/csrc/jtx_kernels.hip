@@ -25,7 +25,7 @@ namespace jtx {
 #define JTX_RP_OCC 7
 #endif
 #ifndef JTX_WIDE_OCC
-#define JTX_WIDE_OCC 7          // waves per SIMD of the wide-traversal instances
+#define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
 #endif
 constexpr int BLOCK = JTX_RP_BLOCK;          // threads per workgroup of the render / batch kernels
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
