@@ -773,3 +773,42 @@ def test_radiance_buffer_cap_renders_in_passes(gpu, cornell_pair, monkeypatch):
     cam_g.render(sc, count_rays=False, integrator=1, sample_begin=0, sample_end=7)      # and a partial range, odd length
     cam_g.render(sc, count_rays=False, integrator=1, sample_begin=7, sample_end=16)
     assert_same_f32(cam_g.acc_, acc, "multi-pass frame, resumed")
+
+
+@pytest.mark.parametrize("seed,max_prims", [(11, 1), (12, 1), (13, 4)])
+def test_uncounted_random_triangle_soups(gpu, seed, max_prims):
+    """no structure to lean on: thousands of overlapping random triangles of very different sizes, the four material
+    types, a point and a distant light -- the timed kernels (wide BVH, dynamic path assignment) against the oracle,
+    both integrators that have uncounted wide paths"""
+    sc_ = gpu.scenes
+    rs = np.random.RandomState(seed)
+    n = 4000
+    c = rs.uniform(-10, 10, (n, 3))
+    size = np.exp(rs.uniform(np.log(0.05), np.log(5.0), (n, 1, 1)))
+    tri = (c[:, None, :] + rs.normal(size=(n, 3, 3)) * size).astype(np.float32)
+    s = sc_.SceneData("soup")
+    s.materials = [sc_.material(sc_.DIFFUSE, (0.7, 0.5, 0.3)),
+                   sc_.material(sc_.CONDUCTOR, ior=sc_.GOLD_IOR, k=sc_.GOLD_K, alpha_x=0.2, alpha_y=0.1),
+                   sc_.material(sc_.DIELECTRIC, ior=(1.5, 1.5, 1.5), alpha_x=0.0, alpha_y=0.0),
+                   sc_.material(sc_.METALLIC_ROUGHNESS, (0.4, 0.6, 0.8), alpha_x=0.3, alpha_y=0.5)]
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+    for m in range(4):
+        sel = np.arange(n) % 4 == m
+        v = tri[sel].reshape(-1, 3)
+        nrm = np.repeat(fn[sel], 3, axis=0).astype(np.float32)
+        s.add_mesh(np.arange(len(v), dtype=np.int32).reshape(-1, 3), v, nrm, m)
+    s.lights = [sc_.light(sc_.POINT, (3.0, 14.0, 5.0), (1, 1, 1), 400.0), sc_.light(sc_.DISTANT, (0.2, -1.0, 0.3), (1, 0.9, 0.8), 1.0)]
+    s.sky = (0.4, 0.5, 0.7)
+    s.camera = dict(center=(0.0, 2.0, 32.0), target=(0.0, 0.0, 0.0), up=(0, 1, 0), yfov=40.0, defocus_angle=0.0, focus_distance=1.0)
+    s.max_prims_in_node = max_prims
+    sc = gpu.Scene(s); sc.buildBVH(max_prims)
+    assert sc.info()["wide_depth"] >= 3
+    osc = ol.OracleScene(s)
+    acc, img, cnt = osc.render(s.camera_desc(144, 96, 2, 2, 6))
+    assert cnt["n_accept"] > 20000 and cnt["n_any"] > 10000
+    for integrator in (1, 2):
+        cam_g = gpu.StaticCamera(144, 96, s.camera, 2, 2, 6)
+        cam_g.render(sc, count_rays=False, integrator=integrator)
+        assert_same_f32(cam_g.acc_, acc, f"soup seed {seed}, integrator {integrator}")
+        assert (cam_g.img_ == img).all()
