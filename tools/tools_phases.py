@@ -3,8 +3,9 @@ import ctypes as C, sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jtx_pathtracer_amd as jtx
 lib = jtx._capi.load()
-data = jtx.scenes.cornell(); sc = jtx.Scene(data); sc.buildBVH()
-cam = jtx.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+which = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+data = getattr(jtx.scenes, which)(); sc = jtx.Scene(data); sc.buildBVH()
+cam = jtx.StaticCamera(1920, 1080, data.camera, 4, 4, 8)
 cam.render(sc, count_rays=True)
 f = lib.jtx_mi_debug_phases; f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 out = (C.c_uint64 * 6)()
