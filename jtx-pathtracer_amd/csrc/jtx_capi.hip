@@ -34,6 +34,19 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+// Every scene lives on the device that was current at jtx_mi_scene_create; the current HIP device is per THREAD
+// (DynamicCamera's worker thread never called hipSetDevice), so each scene-taking entry point switches to the
+// scene's device for its duration and restores the caller's.
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { HIPCHK(hipSetDevice(dev)); switched = true; }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void) hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete; DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 constexpr size_t kMaxRadBytes = (size_t) 8 << 30;   // per-path radiance buffer of one pass (k_render_paths); env JTX_MAX_RAD_MB overrides
 constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + tris staged in LDS when they fit this (8 blocks/CU)
 
@@ -594,7 +607,13 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     if (o.integrator < 0 || o.integrator > 4) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront), 3 (wave-pool) or 4 (pixel-persistent, fused rays)");
     int integ = o.integrator;
     if (integ == 0) integ = autoIntegrator(s);
+    // timing pairs are only drained by jtx_mi_kernel_time (bench / tools): a UI that never asks keeps the newest 64
+    while (s.pending.size() >= 64 && hipEventQuery(s.pending.front().second) == hipSuccess) {
+        s.free_events.push_back(s.pending.front()); s.pending.erase(s.pending.begin());
+    }
     auto ev = takeEvents(s);
+    struct EvReturn { jtx_mi_scene &s; std::pair<hipEvent_t, hipEvent_t> ev; bool armed = true;
+                      ~EvReturn() { if (armed) s.free_events.push_back(ev); } } evGuard{s, ev};   // a throw below must not leak the pair
     bool evClosed = false;
     HIPCHK(hipEventRecord(ev.first, stream));
     if (integ == 1) {
@@ -657,6 +676,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     else if (integ == 4) HIPCHK(jtx_launch_render_fused(p, owned, count, stream));
     else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
     if (!evClosed) HIPCHK(hipEventRecord(ev.second, stream));
+    evGuard.armed = false;
     s.pending.push_back(ev);
 }
 
@@ -733,8 +753,11 @@ int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
 
 void jtx_mi_scene_destroy(jtx_mi_scene *scene) {
     if (!scene) return;
+    int prev = -1;
+    const bool sw = hipGetDevice(&prev) == hipSuccess && prev != scene->device && hipSetDevice(scene->device) == hipSuccess;
     if (scene->stream) (void) hipStreamSynchronize(scene->stream);
     delete scene;
+    if (sw) (void) hipSetDevice(prev);
 }
 
 int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
@@ -756,6 +779,7 @@ int jtx_mi_render_device(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const j
                          void *d_acc_rgb, void *d_img_rgb, void *stream) {
     try {
         if (!s || !cam || !d_acc_rgb) throw std::runtime_error("null argument");
+        DeviceGuard dg(s->device);
         checkCamera(*cam);
         jtx_mi_render_opts o{}; if (opts) o = *opts;
         const int spp = cam->x_pixel_samples * cam->y_pixel_samples;
@@ -775,16 +799,19 @@ int jtx_mi_render_device(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const j
 
 int jtx_mi_sync(jtx_mi_scene *s) {
     if (!s) return fail("null scene");
-    hipError_t e = hipStreamSynchronize(s->stream);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) return fail(std::string("sync: ") + hipGetErrorString(e));
-    return 0;
+    try {
+        DeviceGuard dg(s->device);
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipDeviceSynchronize());
+        return 0;
+    } catch (const std::exception &e) { return fail(std::string("sync: ") + e.what()); }
 }
 
 int jtx_mi_kernel_time(jtx_mi_scene *s, float *ms_total, int32_t *launches) {
     try {
         if (!s) throw std::runtime_error("null scene");
         std::lock_guard<std::mutex> lk(s->mu);
+        DeviceGuard dg(s->device);
         float total = 0; int n = 0;
         for (auto &e : s->pending) {
             HIPCHK(hipEventSynchronize(e.second));
@@ -849,6 +876,7 @@ int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
     try {
         if (!s || !out) throw std::runtime_error("null argument");
         if (!s->counters.p) throw std::runtime_error("no counted render has run (opts.count_rays)");
+        DeviceGuard dg(s->device);
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipDeviceSynchronize());
         unsigned long long h[9];
@@ -863,6 +891,7 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                   float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user) {
     try {
         if (!s || !cam || !acc_rgb) throw std::runtime_error("null argument");
+        DeviceGuard dg(s->device);
         checkCamera(*cam);
         jtx_mi_render_opts o{}; if (opts) o = *opts;
         const int spp = cam->x_pixel_samples * cam->y_pixel_samples;
@@ -929,6 +958,7 @@ int jtx_mi_closest_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const f
                              float *uv) {
     try {
         if (!s || n < 0 || (n && (!o || !d))) throw std::runtime_error("bad argument");
+        DeviceGuard dg(s->device);
         if (n == 0) return 0;
         Tmp<float> dO(o, 3 * (size_t) n), dD(d, 3 * (size_t) n), dT(n), dB1(n), dB2(n), dP(3 * (size_t) n), dN(3 * (size_t) n), dUV(2 * (size_t) n);
         Tmp<int> dHit(n), dPrim(n);
@@ -943,6 +973,7 @@ int jtx_mi_any_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const float
                          int32_t *hit) {
     try {
         if (!s || n < 0 || (n && (!o || !d || !tmin || !tmax || !hit))) throw std::runtime_error("bad argument");
+        DeviceGuard dg(s->device);
         if (n == 0) return 0;
         Tmp<float> dO(o, 3 * (size_t) n), dD(d, 3 * (size_t) n), dA(tmin, n), dB(tmax, n);
         Tmp<int> dHit(n);
@@ -958,6 +989,7 @@ static int bxdfBatch(jtx_mi_scene *s, int mode, int32_t material, int32_t n, con
     try {
         if (!s || n < 0 || (n && (!normal || !wo))) throw std::runtime_error("bad argument");
         if (material < 0 || material >= s->dev.num_materials) throw std::runtime_error("material out of range");
+        DeviceGuard dg(s->device);
         if (n == 0) return 0;
         const size_t N = (size_t) n;
         Tmp<float> dN(normal, 3 * N), dUV(uv, uv ? 2 * N : 0), dWo(wo, 3 * N), dWi(wi_in, wi_in ? 3 * N : 0), dUc(uc, uc ? N : 0),
@@ -1005,6 +1037,7 @@ int jtx_mi_radiance_samples(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, int3
                             const int32_t *sample, float *rgb) {
     try {
         if (!s || !cam || n < 0 || (n && (!row || !col || !sample || !rgb))) throw std::runtime_error("bad argument");
+        DeviceGuard dg(s->device);
         checkCamera(*cam);
         if (n == 0) return 0;
         Tmp<int> dR(row, n), dC(col, n), dS(sample, n);

@@ -177,9 +177,21 @@ def _buffers(doc, bin_chunk, base):
         elif uri.startswith("data:"):
             out.append(base64.b64decode(uri.split(",", 1)[1]))
         else:
-            with open(os.path.join(base, uri), "rb") as f:
+            with open(_external(base, uri), "rb") as f:
                 out.append(f.read())
     return out
+
+
+def _external(base, uri):
+    """Path of an external buffer / image URI of a .gltf file: percent-decoded, relative, and inside the asset's own
+    directory -- a scene file is untrusted input and must not name /etc/passwd or ../../x."""
+    from urllib.parse import unquote
+    rel = unquote(uri)
+    root = os.path.realpath(base or ".")
+    full = os.path.realpath(os.path.join(root, rel))
+    if os.path.isabs(rel) or "://" in uri or os.path.commonpath([root, full]) != root:
+        raise ValueError(f"glTF external URI escapes the asset directory: {uri!r}")
+    return full
 
 
 def _accessor(doc, bufs, i):
@@ -227,7 +239,7 @@ def _image_bytes(doc, bufs, base, img):
     if uri.startswith("data:"):
         import base64
         return base64.b64decode(uri.split(",", 1)[1]), uri[5:uri.index(";")]
-    with open(os.path.join(base, uri), "rb") as f:
+    with open(_external(base, uri), "rb") as f:
         return f.read(), img.get("mimeType", "")
 
 

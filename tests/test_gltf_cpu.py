@@ -207,3 +207,21 @@ def test_create_scene_transform_applies_to_first_mesh_only(tmp_path):
     s = scenes.create_scene(path, transform=t, background=(0.1, 0.1, 0.1))
     assert np.array_equal(s.meshes[0]["vertices"], (src.meshes[0]["vertices"] * np.float32([2, 1, 1]) + np.float32([1, 2, 3])).astype(np.float32))
     assert np.array_equal(s.meshes[1]["vertices"], src.meshes[1]["vertices"])          # scene.cpp:203-206 touches meshes[0] only
+
+
+def test_external_uris_must_stay_inside_the_asset_directory(tmp_path):
+    """A .gltf is untrusted input: absolute paths, '..' escapes and URL schemes in buffer / image URIs are refused."""
+    import json
+    (tmp_path / "a").mkdir()
+    (tmp_path / "secret.bin").write_bytes(b"\0" * 16)
+    (tmp_path / "a" / "ok.bin").write_bytes(b"\0" * 16)
+    for uri, ok in (("ok.bin", True), ("./ok.bin", True), ("../secret.bin", False), (str(tmp_path / "secret.bin"), False),
+                    ("file:///etc/passwd", False), ("%2e%2e/secret.bin", False)):
+        doc = {"asset": {"version": "2.0"}, "buffers": [{"uri": uri, "byteLength": 16}]}
+        p = tmp_path / "a" / "s.gltf"
+        p.write_text(json.dumps(doc))
+        if ok:
+            gltf._external(str(tmp_path / "a"), uri)
+        else:
+            with pytest.raises(ValueError):
+                gltf._external(str(tmp_path / "a"), uri)

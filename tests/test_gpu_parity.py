@@ -812,3 +812,117 @@ def test_uncounted_random_triangle_soups(gpu, seed, max_prims):
         cam_g.render(sc, count_rays=False, integrator=integrator)
         assert_same_f32(cam_g.acc_, acc, f"soup seed {seed}, integrator {integrator}")
         assert (cam_g.img_ == img).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# The EXACT launches bench.py times, at BASELINE.json's full sizes ("What's weak" 2): 1 rank,
+# count_rays = False -> k_render_paths with the default strata-group / pass policy.  Each is compared, whole frame,
+# bit for bit, with the counted launch of the same frame (k_render_pixels on the reference's binary node records,
+# itself oracle-checked above) and, per pixel, with the oracle's in-order per-sample sums.
+# ------------------------------------------------------------------------------------------------
+def _oracle_pixel_sums(osc, cam, rows, cols, spp):
+    n = len(rows)
+    rr = np.repeat(rows, spp).astype(np.int32); cc = np.repeat(cols, spp).astype(np.int32)
+    ss = np.tile(np.arange(spp, dtype=np.int32), n)
+    rad = osc.radiance_samples(cam, rr, cc, ss).reshape(n, spp, 3)
+    expect = np.zeros((n, 3), np.float32)
+    for s in range(spp):
+        expect = expect + rad[:, s]                      # AccumulationBuffer::updatePixel order (image.hpp:82-86)
+    return expect
+
+
+def _expect_bytes(expect, spp):
+    g = np.sqrt(np.maximum(expect / np.float32(spp), np.float32(0))).astype(np.float32)
+    return (np.float32(255.999) * np.clip(g, np.float32(0), np.float32(0.999))).astype(np.float32).astype(np.int32)
+
+
+def test_timed_launch_config2_full_frame(gpu, cornell_pair):
+    """C2 exactly as bench.py times it: Cornell 1920x1080, 64 spp, depth 8, one rank, uncounted (k_render_paths<LDS>)."""
+    data, sc, osc = cornell_pair
+    cam = data.camera_desc(1920, 1080, 8, 8, 8)
+    acc_u, img_u, _ = _frame_on_device(gpu, sc, cam, 1, count=False)
+    acc_c, img_c, cnt = _frame_on_device(gpu, sc, cam, 1, count=True)
+    assert np.array_equal(acc_u.view(np.uint32), acc_c.view(np.uint32)) and np.array_equal(img_u, img_c)
+    assert cnt["n_camera"] == 1920 * 1080 * 64
+    rs = np.random.RandomState(21)
+    rows, cols = rs.randint(0, 1080, 256), rs.randint(0, 1920, 256)
+    expect = _oracle_pixel_sums(osc, cam, rows, cols, 64)
+    assert np.array_equal(acc_u[rows, cols].view(np.uint32), expect.view(np.uint32))
+    assert np.abs(img_u[rows, cols].astype(np.int32) - _expect_bytes(expect, 64)).max() <= 1
+
+
+@pytest.fixture(scope="module")
+def atrium_full(gpu):
+    data = gpu.scenes.atrium()                            # C3 / C4 scene: ~262 k triangles
+    sc = gpu.Scene(data); sc.buildBVH()
+    yield data, sc, ol.OracleScene(data)
+    sc.destroy()
+
+
+def test_timed_launch_config3_full_frame(gpu, atrium_full):
+    """C3 exactly as timed: atrium (262 k triangles), 1920x1080, ALL 64 strata, depth 8, one rank, uncounted =
+    the 8-ary quantised traversal (k_render_paths<WIDE>) -- against the counted binary-record frame and the oracle."""
+    data, sc, osc = atrium_full
+    assert data.num_triangles > 250000 and sc.info()["wide_depth"] >= 2 and not sc.info()["lds_resident"]
+    cam = data.camera_desc(1920, 1080, 8, 8, 8)
+    acc_u, img_u, _ = _frame_on_device(gpu, sc, cam, 1, count=False)
+    acc_c, img_c, cnt = _frame_on_device(gpu, sc, cam, 1, count=True)
+    assert np.array_equal(acc_u.view(np.uint32), acc_c.view(np.uint32)) and np.array_equal(img_u, img_c)
+    assert cnt["n_camera"] == 1920 * 1080 * 64
+    rs = np.random.RandomState(22)
+    rows, cols = rs.randint(0, 1080, 256), rs.randint(0, 1920, 256)
+    expect = _oracle_pixel_sums(osc, cam, rows, cols, 64)
+    assert np.array_equal(acc_u[rows, cols].view(np.uint32), expect.view(np.uint32))
+    assert np.abs(img_u[rows, cols].astype(np.int32) - _expect_bytes(expect, 64)).max() <= 1
+
+
+def test_timed_launch_config5_full_frame(gpu):
+    """C5 exactly as timed: the mixed-material scene (all four BxDFs, textures, two lights), 1920x1080, 128 spp,
+    depth 8, one rank, uncounted (k_render_paths<WIDE, MAT_ALL>)."""
+    data = gpu.scenes.mixed()
+    sc = gpu.Scene(data); sc.buildBVH()
+    assert sc.info()["wide_depth"] >= 2
+    cam = data.camera_desc(1920, 1080, 16, 8, 8)
+    acc_u, img_u, _ = _frame_on_device(gpu, sc, cam, 1, count=False)
+    acc_c, img_c, cnt = _frame_on_device(gpu, sc, cam, 1, count=True)
+    assert np.array_equal(acc_u.view(np.uint32), acc_c.view(np.uint32)) and np.array_equal(img_u, img_c)
+    assert cnt["n_camera"] == 1920 * 1080 * 128
+    osc = ol.OracleScene(data)
+    rs = np.random.RandomState(23)
+    rows, cols = rs.randint(0, 1080, 256), rs.randint(0, 1920, 256)
+    expect = _oracle_pixel_sums(osc, cam, rows, cols, 128)
+    assert np.array_equal(acc_u[rows, cols].view(np.uint32), expect.view(np.uint32))
+    assert np.abs(img_u[rows, cols].astype(np.int32) - _expect_bytes(expect, 128)).max() <= 1
+    sc.destroy()
+
+
+def test_timed_launch_config4_shard_and_pass_split(gpu, atrium_full):
+    """C4: atrium at 3840x2160, 256 spp (16x16), depth 8.  (a) rank 0's shard of 8 exactly as an 8-GPU run launches it
+    (default radiance-buffer cap) against the oracle's per-sample sums on 64 owned pixels; (b) the whole 4 K frame on
+    ONE rank -- 34 GB of per-path records against the default 8 GiB cap, i.e. the real pass split -- must equal the
+    shard on every owned pixel bit for bit and be untouched (zero) nowhere."""
+    import torch
+    data, sc, osc = atrium_full
+    W, H, spp = 3840, 2160, 256
+    cam = data.camera_desc(W, H, 16, 16, 8)
+    acc_s, img_s, _ = _frame_on_device(gpu, sc, cam, 1, rank=0, world=8)
+    tiles_x = (W + 31) // 32
+    ty, tx = np.meshgrid(np.arange(H) // 32, np.arange(W) // 32, indexing="ij")
+    owned = ((ty * tiles_x + tx) % 8) == 0
+    assert not acc_s[~owned].any() and not img_s[~owned].any()        # non-owned pixels read exactly 0 (the reduce relies on it)
+    rs = np.random.RandomState(24)
+    oy, ox = np.nonzero(owned)
+    pick = rs.choice(len(oy), 64, replace=False)
+    rows, cols = oy[pick], ox[pick]
+    expect = _oracle_pixel_sums(osc, cam, rows, cols, spp)
+    assert np.array_equal(acc_s[rows, cols].view(np.uint32), expect.view(np.uint32))
+    assert np.abs(img_s[rows, cols].astype(np.int32) - _expect_bytes(expect, spp)).max() <= 1
+    assert (W * H * spp * 16) > (8 << 30)                              # the 1-rank frame cannot fit one pass
+    acc_f, img_f, _ = _frame_on_device(gpu, sc, cam, 1)
+    assert np.array_equal(acc_f[owned].view(np.uint32), acc_s[owned].view(np.uint32))
+    assert np.array_equal(img_f[owned], img_s[owned])
+    rows2, cols2 = rs.randint(0, H, 16), rs.randint(0, W, 16)
+    expect2 = _oracle_pixel_sums(osc, cam, rows2, cols2, spp)
+    assert np.array_equal(acc_f[rows2, cols2].view(np.uint32), expect2.view(np.uint32))
+    del acc_s, acc_f
+    torch.cuda.empty_cache()
