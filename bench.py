@@ -144,7 +144,7 @@ def main():
     lib = jtx._capi.load()
 
     integrator = scene.info()["auto_integrator"]
-    INTEG_NAMES = {1: "pixel-persistent", 2: "hbm-wavefront", 3: "wave-pool", 4: "pixel-persistent-fused"}
+    INTEG_NAMES = {1: "pixel-persistent", 2: "hbm-wavefront", 3: "re-entrant-stream"}
 
     # per-frame exchange: compact own-pixel slabs gathered to rank 0 (default) or one sum-reduce of the full buffers
     collective = os.environ.get("JTX_FRAME_COLLECTIVE", "gather")
@@ -230,7 +230,7 @@ def main():
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
         my_bytes = algorithmic_bytes(mine)               # rank 0's launch
-        kernel_name = {1: "k_render_paths", 3: "k_render_wavepool", 4: "k_render_fused"}.get(integrator)
+        kernel_name = {1: "k_render_paths", 3: "k_render_stream"}.get(integrator)
         launches_per_frame = 1
         if integrator == 2:
             # dominant stage of the pipeline; its algorithmic bytes are the SURVEY 8d terms of that stage

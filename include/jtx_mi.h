@@ -105,8 +105,8 @@ typedef struct {
     int32_t tile_rank;        /* multi-GPU pixel-tile sharding: this process owns 32x32 tiles k with */
     int32_t tile_world;       /*   k % tile_world == tile_rank (0/0 or 0/1 => whole frame) */
     int32_t integrator;       /* 0 auto = the measured policy of DESIGN.md section 5 (1 in practice; env JTX_INTEGRATOR overrides);
-                               * 1 pixel-persistent, 2 HBM-queued wavefront, 3 wave-pool (LDS-queued wavefront),
-                               * 4 pixel-persistent with fused rays (experimental).  All give the same film bit for bit. */
+                               * 1 pixel-persistent (the timed one), 2 HBM-queued wavefront, 3 re-entrant stream kernel (experimental;
+                               * counting launches of 3 run as 1).  All give the same film bit for bit. */
     int32_t count_rays;       /* != 0: accumulate jtx_mi_counters on the device (slower); the counting kernels walk the
                                * reference's binary BVH node by node, so the counters are Scene::closestHit / anyHit's own.
                                * 0: same film bit for bit; scenes that do not fit LDS walk an 8-ary quantised BVH instead

@@ -126,11 +126,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("JTX_MI_LIB", LIB_PATH)      # developer builds (tools/: diagnostic -D variants, A/B libraries)
+    if not os.path.exists(path):
         raise JtxMiError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The jtx_mi core has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol
         fn.restype = res

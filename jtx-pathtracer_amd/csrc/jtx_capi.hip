@@ -474,7 +474,7 @@ std::pair<hipEvent_t, hipEvent_t> takeEvents(jtx_mi_scene &s) {
 int autoIntegrator(const jtx_mi_scene &s) {
     const char *e = getenv("JTX_INTEGRATOR");
     const int v = e ? atoi(e) : 0;
-    if (v >= 1 && v <= 4) return v;
+    if (v >= 1 && v <= 3) return v;
     return (s.dev.lds_threaded || s.dev.material_mask == MAT_DIFFUSE_ONLY || s.dev.wide) ? 1 : 2;
 }
 
@@ -547,8 +547,8 @@ void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_m
     { const char *e = getenv("JTX_WF_SORT_SHADE"); p.sort_shade = (e && atoi(e) != 0 && __builtin_popcount(s.dev.material_mask) > 1) ? 1 : 0; }
     const bool count = o.count_rays != 0;
     if (count) {
-        if (!s.counters.p) s.counters.alloc(32);
-        HIPCHK(hipMemsetAsync(s.counters.p, 0, 32 * sizeof(unsigned long long), stream));
+        if (!s.counters.p) s.counters.alloc(64);
+        HIPCHK(hipMemsetAsync(s.counters.p, 0, 64 * sizeof(unsigned long long), stream));
     }
     p.counters = count ? s.counters.p : nullptr;
     const int grid = s.num_cus * 8;
@@ -597,14 +597,14 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     p.acc = d_acc; p.img = d_img;
     const bool count = o.count_rays != 0;
     if (count) {
-        if (!s.counters.p) s.counters.alloc(32);
-        HIPCHK(hipMemsetAsync(s.counters.p, 0, 32 * sizeof(unsigned long long), stream));
+        if (!s.counters.p) s.counters.alloc(64);
+        HIPCHK(hipMemsetAsync(s.counters.p, 0, 64 * sizeof(unsigned long long), stream));
     }
 #ifdef JTX_PROFILE_TIMELINE
     if (s.counters.n < 64 + 2 * 65536) { s.counters.alloc(64 + 2 * 65536); HIPCHK(hipMemsetAsync(s.counters.p, 0, (64 + 2 * 65536) * sizeof(unsigned long long), stream)); }
 #endif
     p.counters = s.counters.p;
-    if (o.integrator < 0 || o.integrator > 4) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront), 3 (wave-pool) or 4 (pixel-persistent, fused rays)");
+    if (o.integrator < 0 || o.integrator > 3) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront) or 3 (re-entrant stream kernel, experimental)");
     int integ = o.integrator;
     if (integ == 0) integ = autoIntegrator(s);
     // timing pairs are only drained by jtx_mi_kernel_time (bench / tools): a UI that never asks keeps the newest 64
@@ -616,7 +616,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                       ~EvReturn() { if (armed) s.free_events.push_back(ev); } } evGuard{s, ev};   // a throw below must not leak the pair
     bool evClosed = false;
     HIPCHK(hipEventRecord(ev.first, stream));
-    if (integ == 1) {
+    if (integ == 1 || integ == 3) {
         // strata groups: the strata of a pixel block are spread over `groups` waves (gridDim.y); every path's clamped
         // radiance goes to rad[stratum][pixel] and k_resolve_samples adds them to the film in sample order.
         // One-lane-per-pixel launches (counting, JTX_DYNAMIC_PATHS=0) split only small shards / frames: 32 or 64 ways.
@@ -656,7 +656,8 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 if (!s.work.p) s.work.alloc(64);
                 q.work = s.work.p + (s.work_slot++ & 63);                 // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
-                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
+                if (integ == 3) HIPCHK(jtx_launch_render_stream(q, owned, s.num_cus, stream));       // re-entrant path kernel (jtx_stream.hip)
+                else HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }
@@ -672,8 +673,6 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
         }
     }
-    else if (integ == 3) HIPCHK(jtx_launch_render_wavepool(p, owned, count, stream));
-    else if (integ == 4) HIPCHK(jtx_launch_render_fused(p, owned, count, stream));
     else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
     if (!evClosed) HIPCHK(hipEventRecord(ev.second, stream));
     evGuard.armed = false;
@@ -838,16 +837,35 @@ int jtx_mi_debug_util_hist(jtx_mi_scene *s, unsigned long long *out7) {
     return hipMemcpy(out7, s->counters.p + 24, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
+#if defined(JTX_PROFILE_UTIL) && !defined(JTX_PROFILE_WIDE)
+int jtx_mi_debug_wide_idle(jtx_mi_scene *s, unsigned long long *out4) {   // interior iterations parked / done, leaf phases walking / done
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out4, s->counters.p + 48, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef JTX_PROFILE_WIDE
 int jtx_mi_debug_wide(jtx_mi_scene *s, unsigned long long *out8) {     // diagnostic builds only
     if (!s || !s->counters.p) return 1;
     (void) hipDeviceSynchronize();
     return hipMemcpy(out8, s->counters.p + 24, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
+int jtx_mi_debug_wide_idle(jtx_mi_scene *s, unsigned long long *out4) {   // node iterations parked / done, leaf iterations walking / done
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out4, s->counters.p + 48, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
 int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
     if (!s || !s->counters.p) return 1;
     (void) hipDeviceSynchronize();
     return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+#ifdef JTX_PROFILE_STREAM
+int jtx_mi_debug_stream(jtx_mi_scene *s, unsigned long long *out8) {   // diagnostic builds only: trips and active lanes per block kind
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out8, s->counters.p + 32, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
 #ifdef JTX_PROFILE_TIMELINE

@@ -34,7 +34,7 @@ constexpr int BLOCKS_PER_TILE = 16 / WAVES_PER_BLOCK;   // a 32x32 tile = 16 wav
 // ---- LDS carve of the stackless kernels: [8 threaded node orderings][tris] (16-B aligned), no stack ----
 JD void stageScene(const DevScene &sc, float4 *lds_tnodes, float4 *lds_tris) {
     const int nn = 2 * 8 * sc.num_nodes, nt = 3 * sc.num_prims;
-    for (int i = threadIdx.x; i < nn; i += BLOCK) lds_tnodes[i] = sc.tnodes[i];
+    for (int i = threadIdx.x; i < nn; i += BLOCK) lds_tnodes[(i & 1) * (nn >> 1) + (i >> 1)] = sc.tnodes[i];   // LdsSrc: halves apart
     for (int i = threadIdx.x; i < nt; i += BLOCK) lds_tris[i] = sc.tris[i];
     __syncthreads();
 }
@@ -66,6 +66,23 @@ struct PathState {
 #else
 #define PH_DECL
 #define PH(i)
+#endif
+
+#ifdef JTX_PROFILE_WIDE
+// diagnostic build: lane sums of the steps, wave maxima of the iterations (tools/tools_wide_stats.py)
+JD void exportWideStats(const RenderParams &p, const Counters9 &cnt) {
+    if (!p.counters) return;
+    const unsigned v[12] = {cnt.w_calls, cnt.w_node_iters, cnt.w_node_steps, cnt.w_leaf_iters, cnt.w_leaf_steps, cnt.w_tris, cnt.w_pops, cnt.w_fetch,
+                            cnt.w_np, cnt.w_nd, cnt.w_lw, cnt.w_ld};
+    for (int i = 0; i < 12; ++i) {
+        const bool perWave = (i == 0 || i == 1 || i == 3);
+        unsigned long long sv = v[i];
+        if (perWave) { for (int off = 32; off > 0; off >>= 1) { unsigned long long o2 = __shfl_down(sv, off, 64); sv = sv > o2 ? sv : o2; } }
+        else for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
+        if ((threadIdx.x & 63) == 0 && sv) atomicAdd(&p.counters[i < 8 ? 24 + i : 40 + i], sv);
+    }
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[9 + i], (unsigned long long) cnt.w_hist[i]);
+}
 #endif
 
 template <bool COUNT, int MASK, class Src>
@@ -179,7 +196,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
             bool done;
-            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris;
+            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
                                   done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
             else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BLOCK;
@@ -222,17 +239,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 #endif
     if (COUNT) waveAddCounters(p.counters, cnt);
 #ifdef JTX_PROFILE_WIDE
-    if (SRC == SRC_WIDE && p.counters) {   // diagnostic build: lane sums of the steps, lane 0's view of the wave iterations
-        const unsigned v[8] = {cnt.w_calls, cnt.w_node_iters, cnt.w_node_steps, cnt.w_leaf_iters, cnt.w_leaf_steps, cnt.w_tris, cnt.w_pops, cnt.w_fetch};
-        for (int i = 0; i < 8; ++i) {
-            const bool perWave = (i == 0 || i == 1 || i == 3);
-            unsigned long long sv = v[i];
-            if (perWave) { for (int off = 32; off > 0; off >>= 1) { unsigned long long o2 = __shfl_down(sv, off, 64); sv = sv > o2 ? sv : o2; } }
-            else for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
-            if ((threadIdx.x & 63) == 0 && sv) atomicAdd(&p.counters[24 + i], sv);
-        }
-        if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[9 + i], (unsigned long long) cnt.w_hist[i]);
-    }
+    if (SRC == SRC_WIDE) exportWideStats(p, cnt);
 #endif
 #ifdef JTX_PROFILE_UTIL
     if (COUNT) {
@@ -242,6 +249,9 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         for (int off = 32; off > 0; off >>= 1) { a = max(a, __shfl_down(a, off, 64)); b = max(b, __shfl_down(b, off, 64)); c = max(c, __shfl_down(c, off, 64)); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(&p.counters[20], (unsigned long long) a); atomicAdd(&p.counters[21], (unsigned long long) b); atomicAdd(&p.counters[22], (unsigned long long) c);
                                        for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[24 + i], (unsigned long long) cnt.it_hist[i]); }
+        unsigned long long id[4] = {cnt.it_np, cnt.it_nd, cnt.it_lw, cnt.it_ld};
+        for (int i = 0; i < 4; ++i) { for (int off = 32; off > 0; off >>= 1) id[i] += __shfl_down(id[i], off, 64);
+                                      if ((threadIdx.x & 63) == 0) atomicAdd(&p.counters[48 + i], id[i]); }
     }
 #endif
 }
@@ -330,7 +340,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
         // ---- one bounce of every live path ----
         if (alive) {
             bool done;
-            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris;
+            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
             else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS;
@@ -347,6 +357,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             }
         }
     }
+#ifdef JTX_PROFILE_WIDE
+    if (SRC == SRC_WIDE) exportWideStats(p, cnt);
+#endif
 #ifdef JTX_PROFILE_TIMELINE
     if (p.counters) {
         unsigned long long a = tl_active;

@@ -41,10 +41,12 @@ struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode
 #ifdef JTX_PROFILE_UTIL
     unsigned it_interior, it_leaf, it_calls;   // diagnostic: loop iterations this lane sat through (= wave iterations)
     unsigned it_hist[7];   // interior iterations by number of walking lanes: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
+    unsigned it_np, it_nd, it_lw, it_ld;   // lane-iterations idle: interior iterations spent parked / done, leaf phases spent walking / done
 #endif
 #ifdef JTX_PROFILE_WIDE
     unsigned w_calls, w_node_iters, w_node_steps, w_leaf_iters, w_leaf_steps, w_tris, w_pops, w_fetch;   // diagnostic: wide traversal
     unsigned w_hist[7];    // node iterations by number of walking lanes: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
+    unsigned w_np, w_nd, w_lw, w_ld;   // lane-iterations idle: node iterations spent parked / done, leaf iterations spent walking / done
 #endif
 };
 #ifdef JTX_PROFILE_UTIL
@@ -65,9 +67,14 @@ struct GlobalSrc {
     JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
 };
-struct LdsSrc {           // pointers into the workgroup's LDS copy
+// The workgroup's LDS copy.  The two 16-B halves of the records are kept as two arrays ([all first halves][all second
+// halves]): a ds_read_b128 serves 16 lanes at a time over 64 banks, and with interleaved 32-B records every first half
+// starts on an even bank quad -- 8 positions for 16 lanes, a 2-way conflict at best; split, a half of record i sits on
+// quad i mod 16 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the C2 kernel: 28 % interleaved).
+struct LdsSrc {
     const float4 *tnodes, *tris;
-    JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
+    int half;             // records per half array = 8 * num_nodes
+    JD float4 tnode(int i, int h) const { return tnodes[h * half + i]; }
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
 };
 
@@ -173,7 +180,8 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 #pragma unroll
             for (int rep = 0; rep < JTX_STEPS_PER_VOTE; ++rep) {
                 UTIL(if (COUNT) { cnt.it_interior++; const int na = __popcll(__ballot(leafW == 0 && cur >= 0));
-                                  cnt.it_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++; })
+                                  cnt.it_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++;
+                                  if (leafW != 0) cnt.it_np++; else if (cur < 0) cnt.it_nd++; })
                 if (leafW == 0 && cur >= 0) {
                     const float4 na = src.tnode(cur, 0);
                     const float4 nb = src.tnode(cur, 1);
@@ -190,7 +198,7 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
             if (parked != 0ull && __popcll(walking) <= JTX_FEW_WALKERS) break;      // do not let a few long walks hold the parked lanes
         }
         if (__ballot(leafW != 0) == 0ull) break;            // wave-uniform: every lane is done
-        UTIL(if (COUNT) cnt.it_leaf++;)
+        UTIL(if (COUNT) { cnt.it_leaf++; if (leafW == 0) { if (cur < 0) cnt.it_ld++; else cnt.it_lw++; } })
         if (leafW != 0) {
             const int n = leafW & 0xffff;
             for (int i = 0; i < n; ++i) {
@@ -357,6 +365,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
                 WSTAT(cnt.w_node_iters++;
                       { const int na = __popcll(__ballot(ws.walking()));
                         cnt.w_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++; })
+                WSTAT(if (ws.pendLeaf >= 0) cnt.w_np++; else if (ws.done) cnt.w_nd++;)
                 if (ws.walking()) {
                     WSTAT(cnt.w_node_steps++; const int leafBefore = ws.pendLeaf; const bool doneBefore = ws.done;)
                     wideNodeStep<!ANY>(wide, stk, stride, r, ws);
@@ -369,7 +378,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
             if (parked != 0ull && __popcll(walking) <= JTX_WIDE_FEW_WALKERS) break;
         }
         if (__ballot(ws.pendLeaf >= 0) == 0ull) break;          // wave-uniform: every lane is done
-        WSTAT(cnt.w_leaf_iters++;)
+        WSTAT(cnt.w_leaf_iters++; if (ws.pendLeaf < 0) { if (ws.done) cnt.w_ld++; else cnt.w_lw++; })
         if (ws.pendLeaf >= 0) { WSTAT(cnt.w_leaf_steps++;) wideLeafStep(wide, src, ANY, r, ws, rec); }
     }
     return ws.hitAnything;

@@ -156,7 +156,7 @@ def _render_both(gpu, data, sc, osc, w, h, xs, ys, depth, **kw):
     return cam_g, acc, img, cnt
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("integrator", [1, 2, 3])
 def test_render_config1_cornell_512(gpu, cornell_pair, integrator):
     """BASELINE config 1: Cornell 512x512, 16 spp (4x4), depth 4 -- whole frame, bit-exact, both integrators."""
     data, sc, osc = cornell_pair
@@ -167,7 +167,7 @@ def test_render_config1_cornell_512(gpu, cornell_pair, integrator):
     assert cnt["n_camera"] == 512 * 512 * 16
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("integrator", [1, 2, 3])
 def test_render_mixed_small(gpu, mixed_pair, integrator):
     data, sc, osc = mixed_pair
     cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 200, 120, 2, 2, 8, integrator=integrator)
@@ -176,7 +176,7 @@ def test_render_mixed_small(gpu, mixed_pair, integrator):
     assert cam_g.counters == cnt
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("integrator", [1, 2, 3])
 def test_render_ragged_sizes(gpu, cornell_pair, integrator):
     """widths/heights that are not multiples of the 8x8 wave block or the 32x32 tile; 1x1 image."""
     data, sc, osc = cornell_pair
@@ -207,7 +207,7 @@ def test_render_resume_and_progress(gpu, cornell_pair):
     assert stop.currentSample_ == 2
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("integrator", [1, 2, 3])
 def test_render_tile_sharding(gpu, cornell_pair, integrator):
     """pixel-tile shards of 3 ranks are disjoint, zero elsewhere, and sum to the 1-GPU frame exactly."""
     data, sc, osc = cornell_pair
@@ -268,7 +268,7 @@ def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
     assert kv["dynhash"] == "1af9ba89" and kv["dynsamples"] == "4" and kv["restart_same"] == "1"
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("integrator", [1, 2, 3])
 def test_render_atrium_small(gpu, integrator):
     """config C3's scene family (deep BVH in HBM, DISTANT light + sky) at a size the oracle renders in seconds."""
     data = gpu.scenes.atrium(target_tris=20000)
@@ -309,7 +309,7 @@ def test_full_size_config2_properties(gpu, cornell_pair):
     data, sc, osc = cornell_pair
     cam = data.camera_desc(1920, 1080, 8, 8, 8)
     acc1, img1, cnt1 = _frame_on_device(gpu, sc, cam, 1, count=True)
-    acc3, img3, cnt3 = _frame_on_device(gpu, sc, cam, 3, count=True)
+    acc3, img3, cnt3 = _frame_on_device(gpu, sc, cam, 2, count=True)
     assert np.array_equal(acc1.view(np.uint32), acc3.view(np.uint32)) and np.array_equal(img1, img3)
     assert cnt1 == cnt3
     assert cnt1["n_camera"] == 1920 * 1080 * 64
@@ -336,12 +336,12 @@ def test_full_size_config2_properties(gpu, cornell_pair):
 
 def test_full_size_config3_properties(gpu):
     """BASELINE config 3 (atrium ~262 k triangles, 1920x1080; 16 of the 64 strata to bound the run): the
-    pixel-persistent and the wave-pool integrators agree bit for bit; pixels checked against the oracle."""
+    pixel-persistent and the wavefront integrators agree bit for bit; pixels checked against the oracle."""
     data = gpu.scenes.atrium()
     sc = gpu.Scene(data); sc.buildBVH()
     cam = data.camera_desc(1920, 1080, 4, 4, 8)
     acc1, img1, cnt1 = _frame_on_device(gpu, sc, cam, 1, count=True)
-    acc3, img3, cnt3 = _frame_on_device(gpu, sc, cam, 3, count=True)
+    acc3, img3, cnt3 = _frame_on_device(gpu, sc, cam, 2, count=True)
     assert np.array_equal(acc1.view(np.uint32), acc3.view(np.uint32)) and np.array_equal(img1, img3) and cnt1 == cnt3
     osc = ol.OracleScene(data)
     rs = np.random.RandomState(6)
@@ -376,7 +376,7 @@ def _edge_scene(gpu):
     return s
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("integrator", [1, 2, 3])
 @pytest.mark.parametrize("max_prims", [1, 4])
 def test_render_edge_cases(gpu, integrator, max_prims):
     """mesh transforms baked on upload, texture wrap with negative uv, 3 lights (Q2), thin lens, maxPrimsInNode > 1."""
@@ -391,7 +391,7 @@ def test_render_edge_cases(gpu, integrator, max_prims):
         assert sc.bvh()[0]["num_prims"].max() > 1
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3, 4])
+@pytest.mark.parametrize("integrator", [1, 2, 3])
 def test_render_depth_zero_and_no_lights(gpu, cornell_pair, integrator):
     data, sc, osc = cornell_pair
     cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 64, 48, 1, 2, 0, integrator=integrator)    # maxDepth 0: one closestHit per path

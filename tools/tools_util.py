@@ -20,3 +20,8 @@ h = lib.jtx_mi_debug_util_hist; h.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 hv = (C.c_uint64 * 7)(); assert h(sc.handle, hv) == 0
 tot = sum(int(x) for x in hv)
 print("interior iterations by walking lanes  1-2 3-4 5-8 9-16 17-32 33-48 49-64:", " ".join(f"{int(x) / tot:.3f}" for x in hv))
+g = lib.jtx_mi_debug_wide_idle; g.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+iv = (C.c_uint64 * 4)(); assert g(sc.handle, iv) == 0
+npk, nd, lw, ld = [int(x) for x in iv]
+print("interior iterations, lane share: walking %.3f parked %.3f done %.3f" % (nodes / (64.0 * it_int), npk / (64.0 * it_int), nd / (64.0 * it_int)))
+print("leaf phases, lane share: walking %.3f done %.3f" % (lw / (64.0 * it_leaf), ld / (64.0 * it_leaf)))

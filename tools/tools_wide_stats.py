@@ -23,3 +23,8 @@ h = lib.jtx_mi_debug_wide_hist; h.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 hv = (C.c_uint64 * 7)(); assert h(sc.handle, hv) == 0
 tot = sum(int(x) for x in hv)
 print("node iterations by walking lanes  1-2 3-4 5-8 9-16 17-32 33-48 49-64:", " ".join(f"{int(x) / tot:.3f}" for x in hv))
+g = lib.jtx_mi_debug_wide_idle; g.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+iv = (C.c_uint64 * 4)(); assert g(sc.handle, iv) == 0
+npk, nd, lw, ld = [int(x) for x in iv]
+print(f"node iterations, lane share: walking {nst / (64.0 * nit):.3f} parked {npk / (64.0 * nit):.3f} done {nd / (64.0 * nit):.3f} (rest: lanes without a path)")
+print(f"leaf iterations, lane share: on a leaf {lst / (64.0 * lit):.3f} walking {lw / (64.0 * lit):.3f} done {ld / (64.0 * lit):.3f}")
