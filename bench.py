@@ -40,16 +40,30 @@ def algorithmic_bytes(c):
     return b_closest + b_any + b_shade + b_cam
 
 
-def cpu_baseline(data, width, height, xs, ys, depth, budget_s=12.0):
-    """The CPU oracle (kind "port": a restatement of the reference's algorithm, reference flags
-    -O3 -ffast-math, one barrier per sample pass as StaticCamera::render) timed on this host's cores
-    over a bounded number of strata of the SAME frame."""
+def source_hash():
+    """sha1 over the kernel sources: ties a profiles/ counter file to the build it was collected from."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "jtx-pathtracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(data, width, height, xs, ys, depth, budget_s=9.0):
+    """SURVEY 8d "CPU baseline timing": the CPU oracle (kind "port": a restatement of the reference's algorithm)
+    built with the reference's flags (-O3 -ffast-math, CMakeLists.txt:55), scheduled as StaticCamera::render does it
+    (persistent threads, 32x32 tile queue, samplesPerPass = 1, one barrier per sample pass), on a BOUNDED sample of the
+    same workload: all host cores and one thread, median of 3 runs each."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
     import jtx_pathtracer_amd as jtx
+    import numpy as np
     capi = jtx._capi
     fast = os.path.join(ROOT, "oracle", "_build", "libjtx_oracle_fast.so")
-    if not os.path.exists(fast):
+    src_t = max(os.path.getmtime(os.path.join(ROOT, "oracle", f)) for f in ("jtx_oracle.cpp", "jtx_oracle.h"))
+    if not os.path.exists(fast) or os.path.getmtime(fast) < src_t:
         ol.build(fast=True)
     lib = C.CDLL(fast)
     lib.ora_scene_create.restype = C.c_void_p
@@ -58,34 +72,108 @@ def cpu_baseline(data, width, height, xs, ys, depth, budget_s=12.0):
     lib.ora_render.argtypes = [C.c_void_p, C.POINTER(capi.CameraDesc), C.c_int, C.c_int, C.c_int, C.c_int,
                                C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(capi.Counters)]
     lib.ora_scene_destroy.argtypes = [C.c_void_p]
-    import numpy as np
     desc = data.to_desc()
     h = C.c_void_p(lib.ora_scene_create(C.byref(desc)))
-    cam = data.camera_desc(width, height, xs, ys, depth)
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    acc = np.zeros((height, width, 3), np.float32)
-    img = np.zeros((height, width, 3), np.uint8)
 
-    def run(s0, s1):
+    def run(cam, threads, s0, s1):
+        acc = np.zeros((cam.height, cam.width, 3), np.float32)
+        img = np.zeros((cam.height, cam.width, 3), np.uint8)
         cnt = capi.Counters()
         t = time.perf_counter()
-        lib.ora_render(h, C.byref(cam), cores, s0, s1, 1, acc.ctypes.data_as(C.POINTER(C.c_float)),
+        lib.ora_render(h, C.byref(cam), threads, s0, s1, 1, acc.ctypes.data_as(C.POINTER(C.c_float)),
                        img.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(cnt))
-        dt = time.perf_counter() - t
-        return dt, cnt.n_closest + cnt.n_any
+        return time.perf_counter() - t, cnt.n_closest + cnt.n_any
 
-    dt1, rays1 = run(0, 1)                                # calibration stratum (also warms the caches)
+    def median3(cam, threads, n):
+        runs = sorted(run(cam, threads, 1, 1 + n) for _ in range(3))
+        dt, rays = runs[1]
+        return rays / dt / 1e6, rays, dt
+
     spp = xs * ys
-    n = int(max(1, min(spp - 1, budget_s / max(dt1, 1e-3))))
-    dt, rays = run(1, 1 + n)
+    cam = data.camera_desc(width, height, xs, ys, depth)
+    dt1, _ = run(cam, cores, 0, 1)                        # calibration pass (also warms the caches)
+    n = int(max(1, min(spp - 1, budget_s / 3.0 / max(dt1, 1e-3))))
+    all_v, all_rays, all_dt = median3(cam, cores, n)
+    # one thread: the same view at 1/4 x 1/4 of the pixels (same scene, same rays per pixel), sized the same way
+    cam1 = data.camera_desc(max(32, width // 4), max(32, height // 4), xs, ys, depth)
+    dt1s, _ = run(cam1, 1, 0, 1)
+    n1 = int(max(1, min(spp - 1, budget_s / 3.0 / max(dt1s, 1e-3))))
+    one_v, one_rays, one_dt = median3(cam1, 1, n1)
     lib.ora_scene_destroy(h)
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"strata 1..{n} of {spp} of the same {width}x{height} frame ({rays} rays, {dt:.2f} s), "
-                      "oracle built -O3 -ffast-math, one barrier per sample pass"}
+    return {"value": round(all_v, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "one_thread": {"value": round(one_v, 3), "unit": "Mrays/s", "cores": 1,
+                           "sample": f"median of 3 x strata 1..{n1} of {spp} at {cam1.width}x{cam1.height} ({one_rays} rays, {one_dt:.2f} s)"},
+            "sample": f"median of 3 x strata 1..{n} of {spp} of the same {width}x{height} frame ({all_rays} rays, {all_dt:.2f} s per run); "
+                      "oracle built -O3 -ffast-math; StaticCamera::render's schedule: persistent threads, 32x32 tile queue, "
+                      "samplesPerPass = 1, one barrier per sample pass"}
+
+
+def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_per_frame, num_cus, grid_note=""):
+    """roofline of the dominant kernel.  The binding ceiling of this path is VALU instruction issue (no MFMA work, and
+    the BVH is served from LDS / L2: measured HBM traffic is a few percent of peak), so `bound` names that ceiling and
+    `frac` is the issued fraction of it; the HBM view (own-layout algorithmic bytes and PMC-measured bytes) and the
+    SURVEY 8d reference-layout figure ride along.  Counter inputs come from profiles/r02_pmc.json (rocprofv3 --pmc
+    passes over the same launch, tools/pmc_collect.sh); everything time-like is measured live with HIP events."""
+    SIMDS = num_cus * 4
+    CLK = 2.4e9                                            # MI355X max shader clock (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE / 8 / kernel time reads 2.39 GHz
+    valu_peak = SIMDS * CLK / 2.0 / 1e9                    # wave64 VALU instructions per second: one per 2 cycles per SIMD-32
+    t = kernel_ms * 1e-3
+    out = {"bound": "valu", "achieved": None, "peak": round(valu_peak, 1), "unit": "G wave-instructions/s", "frac": None,
+           "traffic": None, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches_per_frame}
+    pmc = None
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if os.path.exists(path):
+        try:
+            j = json.load(open(path))
+            pmc = j.get("workloads", {}).get(workload)
+            out["pmc_source"] = "profiles/r02_pmc.json"
+            out["pmc_stale"] = j.get("source_hash") != source_hash()
+        except Exception:
+            pmc = None
+    # ---- own-layout algorithmic HBM bytes of this launch (DESIGN.md section 6) ----
+    paths = mine["n_camera"]; rays = mine["n_closest"] + mine["n_any"]
+    own = 16 * paths                                       # one 16-B radiance record per path (k_resolve_samples reads them back)
+    own += 128 * mine["n_shade"]                           # 64-B shading record + 64-B material per shading event
+    ws = (pmc or {}).get("wide_stats")
+    if scene_info["lds_resident"]:
+        own += scene_info["lds_bytes"] * scene_info.get("workgroups", 0)     # the scene staged once per workgroup
+    elif ws:
+        own += int(rays * (80 * ws["node_steps_per_ray"] + 32 * ws["leaf_steps_per_ray"] + 48 * ws["tri_tests_per_ray"]))
+    hbm = {"algorithmic_bytes_per_launch": int(own), "achieved": round(own / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+           "frac": round(own / t / 1e9 / 8000.0, 4)}
+    if pmc:
+        c = pmc["counters"]
+        insts = c["SQ_INSTS_VALU"]
+        out["achieved"] = round(insts / t / 1e9, 1)
+        out["frac"] = round(insts / t / 1e9 / valu_peak, 4)
+        out["valu_instructions_per_launch"] = int(insts)
+        out["lane_util"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4)
+        out["fp32_lane_frac"] = round(out["frac"] * out["lane_util"], 4)       # share of the chip's fp32 lane slots doing work
+        # FETCH_SIZE / WRITE_SIZE are KiB; gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md "HBM"): x2 on reads
+        measured = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["traffic"] = int(measured)
+        hbm["measured_bytes_per_launch"] = int(measured)
+        hbm["measured_frac"] = round(measured / t / 1e9 / 8000.0, 4)
+        hbm["raw_kib"] = {"FETCH_SIZE": c["FETCH_SIZE"], "WRITE_SIZE": c["WRITE_SIZE"]}
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            out["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
+        out["wait_share"] = {"s_waitcnt": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
+                             "issue_stall": round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 3)}
+    out["hbm"] = hbm
+    ref_bytes = algorithmic_bytes(mine)
+    out["reference_layout_equiv"] = {"bytes_per_launch": int(ref_bytes), "GBps": round(ref_bytes / t / 1e9, 1),
+                                     "x_hbm_peak": round(ref_bytes / t / 1e9 / 8000.0, 4),
+                                     "note": "SURVEY 8d formula (the reference's 32-B binary nodes / 56-B triangle fetches) on this frame's "
+                                             "device counters: what the REFERENCE's layout would have to move; not this kernel's traffic"}
+    out["note"] = ("bound = VALU instruction issue: achieved = SQ_INSTS_VALU of this launch (rocprofv3 --pmc, profiles/) / live HIP-event "
+                   "kernel time; peak = 4 SIMD x CUs x 2.4 GHz / 2 cycles per wave64 instruction.  lane_util = SQ_THREAD_CYCLES_VALU / "
+                   "(64 SQ_ACTIVE_INST_VALU).  hbm.* = own-layout algorithmic bytes and PMC-measured bytes against 8 TB/s." + grid_note)
+    return out
 
 
 def main():
@@ -173,22 +261,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # counted pass: deterministic ray / node / triangle tallies of this rank's shard (untimed).  It is also the first
-    # use of the exchange: if the slab gather is refused by this RCCL build, every rank falls back to the reduce.
-    try:
-        step(count=True)
+    # The exchange form is decided BEFORE the first frame: JTX_FRAME_COLLECTIVE names it, and a one-element probe of the
+    # slab gather (every rank, same order) falls back to the reduce on all ranks together if this RCCL build refuses it.
+    if gatherer is not None and backend == "nccl":
         ok = 1
-    except RuntimeError as e:
-        if gatherer is None:
-            raise
-        sys.stderr.write(f"[bench rank {rank}] FrameGather failed ({e}); falling back to reduce\n")
-        ok = 0
-    if gatherer is not None:
+        try:
+            probe = torch.zeros(4, dtype=torch.uint8, device=dev)
+            dist.gather(probe, [torch.zeros_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            sys.stderr.write(f"[bench rank {rank}] gather probe failed ({e}); falling back to reduce\n")
+            ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            gatherer, collective = None, "reduce"
-            step(count=True)
+            gatherer, pipe, collective = None, None, "reduce"
+    # counted pass: deterministic ray / node / triangle tallies of this rank's shard (untimed)
+    step(count=True)
     fence()
     cnt = jtx._capi.Counters()
     jtx._capi.check(lib.jtx_mi_get_counters(scene.handle, C.byref(cnt)))
@@ -227,37 +316,40 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
 
+    # N = 1: the same frames DELIVERED TO HOST buffers (jtx_mi_render: SURVEY 8d's wall time, first launch to last byte of
+    # acc / img on the host), reported beside the HBM-resident figure (never as `value`)
+    host_ms = None
+    if world == 1:
+        import numpy as np
+        hacc = np.zeros(H * W * 3, np.float32); himg = np.zeros(H * W * 3, np.uint8)
+        o = jtx._capi.RenderOpts(); o.integrator = integrator
+        def host_frame():
+            jtx._capi.check(lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), hacc.ctypes.data_as(C.POINTER(C.c_float)),
+                                              himg.ctypes.data_as(C.POINTER(C.c_uint8)), jtx._capi.PROGRESS_CB(0), None))
+        host_frame()
+        th = time.perf_counter()
+        nh = max(1, min(args.steps, 5))
+        for _ in range(nh):
+            host_frame()
+        host_ms = (time.perf_counter() - th) / nh * 1e3
+        jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))     # drop those events
+
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
-        my_bytes = algorithmic_bytes(mine)               # rank 0's launch
         kernel_name = {1: "k_render_paths", 3: "k_render_stream"}.get(integrator)
         launches_per_frame = 1
+        info = scene.info()
+        sinfo = {"lds_resident": bool(info["lds_resident"]), "lds_bytes": 8 * 32 * info["num_nodes"] + 48 * info["num_prims"],
+                 "workgroups": 256 * 7}
+        roof_counters = mine
         if integrator == 2:
-            # dominant stage of the pipeline; its algorithmic bytes are the SURVEY 8d terms of that stage
-            stage_bytes = [27 * mine["n_camera"],
-                           32 * mine["n_nodes_closest"] + 56 * mine["n_tri_closest"] + 60 * mine["n_accept"] + 64 * mine["n_closest"],
-                           176 * mine["n_shade"],
-                           32 * mine["n_nodes_any"] + 56 * mine["n_tri_any"] + 64 * mine["n_any"], 0]
             names = ["k_wf_generate", "k_wf_trace<closest>", "k_wf_shade", "k_wf_trace<any>", "k_wf_resolve"]
             dom = max(range(5), key=lambda i: kind_ms[i][0])
             kernel_name = names[dom]
             launches_per_frame = max(1, kind_ms[dom][1])
             kernel_ms = kind_ms[dom][0] / launches_per_frame          # average launch duration of that kernel
-            my_bytes = stage_bytes[dom] // launches_per_frame         # algorithmic bytes per launch
-        achieved = my_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                if world == 1:
-                    w = j.get("workloads", {}).get(args.workload)
-                    if w is not None:
-                        traffic = w.get("hbm_bytes_per_launch")
-                    elif j.get("workload") == args.workload:
-                        traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        roof = roofline_block(args.workload if world == 1 else args.workload + f"@{world}", sinfo, roof_counters, kernel_name,
+                              kernel_ms, launches_per_frame, 256)
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -268,16 +360,14 @@ def main():
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
                        "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu",
                        "scene_upload_ms": round(t_upload * 1e3, 2),
-                       "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": scene.info()["lds_resident"],
-                       "wide_bvh_bytes": scene.info()["wide_bytes"]},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                         "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches_per_frame,
-                         "algorithmic_bytes_per_launch": my_bytes,
-                         "note": "algorithmic bytes = SURVEY 8d formula (the reference's binary-BVH layout) on this frame's device ray "
-                                 "counters; an LDS-resident BVH serves them on-chip and the 8-ary quantised BVH of HBM-resident "
-                                 "scenes fetches far fewer bytes per ray, so frac can exceed 1 (DESIGN.md section 6)"},
+                       "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": info["lds_resident"],
+                       "wide_bvh_bytes": info["wide_bytes"],
+                       "timed_region": "frames rendered into HBM-resident film buffers (jtx_mi_render_device), incl. the resolve pass"},
+            "roofline": roof,
         }
+        if host_ms is not None:
+            out["ms_per_step_host"] = round(host_ms, 3)
+            out["value_host"] = round(rays_frame / host_ms / 1e3, 2)        # Mrays/s with the film delivered to host memory (PCIe-inclusive)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(data, W, H, xs, ys, depth)

@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define JTX_MI_VERSION 1
+#define JTX_MI_VERSION 2
+#define JTX_MI_CANCELLED 2   /* jtx_mi_render: stopped by the callback / jtx_mi_cancel; the film holds the completed passes */
 
 /* LinearBVHNode, src/bvh.hpp:7-15 (32 B) */
 typedef struct {
@@ -160,14 +161,35 @@ int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
 int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
 
 /* StaticCamera::render(const Scene&) (camera.cpp:45-128), blocking.  acc_rgb: W*H*3 float sums
- * (AccumulationBuffer), img_rgb: W*H*3 u8 (RGB8Image); both HOST buffers owned by the caller. */
+ * (AccumulationBuffer), img_rgb: W*H*3 u8 (RGB8Image); both HOST buffers owned by the caller.
+ * With a callback, one pass = opts.samples_per_tick strata (samplesPerPass_, camera.hpp:181): after every pass img_rgb
+ * holds the preview of the samples so far (what the UI uploads, display.cpp:702-703) and cb(current_sample, total, user)
+ * runs while the next pass is already rendering; acc_rgb is written once, before the call returns.
+ * Cancellation (Camera::terminateRender, camera.hpp:77; the reference polls stopRender_ per pixel, camera.cpp:84-98):
+ * a non-zero return of the callback, or jtx_mi_cancel() from ANY thread at ANY time -- the persistent kernels poll the
+ * flag whenever a wave fetches its next chunk of 64 x strata paths, so a running pass stops within microseconds of work
+ * per wave; an abandoned pass leaves no trace in the film.  Returns JTX_MI_CANCELLED then (acc_rgb / img_rgb hold the
+ * completed passes; jtx_mi_last_completed_sample tells how many strata that is), 0 when the frame is complete. */
 int jtx_mi_render(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
                   float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user);
+int jtx_mi_cancel(jtx_mi_scene *scene);                                     /* Camera::terminateRender(); thread-safe */
+/* Optional: page-lock a caller buffer (Camera::img_ / acc_, image.hpp:60-61,90-91) for as long as it lives, so that
+ * jtx_mi_render DMA-writes it directly; pageable buffers work too (one extra host copy from the library's pinned staging). */
+int jtx_mi_pin_host(void *ptr, uint64_t bytes);
+int jtx_mi_unpin_host(void *ptr);
+int jtx_mi_last_completed_sample(const jtx_mi_scene *scene, int32_t *out);  /* currentSample_ after the last jtx_mi_render */
 
 /* Same, DEVICE buffers, asynchronous on `stream` (a hipStream_t, NULL = the library's own stream).
- * d_acc_rgb must stay valid until the stream is synchronised.  Used by bench.py / multi-GPU. */
+ * d_acc_rgb must stay valid until the stream is synchronised.  Used by bench.py / multi-GPU.
+ * ONE STREAM PER SCENE AT A TIME: the per-path radiance buffer, the chunk counters, the wavefront slot arrays and the
+ * ray counters are per-scene singletons -- renders of one scene must all be ordered on one stream (or be separated by a
+ * synchronisation); renders of DIFFERENT scenes are independent.  jtx_mi_render uses the library's own stream.
+ * jtx_mi_cancel() also stops a device render in flight (the film then keeps its previous content). */
 int jtx_mi_render_device(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
                          void *d_acc_rgb, void *d_img_rgb, void *stream);
+/* for jtx_mi_render_device users: the cancellation word of jtx_mi_cancel is sticky; jtx_mi_render clears it itself */
+int jtx_mi_cancel_pending(const jtx_mi_scene *scene, int32_t *out);
+int jtx_mi_cancel_reset(jtx_mi_scene *scene);
 int jtx_mi_sync(jtx_mi_scene *scene);
 /* GPU time of the integrator kernel(s) of the last render call(s) since the previous query,
  * from HIP events recorded on the launch stream: sum in ms and number of launches. */
@@ -176,6 +198,22 @@ int jtx_mi_kernel_time(jtx_mi_scene *scene, float *ms_total, int32_t *launches);
  * query: [0] generate, [1] trace closest, [2] shade, [3] trace any (shadow), [4] resolve. */
 int jtx_mi_kernel_time_by_kind(jtx_mi_scene *scene, float *ms5, int32_t *n5);
 int jtx_mi_get_counters(jtx_mi_scene *scene, jtx_mi_counters *out);  /* of the last count_rays render */
+
+/* ---- one host process, N devices (replaces the thread pool of StaticCamera::render, camera.cpp:55-127) ----
+ * jtx_mi_multi_create replicates the scene on every listed device (devices == NULL: 0..n-1; a device may be listed more
+ * than once, its shards then share it).  jtx_mi_multi_render is jtx_mi_render over all of them: shard r renders the
+ * 32x32 tiles k % n == r, pushes its own pixels to devices[0] over xGMI (one hipMemcpyPeerAsync pair per shard and pass)
+ * and devices[0] assembles the frame -- the same bytes one device renders alone.  Same progress / cancellation contract
+ * as jtx_mi_render (jtx_mi_multi_cancel from any thread); count_rays and sample_begin > 0 are not supported here. */
+typedef struct jtx_mi_multi jtx_mi_multi;
+int  jtx_mi_multi_create(const jtx_mi_scene_desc *desc, const int32_t *devices, int32_t n_devices, jtx_mi_multi **out);
+void jtx_mi_multi_destroy(jtx_mi_multi *m);
+int  jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
+                         float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user);
+int  jtx_mi_multi_cancel(jtx_mi_multi *m);
+int  jtx_mi_multi_last_completed_sample(const jtx_mi_multi *m, int32_t *out);
+/* GPU ms of the integrator kernel per shard in the last jtx_mi_multi_render (n values) */
+int  jtx_mi_multi_shard_time(jtx_mi_multi *m, float *ms_per_shard, int32_t n);
 
 /* Fine-grained entry points for parity tests (HOST buffers; blocking). */
 /* Scene::closestHit (scene.cpp:10-55): prim = index into the BVH-ordered refs, -1 on miss */

@@ -5,5 +5,5 @@ The directory name has a hyphen (it is the name the task prescribes); import it 
 `importlib.import_module("jtx-pathtracer_amd")`.
 """
 from . import _capi, scenes, api, distributed, gltf     # noqa: F401
-from .api import Scene, StaticCamera, DynamicCamera, JtxMiError  # noqa: F401
+from .api import Scene, MultiScene, StaticCamera, DynamicCamera, JtxMiError  # noqa: F401
 from .build import build_all, lib_is_built      # noqa: F401

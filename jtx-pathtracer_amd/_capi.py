@@ -79,6 +79,7 @@ class SceneInfo(C.Structure):
                 ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32)]
 
 
+CANCELLED = 2          # JTX_MI_CANCELLED
 PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_int32, C.c_void_p)
 
 P = C.POINTER
@@ -98,6 +99,18 @@ SYMBOLS = {
     "jtx_mi_scene_get_info": (C.c_int, [_scene, P(SceneInfo)]),
     "jtx_mi_scene_get_bvh": (C.c_int, [_scene, P(BvhNode), P(TriRef)]),
     "jtx_mi_render": (C.c_int, [_scene, P(CameraDesc), P(RenderOpts), _f, _u8, PROGRESS_CB, C.c_void_p]),
+    "jtx_mi_cancel": (C.c_int, [_scene]),
+    "jtx_mi_pin_host": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "jtx_mi_unpin_host": (C.c_int, [C.c_void_p]),
+    "jtx_mi_cancel_pending": (C.c_int, [_scene, P(C.c_int32)]),
+    "jtx_mi_cancel_reset": (C.c_int, [_scene]),
+    "jtx_mi_multi_create": (C.c_int, [P(SceneDesc), P(C.c_int32), C.c_int32, P(C.c_void_p)]),
+    "jtx_mi_multi_destroy": (None, [C.c_void_p]),
+    "jtx_mi_multi_render": (C.c_int, [C.c_void_p, P(CameraDesc), P(RenderOpts), _f, _u8, PROGRESS_CB, C.c_void_p]),
+    "jtx_mi_multi_cancel": (C.c_int, [C.c_void_p]),
+    "jtx_mi_multi_last_completed_sample": (C.c_int, [C.c_void_p, P(C.c_int32)]),
+    "jtx_mi_multi_shard_time": (C.c_int, [C.c_void_p, _f, C.c_int32]),
+    "jtx_mi_last_completed_sample": (C.c_int, [_scene, P(C.c_int32)]),
     "jtx_mi_render_device": (C.c_int, [_scene, P(CameraDesc), P(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p]),
     "jtx_mi_sync": (C.c_int, [_scene]),
     "jtx_mi_kernel_time": (C.c_int, [_scene, _f, _i]),

@@ -7,6 +7,7 @@ Names and argument meaning follow the reference (src/scene.hpp:24-91, src/camera
 Everything that computes runs in the HIP library; nothing here falls back to the CPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -187,6 +188,53 @@ def wide_build_host(nodes):
     return out[: ng.value], depth.value
 
 
+class MultiScene:
+    """N replicas of a scene on N devices behind one handle (jtx_mi_multi_*, csrc/jtx_multi.hip): what a C++ host gets
+    from Scene::useDevices().  devices: list of device indices (a device may repeat: its shards share it)."""
+
+    def __init__(self, data, devices, maxPrimsInNode=1):
+        self._lib = capi.load()
+        self.data = data
+        data.max_prims_in_node = maxPrimsInNode
+        desc = data.to_desc()
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self._lib.jtx_mi_multi_create(C.byref(desc), devs, len(devices), C.byref(h)))
+        self._h, self.n = h, len(devices)
+
+    def render(self, cam, progress=None, samples_per_tick=0):
+        """jtx_mi_multi_render into cam.acc_ / cam.img_ (a StaticCamera); returns True when complete, False when cancelled."""
+        o = capi.RenderOpts(); o.samples_per_tick = samples_per_tick
+        cb = capi.PROGRESS_CB(lambda cur, tot, _u: 1 if (progress is not None and progress(cur, tot)) else 0)
+        d = cam.desc()
+        rc = self._lib.jtx_mi_multi_render(self._h, C.byref(d), C.byref(o), _fp(cam.acc_), cam.img_.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None)
+        if rc != capi.CANCELLED:
+            check(rc)
+        done = C.c_int32(0)
+        check(self._lib.jtx_mi_multi_last_completed_sample(self._h, C.byref(done)))
+        cam.currentSample_ = done.value
+        return rc == 0
+
+    def cancel(self):
+        self._lib.jtx_mi_multi_cancel(self._h)
+
+    def shard_ms(self):
+        ms = (C.c_float * self.n)()
+        check(self._lib.jtx_mi_multi_shard_time(self._h, ms, self.n))
+        return [float(x) for x in ms]
+
+    def destroy(self):
+        if self._h is not None:
+            self._lib.jtx_mi_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class StaticCamera:
     """StaticCamera (src/camera.hpp:179-188) -- one blocking render per call."""
 
@@ -207,12 +255,39 @@ class StaticCamera:
         return self.xPixelSamples_ * self.yPixelSamples_
 
     def terminateRender(self):
+        """Camera::terminateRender (camera.hpp:77): also reaches the pass in flight (jtx_mi_cancel)."""
         self.stopRender_ = True
+        sc = getattr(self, "_active_scene", None)
+        if sc is not None and sc.handle:
+            self._lib.jtx_mi_cancel(sc.handle)
 
     def resize(self, w, h):
+        self._unpin()
         self.width_, self.height_ = int(w), int(h)
         self.img_ = np.zeros((h, w, 3), np.uint8)
         self.acc_ = np.zeros((h, w, 3), np.float32)
+
+    # img_ / acc_ live as long as the camera (image.hpp:60-61,90-91): page-lock them once so that jtx_mi_render DMA-writes
+    # them directly (jtx_mi_pin_host); a refusal only costs the library's staging copy
+    def _pin(self):
+        if getattr(self, "_pinned", None) is None:
+            self._pinned = []
+            if os.environ.get("JTX_PIN_CAMERA_BUFFERS", "1") == "0":
+                return
+            for a in (self.img_, self.acc_):
+                if self._lib.jtx_mi_pin_host(a.ctypes.data_as(C.c_void_p), a.nbytes) == 0:
+                    self._pinned.append(a)
+
+    def _unpin(self):
+        for a in getattr(self, "_pinned", None) or []:
+            self._lib.jtx_mi_unpin_host(a.ctypes.data_as(C.c_void_p))
+        self._pinned = None
+
+    def __del__(self):
+        try:
+            self._unpin()
+        except Exception:
+            pass
 
     def clear(self):
         self.img_[...] = 0
@@ -246,10 +321,18 @@ class StaticCamera:
 
         cb = capi.PROGRESS_CB(_cb)
         cam = self.desc()
-        check(self._lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), _fp(self.acc_),
-                                      self.img_.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None))
-        if progress is None:
-            self.currentSample_ = sample_end if sample_end > 0 else self.getSpp()
+        self._pin()
+        self._active_scene = scene
+        try:
+            rc = self._lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), _fp(self.acc_),
+                                         self.img_.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None)
+        finally:
+            self._active_scene = None
+        if rc != capi.CANCELLED:
+            check(rc)
+        done = C.c_int32(0)
+        check(self._lib.jtx_mi_last_completed_sample(scene.handle, C.byref(done)))
+        self.currentSample_ = done.value
         if count_rays:
             c = capi.Counters()
             check(self._lib.jtx_mi_get_counters(scene.handle, C.byref(c)))
@@ -281,10 +364,15 @@ class DynamicCamera(StaticCamera):
         self._thread = threading.Thread(target=self._workerThread, daemon=True)
         self._thread.start()
 
+    def _abandon(self):             # caller holds _cv: reach the pass in flight instead of waiting for its end
+        if self._busy and self._scene is not None and self._scene.handle:
+            self._lib.jtx_mi_cancel(self._scene.handle)
+
     def render(self, scene, **_unused):
         with self._cv:
             self._pending = False
             self._generation += 1
+            self._abandon()
             self._cv.wait_for(lambda: not self._busy)
             self._scene = scene
             self.acc_[...] = 0; self.img_[...] = 0
@@ -297,6 +385,7 @@ class DynamicCamera(StaticCamera):
         with self._cv:
             self._pending = False
             self._generation += 1
+            self._abandon()
             self._cv.wait_for(lambda: not self._busy)
             super().resize(w, h)
             self._scene = None
@@ -306,6 +395,7 @@ class DynamicCamera(StaticCamera):
         with self._cv:
             self._stop = True
             self._generation += 1
+            self._abandon()
             self._cv.notify_all()
         self._thread.join()
 
@@ -342,7 +432,7 @@ class DynamicCamera(StaticCamera):
                 try:
                     rc = self._lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), _fp(self.acc_),
                                                  self.img_.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None)
-                    err = None if rc == 0 else self._lib.jtx_mi_last_error().decode()
+                    err = None if rc in (0, capi.CANCELLED) else self._lib.jtx_mi_last_error().decode()
                 finally:
                     self._cv.acquire()
                 self._error = err

@@ -6,7 +6,9 @@
 #include "jtx_host.hpp"
 #include "jtx_launch.hpp"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -52,6 +54,16 @@ constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + 
 
 } // namespace
 
+namespace {
+bool hostPinned(const void *p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void) hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+}
+
+int jtx_capi_fail(const std::string &msg) { return fail(msg); }     // for the other translation units of the library
+
 struct jtx_mi_scene {
     jtxh::BvhResult bvh;
     DevBuf<float4> tnodes, tris, shade;
@@ -81,11 +93,18 @@ struct jtx_mi_scene {
     size_t device_bytes = 0;
     int device = 0;
     std::mutex mu;
+    unsigned char *pin_img = nullptr; float *pin_acc = nullptr; size_t pin_pixels = 0;   // pinned staging for pageable caller buffers
+    int last_completed = 0;              // strata in the film after the last jtx_mi_render (== sample_end unless cancelled)
+    unsigned *stop_host = nullptr;       // host-mapped cancellation word (jtx_mi_cancel), read by the persistent kernels
+    const unsigned *stop_dev = nullptr;
 
     ~jtx_mi_scene() {
         for (auto &e : pending) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         for (auto &e : free_events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         if (stream) (void) hipStreamDestroy(stream);
+        if (stop_host) (void) hipHostFree(stop_host);
+        if (pin_img) (void) hipHostFree(pin_img);
+        if (pin_acc) (void) hipHostFree(pin_acc);
     }
 };
 
@@ -595,6 +614,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     const int tiles = p.tiles_x * ((cam.height + 31) / 32);
     const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
     p.acc = d_acc; p.img = d_img;
+    p.stop = s.stop_dev;
     const bool count = o.count_rays != 0;
     if (count) {
         if (!s.counters.p) s.counters.alloc(64);
@@ -744,6 +764,9 @@ int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
         jtxh::buildBVH(*desc, s->bvh);
         flatten(*desc, *s);
         HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        HIPCHK(hipHostMalloc((void **) &s->stop_host, sizeof(unsigned), hipHostMallocMapped));
+        *s->stop_host = 0u;
+        { void *d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, s->stop_host, 0)); s->stop_dev = (const unsigned *) d; }
         { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, s->device)); s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
         *out = s;
         return 0;
@@ -905,6 +928,23 @@ int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 
+int jtx_mi_cancel_pending(const jtx_mi_scene *s, int32_t *out) {
+    if (!s || !out || !s->stop_host) return fail("null argument");
+    *out = __atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE) ? 1 : 0;
+    return 0;
+}
+int jtx_mi_cancel_reset(jtx_mi_scene *s) {
+    if (!s || !s->stop_host) return fail("null scene");
+    __atomic_store_n(s->stop_host, 0u, __ATOMIC_RELEASE);
+    return 0;
+}
+
+int jtx_mi_cancel(jtx_mi_scene *s) {
+    if (!s || !s->stop_host) return fail("null scene");
+    __atomic_store_n(s->stop_host, 1u, __ATOMIC_RELEASE);
+    return 0;
+}
+
 int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
                   float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user) {
     try {
@@ -918,18 +958,53 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         if (sb >= se) throw std::runtime_error("empty sample range");
         const size_t npix = (size_t) cam->width * cam->height;
         std::unique_lock<std::mutex> lk(s->mu);
+        __atomic_store_n(s->stop_host, 0u, __ATOMIC_RELEASE);                  // stopRender_ = false (camera.cpp:48)
         if (s->film_acc.n != 3 * npix) { s->film_acc.alloc(3 * npix); s->film_img.alloc(3 * npix); }
         if (sb == 0) HIPCHK(hipMemsetAsync(s->film_acc.p, 0, sizeof(float) * 3 * npix, s->stream));
         else HIPCHK(hipMemcpyAsync(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix, hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemsetAsync(s->film_img.p, 0, 3 * npix, s->stream));
         const int tick = (cb && o.samples_per_tick > 0) ? o.samples_per_tick : (se - sb);
         jtx_mi_counters total{}; const bool count = o.count_rays != 0;
-        for (int b = sb; b < se; b += tick) {
+        // Passes are pipelined one deep: pass i + 1 is enqueued before pass i's preview is handed to the callback, so the
+        // GPU never waits for the host.  Per pass only the RGB8 preview travels (what the UI shows, display.cpp:702-703);
+        // the float accumulation buffer is copied once, at the end or at the cancellation.
+        auto enqueue = [&](int b) {
             const int e = b + tick < se ? b + tick : se;
             launchRender(*s, *cam, o, b, e, s->film_acc.p, img_rgb ? s->film_img.p : nullptr, s->stream);
-            HIPCHK(hipMemcpyAsync(acc_rgb, s->film_acc.p, sizeof(float) * 3 * npix, hipMemcpyDeviceToHost, s->stream));
-            if (img_rgb) HIPCHK(hipMemcpyAsync(img_rgb, s->film_img.p, 3 * npix, hipMemcpyDeviceToHost, s->stream));
+            return e;
+        };
+        // Film delivery: a pinned caller buffer (jtx_mi_pin_host / hipHostRegister: what the Camera mirrors do with img_ /
+        // acc_) is the DMA target itself; a pageable one is fed through the scene's pinned staging buffers and one host
+        // memcpy -- hipMemcpy to pageable memory would stage through small driver buffers at a fraction of the PCIe rate.
+        const bool imgDirect = img_rgb && hostPinned(img_rgb), accDirect = hostPinned(acc_rgb);
+        if ((img_rgb && !imgDirect) || !accDirect) {
+            if (s->pin_pixels != npix) {
+                if (s->pin_img) (void) hipHostFree(s->pin_img);
+                if (s->pin_acc) (void) hipHostFree(s->pin_acc);
+                s->pin_img = nullptr; s->pin_acc = nullptr; s->pin_pixels = 0;
+                HIPCHK(hipHostMalloc((void **) &s->pin_img, 3 * npix, hipHostMallocDefault));
+                HIPCHK(hipHostMalloc((void **) &s->pin_acc, 3 * npix * sizeof(float), hipHostMallocDefault));
+                s->pin_pixels = npix;
+            }
+        }
+        static const bool trace = getenv("JTX_TRACE_RENDER") != nullptr;        // developer aid: host-side phase times to stderr
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tMark = now();
+        auto lap = [&](const char *what) { if (trace) { const double t = now(); fprintf(stderr, "[jtx_mi_render] %-18s %8.3f ms\n", what, t - tMark); tMark = t; } };
+        auto fetchImg = [&] {                                                   // blocks until the stream has drained
+            if (!img_rgb) { HIPCHK(hipStreamSynchronize(s->stream)); return; }
+            HIPCHK(hipMemcpyAsync(imgDirect ? img_rgb : s->pin_img, s->film_img.p, 3 * npix, hipMemcpyDeviceToHost, s->stream));
             HIPCHK(hipStreamSynchronize(s->stream));
+        };
+        bool cancelled = false;
+        int done = sb;                                                          // strata whose sums are in the film
+        int inFlightEnd = enqueue(sb);
+        while (true) {
+            lap("enqueue");
+            fetchImg();                                                         // the pass in flight: preview to (pinned) host memory
+            lap("pass + img D2H");
+            if (__atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE)) { cancelled = true; break; }   // that pass was abandoned by the kernels
+            done = inFlightEnd;
             if (count) {
                 unsigned long long h[9];
                 HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
@@ -937,20 +1012,59 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                 total.n_tri_closest += h[4]; total.n_accept += h[5]; total.n_nodes_any += h[6]; total.n_tri_any += h[7];
                 total.n_shade += h[8];
             }
+            const bool more = done < se;
+            if (more && !count) inFlightEnd = enqueue(done);                   // next pass runs while the host copies / the callback looks
+            if (img_rgb && !imgDirect && (cb || !more)) std::memcpy(img_rgb, s->pin_img, 3 * npix);
+            lap("img memcpy");
             if (cb) {
                 lk.unlock();
-                const int stop = cb(e, spp, user);                      // currentSample_ advance, camera.cpp:68-74
+                const int stop = cb(done, spp, user);                           // currentSample_ advance, camera.cpp:68-74
                 lk.lock();
-                if (stop) break;
+                if (stop) {
+                    if (more && !count) {                                       // abandon the pass in flight
+                        __atomic_store_n(s->stop_host, 1u, __ATOMIC_RELEASE);
+                        HIPCHK(hipStreamSynchronize(s->stream));
+                    }
+                    cancelled = true; break;
+                }
             }
+            if (!more) break;
+            if (count) inFlightEnd = enqueue(done);                            // counted passes: the counter block is per launch
         }
+        HIPCHK(hipMemcpyAsync(accDirect ? acc_rgb : s->pin_acc, s->film_acc.p, sizeof(float) * 3 * npix, hipMemcpyDeviceToHost, s->stream));
+        if (cancelled) fetchImg(); else HIPCHK(hipStreamSynchronize(s->stream));
+        if (cancelled && img_rgb && !imgDirect) std::memcpy(img_rgb, s->pin_img, 3 * npix);
+        lap("acc D2H");
+        if (!accDirect) std::memcpy(acc_rgb, s->pin_acc, sizeof(float) * 3 * npix);
+        lap("acc memcpy");
+        s->last_completed = done;
         if (count) {   // leave the frame totals on the device for jtx_mi_get_counters
             unsigned long long h[9] = {total.n_camera, total.n_closest, total.n_any, total.n_nodes_closest, total.n_tri_closest,
                                        total.n_accept, total.n_nodes_any, total.n_tri_any, total.n_shade};
             HIPCHK(hipMemcpy(s->counters.p, h, sizeof h, hipMemcpyHostToDevice));
         }
-        return 0;
+        return cancelled ? JTX_MI_CANCELLED : 0;
     } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+// Pin a caller buffer so that jtx_mi_render DMA-writes it directly (Camera::img_ / acc_ live as long as the camera).
+int jtx_mi_pin_host(void *ptr, uint64_t bytes) {
+    if (!ptr || !bytes) return fail("null argument");
+    hipError_t e = hipHostRegister(ptr, (size_t) bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void) hipGetLastError(); return fail(std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    return 0;
+}
+int jtx_mi_unpin_host(void *ptr) {
+    if (!ptr) return fail("null argument");
+    hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void) hipGetLastError(); return fail(std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
+    return 0;
+}
+
+int jtx_mi_last_completed_sample(const jtx_mi_scene *s, int32_t *out) {
+    if (!s || !out) return fail("null argument");
+    *out = s->last_completed;
+    return 0;
 }
 
 } // extern "C"

@@ -305,7 +305,18 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             if (next >= nunits) {                                        // chunk used up: fetch the next one
                 if (exhausted) { need = false; break; }
                 int c = 0;
+#ifdef JTX_NO_STOP_POLL            /* A/B only: what the cancellation poll costs */
                 if (lane == 0) c = (int) atomicAdd(p.work, 1u);
+#else
+                if (lane == 0) {
+                    c = (int) atomicAdd(p.work, 1u);
+                    // cancellation poll: the flag lives in HOST memory (one PCIe read), so only every 64th fetch looks, and the
+                    // wave that sees it pushes the chunk counter past the end: every other wave stops at its next fetch
+                    if (p.stop && (c & 63) == 0 && c < nchunks && __hip_atomic_load(p.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                        atomicMax(p.work, 0x40000000u); c = nchunks;
+                    }
+                }
+#endif
                 c = __shfl(c, 0, 64);
                 if (c >= nchunks) { exhausted = true; need = false; break; }
                 // chunk c: strata group-major, so that the whole frame advances stratum range by stratum range
@@ -523,6 +534,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
     const int row = trow * 32 + (sub >> 2) * 8 + (lane >> 3);
     const int col = tcol * 32 + (sub & 3) * 8 + (lane & 7);
     if (pslot >= p.rad_stride || row >= p.height || col >= p.width) return;
+    if (p.stop && __hip_atomic_load(p.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;   // cancelled pass: its records are incomplete
     const size_t pix = (size_t) row * p.width + col;
     f3 acc = mk3(0.0f);
     if (p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);

@@ -24,6 +24,10 @@ struct RenderParams {
     float4 *rad; int strata_per_group; int rad_stride;
     // k_render_paths: persistent waves take (8x8 pixel block, strata group) chunks from this counter (zeroed per launch)
     unsigned *work; int num_subblocks; int num_groups;
+    // cancellation (Camera::terminateRender / stopRender_, camera.hpp:77, polled per pixel camera.cpp:84-98): a host-mapped
+    // word; persistent waves read it whenever they fetch a chunk and stop handing out paths, k_resolve_samples then leaves
+    // the film as the last completed pass left it
+    const unsigned *stop;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----

@@ -315,7 +315,14 @@ k_render_stream(RenderParams p) {
                 if (mask == 0ull) break;
                 if (next >= nunits) {                                         // chunk used up: fetch the next one
                     int c = 0;
-                    if (lane == 0) c = (int) atomicAdd(p.work, 1u);
+                    if (lane == 0) {
+                    c = (int) atomicAdd(p.work, 1u);
+                    // cancellation poll: the flag lives in HOST memory (one PCIe read), so only every 64th fetch looks, and the
+                    // wave that sees it pushes the chunk counter past the end: every other wave stops at its next fetch
+                    if (p.stop && (c & 63) == 0 && c < nchunks && __hip_atomic_load(p.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                        atomicMax(p.work, 0x40000000u); c = nchunks;
+                    }
+                }
                     c = __shfl(c, 0, 64);
                     if (c >= nchunks) { exhausted = true; need = false; break; }
                     const int grp = c / p.num_subblocks, sb8 = c - grp * p.num_subblocks;

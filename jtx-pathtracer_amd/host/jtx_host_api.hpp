@@ -67,6 +67,10 @@ public:
     ~Scene() { destroyBVH(); }
     int numPrimitives() const { return (int) triangles.size(); }
 
+    // Multi-GPU: name the devices BEFORE buildBVH(); StaticCamera::render then shards the frame over them
+    // (jtx_mi_multi_render: tile k of camera.cpp:55-64 goes to devices[k % n]).  Empty = the current device only.
+    void useDevices(std::vector<int> devices) { devices_ = std::move(devices); }
+
     void buildBVH(int maxPrimsInNode = 1) {                           // scene.cpp:96-135 -> jtx_mi_scene_create
         if (handle_) return;
         std::vector<jtx_mi_mesh> ms(meshes.size());
@@ -100,10 +104,12 @@ public:
         d.sky_color[0] = skyColor.x; d.sky_color[1] = skyColor.y; d.sky_color[2] = skyColor.z;
         d.max_prims_in_node = maxPrimsInNode;
         check(jtx_mi_scene_create(&d, &handle_));
+        if (devices_.size() > 1) check(jtx_mi_multi_create(&d, devices_.data(), (int) devices_.size(), &multi_));
         jtx_mi_scene_info info; check(jtx_mi_scene_get_info(handle_, &info));
         for (auto &l : lights) if (l.type == Light::DISTANT) l.sceneRadius = info.scene_radius;   // scene.cpp:128-134
     }
-    void destroyBVH() { if (handle_) { jtx_mi_scene_destroy(handle_); handle_ = nullptr; } }
+    void destroyBVH() { if (multi_) { jtx_mi_multi_destroy(multi_); multi_ = nullptr; } if (handle_) { jtx_mi_scene_destroy(handle_); handle_ = nullptr; } }
+    jtx_mi_multi *multiHandle() const { return multi_; }
     void rebuildBVH(int maxPrimsInNode = 1) { destroyBVH(); buildBVH(maxPrimsInNode); }
     void destroy() { destroyBVH(); }                                  // mesh arrays stay with the caller
     float getSceneRadius() const { if (!handle_) return 0; jtx_mi_scene_info i; check(jtx_mi_scene_get_info(handle_, &i)); return i.scene_radius; }
@@ -126,6 +132,8 @@ public:
 private:
     jtx_mi_scene *need() const { if (!handle_) throw std::runtime_error("Scene::buildBVH() has not been called"); return handle_; }
     jtx_mi_scene *handle_ = nullptr;
+    jtx_mi_multi *multi_ = nullptr;
+    std::vector<int> devices_;
 };
 
 struct RGB { unsigned char R, G, B; };
@@ -169,7 +177,8 @@ public:
         : width_(width), height_(height), aspectRatio_((float) width / (float) height), xPixelSamples_(xs), yPixelSamples_(ys),
           maxDepth_(maxDepth), properties_(cp), img_(width, height), acc_(width, height), threadCount_(threadCount) {}
     void save(const char *path) const { img_.save(path); }
-    void resize(int w, int h) { width_ = w; height_ = h; aspectRatio_ = (float) w / (float) h; img_.clear(); img_.resize(w, h); acc_.clear(); acc_.resize(w, h); }
+    ~Camera() { unpin(); }
+    void resize(int w, int h) { unpin(); width_ = w; height_ = h; aspectRatio_ = (float) w / (float) h; img_.clear(); img_.resize(w, h); acc_.clear(); acc_.resize(w, h); }
     void clear() { img_.clear(); }
     void terminateRender() { stopRender_ = true; }
     int getSpp() const { return xPixelSamples_ * yPixelSamples_; }
@@ -179,6 +188,18 @@ protected:
     AccumulationBuffer acc_;
     int threadCount_;
     std::atomic<bool> stopRender_{false};
+    // img_ / acc_ live as long as the camera: page-lock them once so that jtx_mi_render DMA-writes them directly
+    // (a refusal only costs the library's staging copy)
+    bool pinnedImg_ = false, pinnedAcc_ = false;
+    void pin() {
+        if (!pinnedImg_) pinnedImg_ = jtx_mi_pin_host(&img_.data()[0].R, (uint64_t) width_ * height_ * 3) == 0;
+        if (!pinnedAcc_) pinnedAcc_ = jtx_mi_pin_host(&acc_.data()[0].x, (uint64_t) width_ * height_ * 3 * sizeof(float)) == 0;
+    }
+    void unpin() {
+        if (pinnedImg_) jtx_mi_unpin_host(&img_.data()[0].R);
+        if (pinnedAcc_) jtx_mi_unpin_host(&acc_.data()[0].x);
+        pinnedImg_ = pinnedAcc_ = false;
+    }
     jtx_mi_camera_desc desc() const {
         jtx_mi_camera_desc c{};
         for (int k = 0; k < 3; ++k) { c.center[k] = properties_.center[k]; c.target[k] = properties_.target[k]; c.up[k] = properties_.up[k]; }
@@ -195,19 +216,37 @@ public:
     // StaticCamera::render(const Scene&) camera.cpp:45-128: blocking; img_ and currentSample_ advance per pass so a UI
     // thread can keep showing the progressive image (display.cpp:702-703); terminateRender() stops after the pass.
     void render(const Scene &scene) {
-        stopRender_ = false; currentSample_.store(0); acc_.clear();
+        stopRender_ = false; currentSample_.store(0); acc_.clear(); pin();
         jtx_mi_render_opts o{}; o.samples_per_tick = samplesPerPass_ > 0 ? samplesPerPass_ : 1;
         jtx_mi_camera_desc c = desc();
-        check(jtx_mi_render(scene.handle(), &c, &o, &acc_.data()[0].x, &img_.data()[0].R, &StaticCamera::tick, this));
+        int rc;
+        if (jtx_mi_multi *mh = scene.multiHandle()) {                    // Scene::useDevices: the frame is sharded over the GPUs
+            activeMulti_ = mh;
+            rc = jtx_mi_multi_render(mh, &c, &o, &acc_.data()[0].x, &img_.data()[0].R, &StaticCamera::tick, this);
+            activeMulti_ = nullptr;
+        } else {
+            active_ = scene.handle();
+            rc = jtx_mi_render(scene.handle(), &c, &o, &acc_.data()[0].x, &img_.data()[0].R, &StaticCamera::tick, this);
+            active_ = nullptr;
+        }
+        if (rc != JTX_MI_CANCELLED) check(rc);
+    }
+    // Camera::terminateRender (camera.hpp:77): also reaches the pass in flight
+    void terminateRender() {
+        stopRender_ = true;
+        if (jtx_mi_scene *h = active_) jtx_mi_cancel(h);
+        if (jtx_mi_multi *h = activeMulti_) jtx_mi_multi_cancel(h);
     }
     // one-shot variant without per-pass host copies (what a non-interactive caller wants)
     void renderFinal(const Scene &scene) {
-        stopRender_ = false; acc_.clear();
+        stopRender_ = false; acc_.clear(); pin();
         jtx_mi_camera_desc c = desc();
         check(jtx_mi_render(scene.handle(), &c, nullptr, &acc_.data()[0].x, &img_.data()[0].R, nullptr, nullptr));
         currentSample_.store(getSpp());
     }
 private:
+    std::atomic<jtx_mi_scene *> active_{nullptr};
+    std::atomic<jtx_mi_multi *> activeMulti_{nullptr};
     static int tick(int32_t cur, int32_t, void *user) { auto *self = (StaticCamera *) user; self->currentSample_.store(cur); return self->stopRender_ ? 1 : 0; }
 };
 
@@ -224,12 +263,12 @@ public:
     ~DynamicCamera() { stopThreads(); }
     void resize(int w, int h) {                                        // camera.cpp:191-194
         std::unique_lock<std::mutex> lk(mu_);
-        pending_ = false; ++generation_; idle_.wait(lk, [&] { return !busy_; });   // let the pass in flight drain before the buffers move
+        pending_ = false; ++generation_; abandon(); idle_.wait(lk, [&] { return !busy_; });   // stop the pass in flight before the buffers move
         Camera::resize(w, h); scene_ = nullptr; currentSample_.store(0);
     }
     void render(const Scene &scene) {                                  // camera.cpp:196-211
         std::unique_lock<std::mutex> lk(mu_);
-        pending_ = false; ++generation_; idle_.wait(lk, [&] { return !busy_; });
+        pending_ = false; ++generation_; abandon(); idle_.wait(lk, [&] { return !busy_; });
         scene_ = &scene; acc_.clear(); img_.clear(); currentSample_.store(0); error_.clear();
         pending_ = true;
         lk.unlock(); wake_.notify_all();
@@ -247,9 +286,10 @@ private:
     unsigned long generation_ = 0, running_ = 0;
     bool busy_ = false, pending_ = false, stopThreads_ = false;
     std::string error_;
+    void abandon() { if (busy_ && scene_) jtx_mi_cancel(scene_->handle()); }   // caller holds mu_: reach the pass in flight
     void startThreads() { stopThreads_ = false; thread_ = std::thread(&DynamicCamera::workerThread, this); }
     void stopThreads() {                                               // camera.cpp:178-189
-        { std::unique_lock<std::mutex> lk(mu_); stopThreads_ = true; ++generation_; }
+        { std::unique_lock<std::mutex> lk(mu_); stopThreads_ = true; ++generation_; abandon(); }
         wake_.notify_all();
         if (thread_.joinable()) thread_.join();
     }
@@ -271,7 +311,7 @@ private:
             lk.unlock();
             const int rc = jtx_mi_render(scene->handle(), &c, &o, &acc_.data()[0].x, &img_.data()[0].R, &DynamicCamera::tick, this);
             lk.lock();
-            if (rc) error_ = jtx_mi_last_error();
+            if (rc && rc != JTX_MI_CANCELLED) error_ = jtx_mi_last_error();
             busy_ = false;
             idle_.notify_all();
         }

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <vector>
 #include <omp.h>
 
@@ -1316,20 +1318,37 @@ void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int
     };
 
     if (reference_barriers) {
-        // one pass (= one barrier) per sample, as samplesPerPass_ = 1 (camera.hpp:181)
-        for (int cs = sample_begin; cs < sample_end; ++cs) {
-            std::atomic<size_t> next{0};
-            std::vector<std::thread> pool;
-            for (int t = 0; t < threads; ++t)
-                pool.emplace_back([&, t] {
+        // StaticCamera::render's own schedule (camera.cpp:67-127): threadCount_ PERSISTENT threads pull 32x32 tiles from
+        // an atomic job index; one pass = samplesPerPass_ = 1 sample (camera.hpp:181); a std::barrier after every pass
+        // whose completion step advances currentSample_ and rewinds the job index (camera.cpp:68-74).
+        std::atomic<size_t> next{0};
+        std::atomic<int> current{sample_begin};
+        std::mutex mu; std::condition_variable cv;
+        int waiting = 0; unsigned long generation = 0;
+        auto arriveAndWait = [&] {
+            std::unique_lock<std::mutex> lk(mu);
+            const unsigned long gen = generation;
+            if (++waiting == threads) {
+                current.fetch_add(1); next.store(0);                            // the barrier's completion function
+                waiting = 0; ++generation;
+                cv.notify_all();
+            } else cv.wait(lk, [&] { return generation != gen; });
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] {
+                while (true) {
+                    const int cs = current.load();
+                    if (cs >= sample_end) break;                                // stopRender_
                     while (true) {
                         size_t j = next.fetch_add(1, std::memory_order_relaxed);
                         if (j >= jobs.size()) break;
                         tileSamples(jobs[j], cs, cs + 1, count ? &tc[t] : nullptr);
                     }
-                });
-            for (auto &th : pool) th.join();
-        }
+                    arriveAndWait();
+                }
+            });
+        for (auto &th : pool) th.join();
     } else {
         std::atomic<size_t> next{0};
         std::vector<std::thread> pool;

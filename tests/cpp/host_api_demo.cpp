@@ -49,6 +49,16 @@ int main() {
         }
         dyn.stopRender();
         std::printf("dynhash %08x dynsamples %d restart_same %d\n", hd, dyn.currentSample_.load(), same);
+        // the same frame over 3 shards through jtx_mi_multi_render (Scene::useDevices; all on device 0 here, 8 GPUs on a node)
+        scene.destroy();
+        scene.useDevices({0, 0, 0});
+        scene.buildBVH();
+        StaticCamera mcam(64, 64, scene.cameraProperties, 2, 2, 4);
+        mcam.render(scene);
+        unsigned hm = 2166136261u;
+        const unsigned char *bm = &mcam.img_.data()[0].R;
+        for (int i = 0; i < 64 * 64 * 3; ++i) { hm ^= bm[i]; hm *= 16777619u; }
+        std::printf("multihash %08x multisamples %d\n", hm, mcam.currentSample_.load());
         scene.destroy();
         return 0;
     } catch (const std::exception &e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }

@@ -86,3 +86,27 @@ def test_owner_masks_partition_the_frame():
         assert (cover == 1).all()
         tiles = ((w + 31) // 32) * ((h + 31) // 32)
         assert sum(jtx.distributed.owned_tiles(w, h, r, world) for r in range(world)) == tiles
+
+
+def test_tile_slot_maps_cpp(tmp_path):
+    """The C++ side of the exchange (csrc/jtx_tiles.hpp, used by jtx_multi.hip's pack / scatter kernels and by the render
+    kernels): slot <-> pixel maps are inverse bijections for ragged sizes and 1..8 shards.  Pure host C++, no GPU."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tile_map_test")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-o", exe, os.path.join(root, "tests", "cpp", "tile_map_test.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "tile maps ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_python_and_cpp_tile_maps_agree():
+    """distributed.tile_owner_mask (what the torchrun path packs / scatters by) and jtx_tiles.hpp's pixelToSlot name the
+    same owner for every pixel."""
+    import numpy as np
+    from jtx_pathtracer_amd import distributed as D
+    for (w, h, world) in [(200, 100, 3), (1920, 1080, 8), (33, 65, 2)]:
+        tiles_x = (w + 31) // 32
+        rows, cols = np.mgrid[0:h, 0:w]
+        owner = ((rows // 32) * tiles_x + cols // 32) % world           # pixelToSlot's rank
+        for r in range(world):
+            assert np.array_equal(D.tile_owner_mask(w, h, r, world), owner == r)

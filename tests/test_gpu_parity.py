@@ -12,6 +12,14 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def atrium_full(gpu):
+    data = gpu.scenes.atrium()                            # C3 / C4 scene: ~262 k triangles
+    sc = gpu.Scene(data); sc.buildBVH()
+    yield data, sc, ol.OracleScene(data)
+    sc.destroy()
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
@@ -205,6 +213,51 @@ def test_render_resume_and_progress(gpu, cornell_pair):
     stop = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4)
     stop.render(sc, progress=lambda c, t: stop.terminateRender() if c == 2 else None)
     assert stop.currentSample_ == 2
+    two = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4); two.render(sc, sample_begin=0, sample_end=2)
+    assert_same_f32(stop.acc_, two.acc_, "film after a cancellation = the completed passes, nothing of the abandoned one")
+    assert (stop.img_ == two.img_).all()
+
+
+def test_cancel_reaches_the_pass_in_flight(gpu, atrium_full):
+    """Camera::terminateRender from another thread (the UI thread, display.cpp:899-910) while ONE long pass is on the
+    GPU (the reference polls stopRender_ per pixel, camera.cpp:84-98): the persistent waves stop fetching chunks, the
+    call returns early with the film untouched, and the next render of the same scene is complete and correct."""
+    import threading, time
+    data, sc, osc = atrium_full
+    cam = gpu.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+    t0 = time.perf_counter(); cam.render(sc); t_full = time.perf_counter() - t0
+    ref_acc = cam.acc_.copy(); ref_img = cam.img_.copy()
+    assert cam.currentSample_ == 64
+    timer = threading.Timer(0.03, cam.terminateRender)
+    t0 = time.perf_counter(); timer.start(); cam.render(sc); t_cancel = time.perf_counter() - t0
+    timer.join()
+    assert cam.currentSample_ == 0 and not cam.acc_.any() and not cam.img_.any(), "an abandoned pass must leave no trace"
+    assert t_cancel < 0.6 * t_full, (t_cancel, t_full)
+    cam.render(sc)                                                    # stopRender_ = false again (camera.cpp:48)
+    assert cam.currentSample_ == 64
+    assert_same_f32(cam.acc_, ref_acc, "render after a cancelled one"); assert (cam.img_ == ref_img).all()
+
+
+def test_dynamic_camera_on_a_second_device(gpu, cornell_pair):
+    """Every scene-taking entry point switches to the scene's device: a DynamicCamera worker thread (which never called
+    hipSetDevice) renders a scene that lives on device 1.  Needs two visible devices."""
+    import ctypes as C
+    lib = gpu._capi.load()
+    n = C.c_int32(0); gpu._capi.check(lib.jtx_mi_device_count(C.byref(n)))
+    if n.value < 2:
+        pytest.skip("one visible device")
+    data, sc0, osc = cornell_pair
+    gpu._capi.check(lib.jtx_mi_set_device(1))
+    try:
+        sc1 = gpu.Scene(data); sc1.buildBVH()
+    finally:
+        gpu._capi.check(lib.jtx_mi_set_device(0))
+    ref = gpu.StaticCamera(96, 64, data.camera, 2, 2, 4); ref.render(sc0)
+    dyn = gpu.DynamicCamera(96, 64, data.camera, 2, 2, 4, samplesPerPass=1)
+    dyn.render(sc1); assert dyn.wait(60)
+    dyn.stopRender()
+    assert_same_f32(dyn.acc_, ref.acc_, "DynamicCamera on device 1"); assert (dyn.img_ == ref.img_).all()
+    sc1.destroy()
 
 
 @pytest.mark.parametrize("integrator", [1, 2, 3])
@@ -266,6 +319,7 @@ def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
     assert abs(float(kv["t"]) - 9.0) < 1e-5 and abs(float(kv["radius"]) - 2 ** 0.5) < 1e-4
     # DynamicCamera: same image as the static render; a restarted render equals a static one from the new camera
     assert kv["dynhash"] == "1af9ba89" and kv["dynsamples"] == "4" and kv["restart_same"] == "1"
+    assert kv["multihash"] == "1af9ba89" and kv["multisamples"] == "4"      # 3 shards through jtx_mi_multi_render
 
 
 @pytest.mark.parametrize("integrator", [1, 2, 3])
@@ -851,14 +905,6 @@ def test_timed_launch_config2_full_frame(gpu, cornell_pair):
     assert np.abs(img_u[rows, cols].astype(np.int32) - _expect_bytes(expect, 64)).max() <= 1
 
 
-@pytest.fixture(scope="module")
-def atrium_full(gpu):
-    data = gpu.scenes.atrium()                            # C3 / C4 scene: ~262 k triangles
-    sc = gpu.Scene(data); sc.buildBVH()
-    yield data, sc, ol.OracleScene(data)
-    sc.destroy()
-
-
 def test_timed_launch_config3_full_frame(gpu, atrium_full):
     """C3 exactly as timed: atrium (262 k triangles), 1920x1080, ALL 64 strata, depth 8, one rank, uncounted =
     the 8-ary quantised traversal (k_render_paths<WIDE>) -- against the counted binary-record frame and the oracle."""
@@ -926,3 +972,41 @@ def test_timed_launch_config4_shard_and_pass_split(gpu, atrium_full):
     assert np.array_equal(acc_f[rows2, cols2].view(np.uint32), expect2.view(np.uint32))
     del acc_s, acc_f
     torch.cuda.empty_cache()
+
+
+# ---- one host process, N devices behind the C-ABI (jtx_mi_multi_*) ----
+@pytest.mark.parametrize("shards", [1, 2, 3, 8])
+def test_multi_device_render_equals_one_device(gpu, cornell_pair, shards):
+    """jtx_mi_multi_render over `shards` shards (all on device 0 here: render -> pack -> peer copy -> scatter is the code
+    an 8-GPU node runs, with hipMemcpyPeerAsync degenerating to a device copy) gives the one-device frame bit for bit,
+    at a ragged size, with and without per-pass previews."""
+    data, sc, osc = cornell_pair
+    ref = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4); ref.render(sc)
+    ms = gpu.MultiScene(data, [0] * shards)
+    cam = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
+    assert ms.render(cam)
+    assert_same_f32(cam.acc_, ref.acc_, f"{shards} shards"); assert (cam.img_ == ref.img_).all()
+    assert cam.currentSample_ == 8 and len(ms.shard_ms()) == shards
+    seen = []
+    cam2 = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
+    assert ms.render(cam2, progress=lambda c, t: seen.append(c), samples_per_tick=3)
+    assert seen == [3, 6, 8]
+    assert_same_f32(cam2.acc_, ref.acc_, f"{shards} shards, 3 passes"); assert (cam2.img_ == ref.img_).all()
+    # cancellation by the callback after the first pass: the frame holds exactly that pass
+    cam3 = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
+    assert not ms.render(cam3, progress=lambda c, t: True, samples_per_tick=3)
+    part = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4); part.render(sc, sample_begin=0, sample_end=3)
+    assert cam3.currentSample_ == 3
+    assert_same_f32(cam3.acc_, part.acc_, "cancelled multi render"); assert (cam3.img_ == part.img_).all()
+    ms.destroy()
+
+
+def test_multi_device_full_size_config2(gpu, cornell_pair):
+    """C2 (1920x1080, 64 spp) over 8 shards through jtx_mi_multi_render = the 1-device timed frame, bit for bit."""
+    data, sc, osc = cornell_pair
+    ref = gpu.StaticCamera(1920, 1080, data.camera, 8, 8, 8); ref.render(sc)
+    ms = gpu.MultiScene(data, [0] * 8)
+    cam = gpu.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+    assert ms.render(cam)
+    assert_same_f32(cam.acc_, ref.acc_, "8 shards, C2"); assert (cam.img_ == ref.img_).all()
+    ms.destroy()
