@@ -38,12 +38,14 @@ typedef struct { int32_t index; int32_t mesh_index; } jtx_mi_tri_ref;
 
 /* Material, src/material.hpp:5-23.  Texture ids: -1 = none (reference quirk Q4). */
 typedef struct {
-    int32_t type;          /* 0 DIFFUSE, 1 DIELECTRIC, 2 CONDUCTOR, 3 METALLIC_ROUGHNESS */
+    int32_t type;          /* 0 DIFFUSE, 1 DIELECTRIC, 2 CONDUCTOR, 3 METALLIC_ROUGHNESS (material.hpp:6-11);
+                            * 4 THIN_DIELECTRIC = ThinDielectricBxDF (dielectric.hpp:163-207; eta = ior[0]), which the reference's
+                            * bxdf.cpp never dispatches */
     float   albedo[3];
     float   ior[3];
     float   k[3];
     float   alpha_x, alpha_y;   /* METALLIC_ROUGHNESS: alpha_x = metallic, alpha_y = roughness (loader.cpp:136-137) */
-    float   emission[3];        /* carried, unused by integrateMIS (integrator.cpp:189-190) */
+    float   emission[3];        /* Material::emission: added by integrate / integrateBasic (integrator.cpp:27,75), not by integrateMIS (:189-190) */
     int32_t albedo_tex;
     int32_t mr_tex;
 } jtx_mi_material;
@@ -114,6 +116,9 @@ typedef struct {
                                * (same leaves, same order, same hits: DESIGN.md section 3) */
     int32_t samples_per_tick; /* progress callback granularity for jtx_mi_render; <= 0 => all */
     int32_t reserved;         /* bit 0: time every wavefront kernel with its own HIP events (jtx_mi_kernel_time_by_kind) */
+    int32_t path_integrator;  /* which Li (camera.cpp:104-106 picks by (un)commenting a line): 0 integrateMIS (integrator.cpp:171-216,
+                               * the timed path), 1 integrate (:54-132: NEE without MIS, emission), 2 integrateBasic (:12-52: emission,
+                               * no light sampling).  1 and 2 (and scenes with a THIN_DIELECTRIC material) run in k_render_alt. */
 } jtx_mi_render_opts;
 
 /* ray / traffic counters */
@@ -237,6 +242,9 @@ int jtx_mi_camera_rays(const jtx_mi_camera_desc *cam, int32_t n, const int32_t *
 /* integrateMIS (integrator.cpp:171-216) + the <=1 clamp (camera.cpp:110-112) per listed (row,col,sample) */
 int jtx_mi_radiance_samples(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, int32_t n, const int32_t *row,
                             const int32_t *col, const int32_t *sample, float *rgb);
+/* the same for integrate (li = 1) / integrateBasic (li = 2) / integrateMIS with every BxDF incl. THIN_DIELECTRIC (li = 0) */
+int jtx_mi_radiance_samples_li(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, int32_t li, int32_t n, const int32_t *row,
+                               const int32_t *col, const int32_t *sample, float *rgb);
 /* RNG (util/rand.hpp:42-107) streams and the deterministic sin/cos, for known-answer tests */
 int jtx_mi_rng_stream(uint32_t x, uint32_t y, uint32_t n, int32_t count, uint32_t *out_u32, float *out_f32);
 int jtx_mi_sincos_batch(const float *x, int32_t n, float *out_sin, float *out_cos);

@@ -62,7 +62,7 @@ class CameraDesc(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("tile_rank", C.c_int32),
                 ("tile_world", C.c_int32), ("integrator", C.c_int32), ("count_rays", C.c_int32),
-                ("samples_per_tick", C.c_int32), ("reserved", C.c_int32)]
+                ("samples_per_tick", C.c_int32), ("reserved", C.c_int32), ("path_integrator", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -123,6 +123,7 @@ SYMBOLS = {
     "jtx_mi_bxdf_pdf_batch": (C.c_int, [_scene, C.c_int32, C.c_int32, _f, _f, _f, _f, _f]),
     "jtx_mi_camera_rays": (C.c_int, [P(CameraDesc), C.c_int32, _i, _i, _i, _f, _f]),
     "jtx_mi_radiance_samples": (C.c_int, [_scene, P(CameraDesc), C.c_int32, _i, _i, _i, _f]),
+    "jtx_mi_radiance_samples_li": (C.c_int, [_scene, P(CameraDesc), C.c_int32, C.c_int32, _i, _i, _i, _f]),
     "jtx_mi_rng_stream": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, _u32, _f]),
     "jtx_mi_sincos_batch": (C.c_int, [_f, C.c_int32, _f, _f]),
 }

@@ -302,8 +302,9 @@ class StaticCamera:
         return c
 
     def render(self, scene, count_rays=False, progress=None, tile_rank=0, tile_world=1, sample_begin=0, sample_end=0,
-               integrator=0):
-        """StaticCamera::render(const Scene&) (camera.cpp:45-128)."""
+               integrator=0, path_integrator=0):
+        """StaticCamera::render(const Scene&) (camera.cpp:45-128).  path_integrator: which Li (camera.cpp:104-106):
+        0 integrateMIS, 1 integrate, 2 integrateBasic."""
         self.stopRender_ = False
         self.currentSample_ = 0
         o = capi.RenderOpts()
@@ -311,6 +312,7 @@ class StaticCamera:
         o.tile_rank, o.tile_world = tile_rank, tile_world
         o.sample_begin, o.sample_end = sample_begin, sample_end
         o.integrator = integrator
+        o.path_integrator = path_integrator
         o.samples_per_tick = self.samplesPerPass_ if progress is not None else 0
 
         def _cb(cur, total, _user):
@@ -449,12 +451,15 @@ def camera_rays(cam_desc, row, col, sample):
     return o, d
 
 
-def radiance_samples(scene, cam_desc, row, col, sample):
+def radiance_samples(scene, cam_desc, row, col, sample, path_integrator=None):
     lib = capi.load()
     row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32); sample = np.ascontiguousarray(sample, np.int32)
     n = len(row)
     rgb = np.zeros((n, 3), np.float32)
-    check(lib.jtx_mi_radiance_samples(scene.handle, C.byref(cam_desc), n, _ip(row), _ip(col), _ip(sample), _fp(rgb)))
+    if path_integrator is None:
+        check(lib.jtx_mi_radiance_samples(scene.handle, C.byref(cam_desc), n, _ip(row), _ip(col), _ip(sample), _fp(rgb)))
+    else:
+        check(lib.jtx_mi_radiance_samples_li(scene.handle, C.byref(cam_desc), path_integrator, n, _ip(row), _ip(col), _ip(sample), _fp(rgb)))
     return rgb
 
 

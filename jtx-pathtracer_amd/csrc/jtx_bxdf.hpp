@@ -7,22 +7,23 @@
 
 namespace jtx {
 
-// Device material record (64 B, one per material; read through the scalar/L1 path).
+// Device material record (80 B, one per material; read through the scalar/L1 path).
 struct DMaterial {
-    int   type;            // 0 DIFFUSE 1 DIELECTRIC 2 CONDUCTOR 3 METALLIC_ROUGHNESS (material.hpp:6-11)
+    int   type;            // 0 DIFFUSE 1 DIELECTRIC 2 CONDUCTOR 3 METALLIC_ROUGHNESS (material.hpp:6-11), 4 THIN_DIELECTRIC (dielectric.hpp:163-207)
     float albedo[3];
     float ior[3];
     float k[3];
     float alpha_x, alpha_y;
     int   albedo_tex, mr_tex;
-    int   pad[2];
+    float emission[3];     // Material::emission (material.hpp:19): read by integrate / integrateBasic only
+    int   pad[3];
 };
 // Device texture descriptor.  `linear_off` points at texels already run through sRGBToLinear on the
 // host at scene_create (color.hpp:13-23 is a pure per-texel function, so decoding once is identical
 // to decoding at every lookup, bxdf.cpp:18,45); `raw_off` at the untouched texels.
 struct DTexture { int w, h, c; int pad; long long raw_off; long long linear_off; };
 
-struct BSample { f3 f; f3 wi; float pdf; };
+struct BSample { f3 f; f3 wi; float pdf; bool specular; };   // specular = BSDFSample::isSpecular (bxdf.hpp:123): only DielectricBxDF sets it
 
 // ---- Fresnel & helpers (bxdf.hpp:7-116) ----
 JD f3 reflect(f3 wo, f3 n) { return -wo + 2.0f * dot(wo, n) * n; }
@@ -185,6 +186,7 @@ JD f3 dielectricEval(GGX mf, float eta, f3 wo, f3 wi) {
     return mk3(a / b);
 }
 JD bool dielectricSample(GGX mf, float eta, f3 wo, float uc, f2 u, BSample &s) {
+    s.specular = mf.smooth();                                                      // dielectric.hpp:43, carried by every sample it returns
     if (eta == 1.0f || mf.smooth()) {
         float R = fresnelDielectric(wo.z, eta);
         float T = 1.0f - R;
@@ -236,6 +238,25 @@ JD float dielectricPdf(GGX mf, float eta, f3 wo, f3 wi) {
     if (refl) return mf.pdf(wo, wm) / (4.0f * absdot(wo, wm)) * (R / (R + T));
     float dn = absdot(wi, wm) / sqr(dot(wi, wm) + dot(wo, wm) / etap);
     return mf.pdf(wo, wm) * dn * (T / (R + T));
+}
+
+// ---- ThinDielectricBxDF (dielectric.hpp:163-207): evaluate = {}, pdf = 0, sample = the specular pair with inter-reflection ----
+JD bool thinDielectricSample(float eta, f3 wo, float uc, BSample &s) {
+    float R = fresnelDielectric(wo.z, eta);
+    float T = 1.0f - R;
+    if (R < 1.0f) {
+        R += (T * T * R) / (1.0f - R * R);
+        T = 1.0f - R;
+    }
+    const float p = R / (R + T);
+    if (uc < p) {
+        f3 wi = mk3(-wo.x, -wo.y, wo.z);
+        s.f = mk3(R / absCosTheta(wi)); s.wi = wi; s.pdf = p;
+        return true;
+    }
+    f3 wi = -wo;
+    s.f = mk3(T / absCosTheta(wi)); s.wi = wi; s.pdf = 1.0f - p;
+    return true;
 }
 
 // ---- glTF metallic-roughness (gltf.hpp:9-123) ----
@@ -333,7 +354,7 @@ JD void mrParams(const ShadeCtx &c, const DMaterial &m, f2 uv, float &metallic, 
 // MASK = bit set of Material::Type values the scene actually contains (scene_create knows them): the
 // kernels are instantiated for "diffuse only" and "anything", so an all-Lambert scene such as the
 // Cornell box does not carry the GGX / Fresnel code (registers, I-cache) it can never reach.
-constexpr int MAT_ALL = 15, MAT_DIFFUSE_ONLY = 1;
+constexpr int MAT_ALL = 15, MAT_DIFFUSE_ONLY = 1, MAT_EVERY = 31;   // MAT_EVERY: + THIN_DIELECTRIC (the alternate-integrator kernels)
 
 // sampleBxdf (bxdf.cpp:9-77)
 template <int MASK = MAT_ALL>
@@ -342,6 +363,7 @@ JD bool sampleBxdf(const ShadeCtx &c, const DMaterial &m, f3 normal, f2 uv, f3 w
     f3 wol = fr.toLocal(wo);
     if (wol.z == 0.0f) return false;
     bool ok = false;
+    out.specular = false;
     if ((MASK & 8) && m.type == 3) {
         float metallic, roughness; mrParams(c, m, uv, metallic, roughness);
         MR b; b.mf.ax = b.mf.ay = roughness * roughness; b.albedo = albedoOf(c, m, uv); b.metallic = metallic;
@@ -354,6 +376,8 @@ JD bool sampleBxdf(const ShadeCtx &c, const DMaterial &m, f3 normal, f2 uv, f3 w
     } else if ((MASK & 2) && m.type == 1) {
         GGX g; g.ax = m.alpha_x; g.ay = m.alpha_y;
         ok = dielectricSample(g, m.ior[0], wol, uc, u, out);
+    } else if ((MASK & 16) && m.type == 4) {
+        ok = thinDielectricSample(m.ior[0], wol, uc, out);
     }
     if (!ok) return false;
     if (!nonzero(out.f) || out.pdf == 0.0f || out.wi.z == 0.0f) return false;

@@ -128,7 +128,7 @@ void validate(const jtx_mi_scene_desc &d) {
     }
     for (int i = 0; i < d.num_materials; ++i) {
         const jtx_mi_material &m = d.materials[i];
-        if (m.type < 0 || m.type > 3) throw std::runtime_error("material.type out of range");
+        if (m.type < 0 || m.type > 4) throw std::runtime_error("material.type out of range (0..3 Material::Type, 4 THIN_DIELECTRIC)");
         if (m.albedo_tex < -1 || m.albedo_tex >= d.num_textures || m.mr_tex < -1 || m.mr_tex >= d.num_textures)
             throw std::runtime_error("material texture id out of range (-1 = none)");
     }
@@ -400,7 +400,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         DMaterial &o = mats[i];
         std::memset(&o, 0, sizeof o);
         o.type = m.type;
-        for (int k = 0; k < 3; ++k) { o.albedo[k] = m.albedo[k]; o.ior[k] = m.ior[k]; o.k[k] = m.k[k]; }
+        for (int k = 0; k < 3; ++k) { o.albedo[k] = m.albedo[k]; o.ior[k] = m.ior[k]; o.k[k] = m.k[k]; o.emission[k] = m.emission[k]; }
         o.alpha_x = m.alpha_x; o.alpha_y = m.alpha_y;
         o.albedo_tex = m.albedo_tex; o.mr_tex = m.mr_tex;
         if (m.albedo_tex >= 0) usedAsAlbedo[m.albedo_tex] = 1;
@@ -631,12 +631,18 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     while (s.pending.size() >= 64 && hipEventQuery(s.pending.front().second) == hipSuccess) {
         s.free_events.push_back(s.pending.front()); s.pending.erase(s.pending.begin());
     }
+    if (o.path_integrator < 0 || o.path_integrator > 2) throw std::runtime_error("path_integrator: 0 integrateMIS, 1 integrate, 2 integrateBasic");
+    const bool alt = o.path_integrator != 0 || (s.dev.material_mask & 16) != 0;
+    if (o.path_integrator == 1 && s.dev.num_lights == 0)
+        throw std::runtime_error("integrate (integrator.cpp:85) indexes scene.lights without a guard: the scene needs at least one light");
     auto ev = takeEvents(s);
     struct EvReturn { jtx_mi_scene &s; std::pair<hipEvent_t, hipEvent_t> ev; bool armed = true;
                       ~EvReturn() { if (armed) s.free_events.push_back(ev); } } evGuard{s, ev};   // a throw below must not leak the pair
     bool evClosed = false;
     HIPCHK(hipEventRecord(ev.first, stream));
-    if (integ == 1 || integ == 3) {
+    if (alt) {
+        HIPCHK(jtx_launch_render_alt(p, owned, count, o.path_integrator, stream));
+    } else if (integ == 1 || integ == 3) {
         // strata groups: the strata of a pixel block are spread over `groups` waves (gridDim.y); every path's clamped
         // radiance goes to rad[stratum][pixel] and k_resolve_samples adds them to the film in sample order.
         // One-lane-per-pixel launches (counting, JTX_DYNAMIC_PATHS=0) split only small shards / frames: 32 or 64 ways.
@@ -1175,6 +1181,24 @@ int jtx_mi_radiance_samples(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, int3
         Tmp<int> dR(row, n), dC(col, n), dS(sample, n);
         Tmp<float> dRGB(3 * (size_t) n);
         HIPCHK(jtx_launch_radiance_samples(s->dev, deriveCamera(*cam), cam->max_depth, n, dR.p, dC.p, dS.p, dRGB.p, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        dRGB.down(rgb);
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
+int jtx_mi_radiance_samples_li(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, int32_t li, int32_t n, const int32_t *row,
+                               const int32_t *col, const int32_t *sample, float *rgb) {
+    try {
+        if (!s || !cam || n < 0 || (n && (!row || !col || !sample || !rgb))) throw std::runtime_error("bad argument");
+        if (li < 0 || li > 2) throw std::runtime_error("li: 0 integrateMIS, 1 integrate, 2 integrateBasic");
+        if (li == 1 && s->dev.num_lights == 0) throw std::runtime_error("integrate needs at least one light");
+        DeviceGuard dg(s->device);
+        checkCamera(*cam);
+        if (n == 0) return 0;
+        Tmp<int> dR(row, n), dC(col, n), dS(sample, n);
+        Tmp<float> dRGB(3 * (size_t) n);
+        HIPCHK(jtx_launch_radiance_samples_alt(s->dev, deriveCamera(*cam), cam->max_depth, li, n, dR.p, dC.p, dS.p, dRGB.p, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         dRGB.down(rgb);
         return 0;

@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(BLOCK) k_bxdf_batch(DevScene sc, int mode, int
     const f3 w_o = mk3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
     if (mode == 0) {
         BSample bs; bs.f = bs.wi = mk3(0.0f); bs.pdf = 0.0f;
-        const bool r = sampleBxdf(ctx, m, nrm, tuv, w_o, uc[i], mk2(u2[2 * i], u2[2 * i + 1]), bs);
+        const bool r = sampleBxdf<MAT_EVERY>(ctx, m, nrm, tuv, w_o, uc[i], mk2(u2[2 * i], u2[2 * i + 1]), bs);
         if (!r) { bs.f = bs.wi = mk3(0.0f); bs.pdf = 0.0f; }
         ok[i] = r ? 1 : 0;
         f[3 * i] = bs.f.x; f[3 * i + 1] = bs.f.y; f[3 * i + 2] = bs.f.z;
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(BLOCK) k_bxdf_batch(DevScene sc, int mode, int
     } else {
         const f3 w_i = mk3(wi_in[3 * i], wi_in[3 * i + 1], wi_in[3 * i + 2]);
         f3 fv; float pv;
-        evalPdfBxdf(ctx, m, nrm, tuv, w_o, w_i, fv, pv);
+        evalPdfBxdf<MAT_EVERY>(ctx, m, nrm, tuv, w_o, w_i, fv, pv);
         if (f) { f[3 * i] = fv.x; f[3 * i + 1] = fv.y; f[3 * i + 2] = fv.z; }
         if (pdf) pdf[i] = pv;
     }

@@ -71,6 +71,9 @@ hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
 hipError_t jtx_launch_render_stream(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
+hipError_t jtx_launch_render_alt(const jtx::RenderParams &p, int num_owned_tiles, bool count, int li, hipStream_t stream);
+hipError_t jtx_launch_radiance_samples_alt(const jtx::DevScene &sc, const jtx::DCam &cam, int maxDepth, int li, int n, const int *row,
+                                           const int *col, const int *sample, float *rgb, hipStream_t stream);
 hipError_t jtx_launch_resolve_samples(const jtx::RenderParams &p, int num_owned_tiles, hipStream_t stream);
 hipError_t jtx_launch_closest_batch(const jtx::DevScene &sc, int n, const float *o, const float *d, float tmin, float tmax,
                                     int *hit, float *t, int *prim, float *b1, float *b2, float *point, float *normal,

@@ -20,6 +20,7 @@ import numpy as np
 from . import _capi as capi
 
 DIFFUSE, DIELECTRIC, CONDUCTOR, METALLIC_ROUGHNESS = 0, 1, 2, 3
+THIN_DIELECTRIC = 4                        # ThinDielectricBxDF (dielectric.hpp:163-207); not a Material::Type of the reference
 POINT, DISTANT = 0, 1
 
 GOLD_IOR = (0.15557, 0.42415, 1.3831)      # src/scene.cpp:7
@@ -296,6 +297,41 @@ def mixed(sphere_res=(48, 24), textured=True):
     s.lights = [light(POINT, (278.0, 500.0, 279.5), (1, 1, 1), 60000.0),
                 light(DISTANT, (0.3, -0.8, 0.52), (1, 0.95, 0.9), 1.5)]
     s.sky = SKY_BLUE
+    s.camera = dict(center=(278.0, 273.0, -800.0), target=(278.0, 273.0, 0.0), up=(0, 1, 0), yfov=39.3077,
+                    defocus_angle=0.0, focus_distance=1.0)
+    return s
+
+
+def emissive(sphere_res=(16, 8)):
+    """Scene for the alternate integrators: the Cornell room whose area_light quad EMITS (cornell_box.obj:121-132),
+    spheres of every BxDF incl. a smooth dielectric (the one BxDF that reports isSpecular), a rough one and two
+    THIN_DIELECTRIC panes, one emissive sphere; a point light so that integrate has something to sample."""
+    s = SceneData("emissive")
+    s.materials = [material(DIFFUSE, (0.73, 0.73, 0.73)), material(DIFFUSE, (0.65, 0.05, 0.05)),
+                   material(DIFFUSE, (0.12, 0.45, 0.15)), material(DIFFUSE, (0.78, 0.78, 0.78), emission=(17.0, 12.0, 4.0))]
+    _cornell_meshes(s, lambda n: {"left_wall": 1, "right_wall": 2, "area_light": 3}.get(n, 0))
+    specs = [
+        material(DIELECTRIC, ior=(1.5, 1.5, 1.5), alpha_x=0.0, alpha_y=0.0),
+        material(THIN_DIELECTRIC, ior=(1.5, 1.5, 1.5)),
+        material(DIELECTRIC, ior=(1.5, 1.5, 1.5), alpha_x=0.3, alpha_y=0.3),
+        material(CONDUCTOR, ior=GOLD_IOR, k=GOLD_K, alpha_x=0.0, alpha_y=0.0),
+        material(METALLIC_ROUGHNESS, (0.9, 0.6, 0.2), alpha_x=1.0, alpha_y=0.3),
+        material(DIFFUSE, (0.2, 0.2, 0.25), emission=(0.4, 0.9, 1.6)),
+        material(THIN_DIELECTRIC, ior=(1.33, 1.33, 1.33)),
+        material(DIFFUSE, (0.4, 0.7, 0.4)),
+    ]
+    base = len(s.materials)
+    s.materials += specs
+    nu, nv = sphere_res
+    k = 0
+    for gy in range(2):
+        for gx in range(4):
+            c = (90.0 + gx * 125.0, 90.0 + gy * 200.0 + (gx % 2) * 40.0, 120.0 + ((gx + gy) % 3) * 140.0)
+            idx, v, n, uv = uv_sphere(c, 48.0, nu, nv)
+            s.add_mesh(idx, v, n, base + k, uvs=uv, name=f"sphere{k}")
+            k += 1
+    s.lights = [light(POINT, (278.0, 500.0, 279.5), (1, 1, 1), 30000.0)]
+    s.sky = (0.05, 0.06, 0.08)
     s.camera = dict(center=(278.0, 273.0, -800.0), target=(278.0, 273.0, 0.0), up=(0, 1, 0), yfov=39.3077,
                     defocus_angle=0.0, focus_distance=1.0)
     return s

@@ -703,7 +703,7 @@ struct GGX {
     }
 };
 
-struct BSample { V3 f; V3 wi; float pdf; };
+struct BSample { V3 f; V3 wi; float pdf; bool specular = false; };   // specular = BSDFSample::isSpecular (bxdf.hpp:123)
 
 // DiffuseBxDF (bsdf/diffuse.hpp)
 inline V3 diffuseEval(V3 R, V3 wo, V3 wi) { return sameHemisphere(wo, wi) ? R * INV_PI : v3(0); }
@@ -776,18 +776,19 @@ inline V3 dielectricEval(GGX mf, float eta, V3 wo, V3 wi) {                     
     }
 }
 inline bool dielectricSample(GGX mf, float eta, V3 wo, float uc, V2 u, BSample &s) {               // dielectric.hpp:42-108
+    const bool isSpecular = mf.smooth();                                        // dielectric.hpp:43: s = {f, w_i, pdf, 0, isSpecular} in all four returns
     if (eta == 1 || mf.smooth()) {
         float R = fresnelDielectric(cosTheta(wo), eta);
         float T = 1 - R;
         float p = R / (R + T);
         if (uc < p) {
             V3 wi = v3(-wo.x, -wo.y, wo.z);
-            s = {v3(R / absCosTheta(wi)), wi, p};
+            s = {v3(R / absCosTheta(wi)), wi, p, isSpecular};
             return true;
         } else {
             V3 wi; float etap;
             if (!refract(wo, v3(0, 0, 1), eta, &etap, wi)) return false;
-            s = {v3(T / absCosTheta(wi)), wi, 1 - p};
+            s = {v3(T / absCosTheta(wi)), wi, 1 - p, isSpecular};
             return true;
         }
     }
@@ -800,7 +801,7 @@ inline bool dielectricSample(GGX mf, float eta, V3 wo, float uc, V2 u, BSample &
         if (!sameHemisphere(wo, wi)) return false;
         float pdf = mf.pdf(wo, wm) / (4 * absdot(wo, wm)) * p;
         float f = mf.D(wm) * mf.G(wo, wi) * R / (4 * absCosTheta(wi) * absCosTheta(wo));
-        s = {v3(f), wi, pdf};
+        s = {v3(f), wi, pdf, isSpecular};
         return true;
     } else {
         float etap; V3 wi = v3(0);     // w_i default-constructed (0,0,0) when refract fails (dielectric.hpp:93-95)
@@ -810,7 +811,7 @@ inline bool dielectricSample(GGX mf, float eta, V3 wo, float uc, V2 u, BSample &
         float pdf = mf.pdf(wo, wm) * dn * (1 - p);
         float f = mf.D(wm) * T * mf.G(wo, wi) * std::fabs(dot(wi, wm) * dot(wo, wm));
         f /= sqr(dot(wi, wm) + dot(wm, wo) / etap) * std::fabs(cosTheta(wi) * cosTheta(wo));
-        s = {v3(f), wi, pdf};
+        s = {v3(f), wi, pdf, isSpecular};
         return true;
     }
 }
@@ -898,6 +899,26 @@ inline float mrPdf(const MR &b, V3 wo, V3 wi) {                                 
     return p * specularPdf + (1 - p) * diffusePdf;
 }
 
+// ThinDielectricBxDF::sample (dielectric.hpp:173-199); evaluate = {}, pdf = 0 (dielectric.hpp:167-169, 201-203).
+// The reference never dispatches it (bxdf.cpp has no case): Material type 4 is this build's way of reaching it.
+inline bool thinDielectricSample(float eta, V3 wo, float uc, BSample &s) {
+    float R = fresnelDielectric(wo.z, eta);
+    float T = 1 - R;
+    if (R < 1) {
+        R += (T * T * R) / (1 - R * R);
+        T = 1 - R;
+    }
+    const float p = R / (R + T);
+    if (uc < p) {
+        V3 wi = v3(-wo.x, -wo.y, wo.z);
+        s.f = v3(R / absCosTheta(wi)); s.wi = wi; s.pdf = p;
+        return true;
+    }
+    V3 wi = -wo;
+    s.f = v3(T / absCosTheta(wi)); s.wi = wi; s.pdf = 1 - p;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sampleBxdf / evalBxdf / pdfBxdf (bsdf/bxdf.cpp:9-166)
 // ---------------------------------------------------------------------------------------------
@@ -918,6 +939,7 @@ bool sampleBxdf(const ora_scene &s, const ora_material &m, V3 normal, V2 uv, V3 
     V3 wol = fr.toLocal(wo);
     if (wol.z == 0) return false;
     bool ok = false;
+    out.specular = false;                                                       // BSDFSample s; / s = {f, w_i, pdf}: default false
     if (m.type == 3) {
         float metallic, roughness; mrParams(s, m, uv, metallic, roughness);
         MR b{GGX{roughness * roughness, roughness * roughness}, albedoOf(s, m, uv), metallic};
@@ -928,6 +950,8 @@ bool sampleBxdf(const ora_scene &s, const ora_material &m, V3 normal, V2 uv, V3 
         ok = conductorSample(GGX{m.alpha_x, m.alpha_y}, a3(m.ior), a3(m.k), wol, u, out);
     } else if (m.type == 1) {
         ok = dielectricSample(GGX{m.alpha_x, m.alpha_y}, m.ior[0], wol, uc, u, out);
+    } else if (m.type == 4) {
+        ok = thinDielectricSample(m.ior[0], wol, uc, out);
     }
     if (!ok) return false;
     if (!nonzero(out.f) || out.pdf == 0 || out.wi.z == 0) return false;
@@ -1039,6 +1063,77 @@ V3 integrateMIS(const ora_scene &s, V3 o, V3 d, int maxDepth, Rng &rng, Counters
     return radiance;
 }
 
+// integrate integrator.cpp:54-132: next-event estimation without MIS; emission and sky only after a specular bounce
+V3 integrateNEE(const ora_scene &s, V3 o, V3 d, int maxDepth, Rng &rng, Counters *cnt) {
+    V3 radiance = v3(0), beta = v3(1);
+    int depth = 0;
+    bool specularBounce = true;
+    Hit rec;
+    const int n = (int) s.lights.size();
+    while (nonzero(beta)) {
+        bool hit = closestHit(s, o, d, 0.001f, INF_F, rec, cnt);
+        if (!hit) {
+            if (specularBounce) radiance = radiance + beta * s.sky;
+            break;
+        }
+        const ora_material &m = s.materials[rec.material];
+        if (specularBounce) radiance = radiance + beta * a3(m.emission);
+        if (depth++ == maxDepth) break;
+        V3 wo = -d;
+        {
+            uint32_t idx = rng.sampleRange(n - 1);                              // integrator.cpp:85 (needs a light: the callers refuse n == 0)
+            const ora_light &light = s.lights[idx];
+            (void) rng.f(); (void) rng.f();                                     // Vec2f u, integrator.cpp:95
+            LightSample ls;
+            bool lightSampled = lightSample(light, rec.point, ls);
+            if (lightSampled && ls.pdf > 0) {
+                V3 wi = ls.wi;
+                V3 f = evalBxdf(s, m, rec.normal, rec.uv, wo, wi) * absdot(wi, rec.normal);
+                V3 sOrigin = rec.point + rec.normal * RAY_EPSILON;
+                float lDist = len(rec.point - ls.p);
+                if (nonzero(f) && !anyHit(s, sOrigin, ls.wi, 0.0f, lDist - RAY_EPSILON, cnt))
+                    radiance = radiance + beta * f * ls.radiance / (ls.pdf * (1.0f / (float) n));
+            }
+        }
+        float u = rng.f();
+        V2 u2; u2.x = rng.f(); u2.y = rng.f();
+        BSample bs;
+        if (cnt) cnt->n_shade++;
+        if (!sampleBxdf(s, m, rec.normal, rec.uv, wo, u, u2, bs)) break;
+        beta = beta * (bs.f * absdot(bs.wi, rec.normal) / bs.pdf);            // unguarded, integrator.cpp:125
+        specularBounce = bs.specular;
+        o = rec.point + bs.wi * RAY_EPSILON;
+        d = bs.wi;
+    }
+    return radiance;
+}
+
+// integrateBasic integrator.cpp:12-52: no light sampling, emission at every hit
+V3 integrateBasic(const ora_scene &s, V3 o, V3 d, int maxDepth, Rng &rng, Counters *cnt) {
+    V3 radiance = v3(0), beta = v3(1);
+    int depth = 0;
+    Hit rec;
+    while (nonzero(beta)) {
+        bool hit = closestHit(s, o, d, 0.001f, INF_F, rec, cnt);
+        if (!hit) { radiance = radiance + beta * s.sky; break; }
+        const ora_material &m = s.materials[rec.material];
+        radiance = radiance + beta * a3(m.emission);
+        if (depth++ == maxDepth) break;
+        V3 wo = -d;
+        float u = rng.f();
+        V2 u2; u2.x = rng.f(); u2.y = rng.f();
+        BSample bs;
+        if (cnt) cnt->n_shade++;
+        if (!sampleBxdf(s, m, rec.normal, rec.uv, wo, u, u2, bs)) break;
+        beta = beta * (bs.f * absdot(bs.wi, rec.normal) / bs.pdf);
+        o = rec.point + bs.wi * RAY_EPSILON;
+        d = bs.wi;
+    }
+    return radiance;
+}
+
+std::atomic<int> g_li{0};      // which Li the render entry points use: 0 integrateMIS, 1 integrate, 2 integrateBasic (camera.cpp:104-106)
+
 // ---------------------------------------------------------------------------------------------
 // Camera (camera.cpp:7-31, camera.hpp:107-139)
 // ---------------------------------------------------------------------------------------------
@@ -1100,7 +1195,9 @@ inline V3 tracePixelSample(const ora_scene &s, const Cam &k, int maxDepth, uint3
     Rng rng(row, col, sample + 1);                                            // camera.cpp:101
     V3 o, d; camRay(k, col, row, sample, rng, o, d);
     if (cnt) cnt->n_camera++;
-    V3 c = integrateMIS(s, o, d, maxDepth, rng, cnt);
+    const int li = g_li.load(std::memory_order_relaxed);
+    V3 c = li == 1 ? integrateNEE(s, o, d, maxDepth, rng, cnt) : li == 2 ? integrateBasic(s, o, d, maxDepth, rng, cnt)
+                   : integrateMIS(s, o, d, maxDepth, rng, cnt);
     if (c.x > 1.0f) c.x = 1.0f;                                               // camera.cpp:110-112
     if (c.y > 1.0f) c.y = 1.0f;
     if (c.z > 1.0f) c.z = 1.0f;
@@ -1124,6 +1221,7 @@ void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int
                 int reference_barriers, float *acc_rgb, uint8_t *img_rgb, ora_counters *counters);
 
 void ora_set_sincos_mode(int mode) { g_sincos_mode.store(mode); }
+void ora_set_integrator(int li) { g_li.store(li); }
 
 // diagnostic: renders the frame once more and returns how often every BVH node was visited (closest + any)
 void ora_node_histogram(const ora_scene *s, const ora_camera_desc *cam, int threads, uint64_t *out) {

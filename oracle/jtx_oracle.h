@@ -113,6 +113,10 @@ typedef struct ora_scene ora_scene;
 /* sincos_mode: 0 = deterministic polynomial sin/cos of DESIGN.md (bit-matched by the HIP kernels),
  *              1 = host libm sinf/cosf (what the reference's jtx::sin/cos presumably forward to). */
 void ora_set_sincos_mode(int mode);
+/* which Li the render / radiance entry points evaluate (camera.cpp:104-106 picks by (un)commenting):
+ * 0 integrateMIS (integrator.cpp:171-216), 1 integrate (:54-132), 2 integrateBasic (:12-52).  Material type 4 =
+ * ThinDielectricBxDF (dielectric.hpp:163-207). */
+void ora_set_integrator(int li);
 
 /* ---- RNG (util/rand.hpp) ---- */
 uint32_t ora_fnv1a_3(uint32_t x, uint32_t y, uint32_t n);

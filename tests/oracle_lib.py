@@ -41,6 +41,7 @@ def load():
     lib = C.CDLL(LIB)
     sig = {
         "ora_set_sincos_mode": (None, [C.c_int]),
+        "ora_set_integrator": (None, [C.c_int]),
         "ora_fnv1a_3": (C.c_uint32, [C.c_uint32] * 3),
         "ora_rng_stream": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u32, _f]),
         "ora_rng_sample_range": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]),
@@ -149,13 +150,17 @@ class OracleScene:
         self.lib.ora_bxdf_pdf_batch(self.h, material, n, _fp(normal), uvp, _fp(wo), _fp(wi), _fp(pdf))
         return pdf
 
-    def radiance_samples(self, cam, row, col, sample):
+    def radiance_samples(self, cam, row, col, sample, path_integrator=0):
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32); sample = np.ascontiguousarray(sample, np.int32)
         rgb = np.zeros((len(row), 3), np.float32)
-        self.lib.ora_radiance_samples(self.h, C.byref(cam), len(row), _ip(row), _ip(col), _ip(sample), _fp(rgb))
+        self.lib.ora_set_integrator(path_integrator)
+        try:
+            self.lib.ora_radiance_samples(self.h, C.byref(cam), len(row), _ip(row), _ip(col), _ip(sample), _fp(rgb))
+        finally:
+            self.lib.ora_set_integrator(0)
         return rgb
 
-    def render(self, cam, threads=0, sample_begin=0, sample_end=0, reference_barriers=False, count=True, acc=None):
+    def render(self, cam, threads=0, sample_begin=0, sample_end=0, reference_barriers=False, count=True, acc=None, path_integrator=0):
         H, W = cam.height, cam.width
         spp = cam.x_pixel_samples * cam.y_pixel_samples
         if sample_end <= 0:
@@ -164,8 +169,12 @@ class OracleScene:
             acc = np.zeros((H, W, 3), np.float32)
         img = np.zeros((H, W, 3), np.uint8)
         cnt = capi.Counters()
-        self.lib.ora_render(self.h, C.byref(cam), threads, sample_begin, sample_end, 1 if reference_barriers else 0,
-                            _fp(acc), img.ctypes.data_as(_u8), C.byref(cnt) if count else None)
+        self.lib.ora_set_integrator(path_integrator)
+        try:
+            self.lib.ora_render(self.h, C.byref(cam), threads, sample_begin, sample_end, 1 if reference_barriers else 0,
+                                _fp(acc), img.ctypes.data_as(_u8), C.byref(cnt) if count else None)
+        finally:
+            self.lib.ora_set_integrator(0)
         return acc, img, (cnt.as_dict() if count else None)
 
 

@@ -1010,3 +1010,76 @@ def test_multi_device_full_size_config2(gpu, cornell_pair):
     assert ms.render(cam)
     assert_same_f32(cam.acc_, ref.acc_, "8 shards, C2"); assert (cam.img_ == ref.img_).all()
     ms.destroy()
+
+
+# ---- integrate / integrateBasic, emission, ThinDielectricBxDF (k_render_alt) ----
+@pytest.fixture(scope="module")
+def emissive_pair(gpu):
+    data = gpu.scenes.emissive()
+    sc = gpu.Scene(data); sc.buildBVH()
+    yield data, sc, ol.OracleScene(data)
+    sc.destroy()
+
+
+@pytest.mark.parametrize("li", [0, 1, 2])
+def test_alternate_integrators_render_like_the_oracle(gpu, emissive_pair, li):
+    """integrateMIS with every BxDF incl. THIN_DIELECTRIC (li 0), integrate (li 1: NEE without MIS, emission and sky only
+    after a specular bounce) and integrateBasic (li 2: emission at every hit): film, RGB8 image and ray counters of a
+    whole frame, bit for bit; tile shards and resumed sample ranges add up."""
+    data, sc, osc = emissive_pair
+    cam = data.camera_desc(160, 96, 3, 2, 6)
+    acc, img, cnt = osc.render(cam, path_integrator=li)
+    g = gpu.StaticCamera(160, 96, data.camera, 3, 2, 6)
+    g.render(sc, count_rays=True, path_integrator=li)
+    assert_same_f32(g.acc_, acc, f"li {li} acc"); assert (g.img_ == img).all(); assert g.counters == cnt
+    g.render(sc, count_rays=False, path_integrator=li)
+    assert_same_f32(g.acc_, acc, f"li {li} uncounted acc"); assert (g.img_ == img).all()
+    assert np.isfinite(acc).all() and acc.max() > 0
+    if li == 2:
+        assert cnt["n_any"] == 0                                     # integrateBasic never samples a light
+    total = np.zeros_like(acc)
+    for r in range(3):
+        c = gpu.StaticCamera(160, 96, data.camera, 3, 2, 6); c.render(sc, tile_rank=r, tile_world=3, path_integrator=li)
+        total += c.acc_
+    assert_same_f32(total, acc, "sum of shards")
+    part = gpu.StaticCamera(160, 96, data.camera, 3, 2, 6)
+    part.render(sc, sample_begin=0, sample_end=2, path_integrator=li); part.render(sc, sample_begin=2, sample_end=6, path_integrator=li)
+    assert_same_f32(part.acc_, acc, "resumed")
+
+
+@pytest.mark.parametrize("li", [0, 1, 2])
+def test_alternate_integrators_radiance_samples(gpu, emissive_pair, li):
+    data, sc, osc = emissive_pair
+    cam = data.camera_desc(320, 200, 4, 4, 8)
+    rs = np.random.RandomState(40 + li)
+    n = 6000
+    rows, cols, ss = rs.randint(0, 200, n), rs.randint(0, 320, n), rs.randint(0, 16, n)
+    want = osc.radiance_samples(cam, rows, cols, ss, path_integrator=li)
+    got = gpu.api.radiance_samples(sc, cam, rows, cols, ss, path_integrator=li)
+    assert_same_f32(got, want, f"li {li} per-sample radiance")
+    assert (want > 0).any()
+
+
+def test_the_three_integrators_differ_where_they_should(gpu, emissive_pair):
+    """integrateMIS ignores emission (integrator.cpp:189-190); integrateBasic sees the emitters but no point light."""
+    data, sc, osc = emissive_pair
+    f = {}
+    for li in (0, 1, 2):
+        g = gpu.StaticCamera(96, 64, data.camera, 2, 2, 4); g.render(sc, path_integrator=li); f[li] = g.acc_.copy()
+    assert not np.array_equal(f[0], f[1]) and not np.array_equal(f[1], f[2]) and not np.array_equal(f[0], f[2])
+
+
+def test_thin_dielectric_bxdf_batch(gpu, emissive_pair):
+    """ThinDielectricBxDF through the BxDF batch entry points: sample bit-equal to the oracle, eval = 0, pdf = 0."""
+    data, sc, osc = emissive_pair
+    thin = [i for i, m in enumerate(data.materials) if m["type"] == gpu.scenes.THIN_DIELECTRIC]
+    assert len(thin) == 2
+    nrm, wo, wi, uc, u2, uv = _bxdf_inputs(20000, 77)
+    for mi in thin:
+        a = osc.sampleBxdf(mi, nrm, wo, uc, u2, uv)
+        b = sc.sampleBxdf(mi, nrm, wo, uc, u2, uv)
+        assert (a["ok"] == b["ok"]).all() and a["ok"].mean() > 0.5
+        for k in ("f", "wi", "pdf"):
+            assert_same_f32(b[k], a[k], f"thin dielectric sample {k}")
+        assert not sc.evalBxdf(mi, nrm, wo, wi, uv).any() and not sc.pdfBxdf(mi, nrm, wo, wi, uv).any()
+        assert not osc.evalBxdf(mi, nrm, wo, wi, uv).any() and not osc.pdfBxdf(mi, nrm, wo, wi, uv).any()

@@ -425,3 +425,58 @@ def test_kernel_known_answers_oracle():
     assert 1000 < hits.sum() < 3000
     # the ray set really contains grazers: rays through triangle vertices / edge midpoints that still hit
     assert GOLD["kernels"]["cornell_closest"]["hits"] > 0.9 * GOLD["kernels"]["cornell_closest"]["rays"]
+
+
+# ---- the oracle's restatements of integrate / integrateBasic / ThinDielectricBxDF (no GPU) ----
+def test_thin_dielectric_sample_properties():
+    """ThinDielectricBxDF::sample (dielectric.hpp:173-199) on the oracle: two specular lobes, reflection (-x,-y,z) with
+    probability R' and straight transmission -wo with T' = 1 - R', R' = R + T^2 R / (1 - R^2); f |cos| / pdf == 1."""
+    from jtx_pathtracer_amd import scenes
+    s = scenes.quad_scene()
+    s.materials = [scenes.material(scenes.THIN_DIELECTRIC, ior=(1.5, 1.5, 1.5))]
+    for m in s.meshes:
+        m["material"] = 0
+    o = ol.OracleScene(s)
+    rs = np.random.RandomState(5)
+    n = 4000
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+    wo = rs.normal(size=(n, 3)).astype(np.float32); wo /= np.linalg.norm(wo, axis=1, keepdims=True); wo[:, 2] = np.abs(wo[:, 2]) + 0.05
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True).astype(np.float32)
+    uc = rs.uniform(0, 1, n).astype(np.float32); u2 = rs.uniform(0, 1, (n, 2)).astype(np.float32)
+    r = o.sampleBxdf(0, nrm, wo, uc, u2)
+    assert r["ok"].all()
+    refl = np.isclose(r["wi"][:, 2], wo[:, 2], atol=1e-5)
+    trans = np.isclose(r["wi"], -wo, atol=1e-5).all(axis=1)
+    assert (refl ^ trans).all() and refl.any() and trans.any()
+    w = r["f"][:, 0] * np.abs(r["wi"][:, 2]) / r["pdf"]
+    assert np.allclose(w, 1.0, atol=2e-6)                               # energy-preserving pane
+    c = wo[:, 2].astype(np.float64)
+    ct = np.sqrt(1 - (1 - c * c) / 2.25)
+    R = 0.5 * (((1.5 * c - ct) / (1.5 * c + ct)) ** 2 + ((c - 1.5 * ct) / (c + 1.5 * ct)) ** 2)
+    Rp = R + (1 - R) ** 2 * R / (1 - R * R)
+    assert np.allclose(np.where(refl, r["pdf"], 1 - r["pdf"]), Rp, atol=1e-5)
+    assert ((uc < Rp - 1e-5) <= refl).all() and ((uc > Rp + 1e-5) <= trans).all()
+
+
+def test_oracle_alternate_integrators_basic_properties():
+    """integrateBasic sees emitters and never traces a shadow ray; integrate needs a specular bounce (or the camera ray)
+    to collect emission; integrateMIS collects none (integrator.cpp:189-190)."""
+    from jtx_pathtracer_amd import scenes
+    s = scenes.emissive(sphere_res=(8, 4))
+    o = ol.OracleScene(s)
+    cam = s.camera_desc(64, 40, 2, 2, 4)
+    a0, _, c0 = o.render(cam, path_integrator=0)
+    a1, _, c1 = o.render(cam, path_integrator=1)
+    a2, _, c2 = o.render(cam, path_integrator=2)
+    assert c2["n_any"] == 0 and c0["n_any"] > 0 and 0 < c1["n_any"] <= c0["n_any"] + c1["n_shade"]
+    assert c0["n_camera"] == c1["n_camera"] == c2["n_camera"] == 64 * 40 * 4
+    # remove every emitter: integrateBasic loses all light but the sky; integrateMIS does not change at all
+    for m in s.materials:
+        m["emission"] = (0, 0, 0)
+    o2 = ol.OracleScene(s)
+    b0, _, _ = o2.render(cam, path_integrator=0)
+    b2, _, _ = o2.render(cam, path_integrator=2)
+    assert np.array_equal(a0.view(np.uint32), b0.view(np.uint32))
+    assert b2.sum() < 0.7 * a2.sum()                                   # what is left is the sky seen directly and by bounces
+    # the camera ray counts as a specular bounce: pixels that look straight at the emissive quad are lit under integrate
+    assert a1.max() > 0 and np.isfinite(a1).all() and np.isfinite(a2).all()
