@@ -152,6 +152,13 @@ int         jtx_mi_set_device(int32_t device);
 int jtx_mi_bvh_build(const jtx_mi_scene_desc *desc, jtx_mi_bvh_node *nodes_out, int32_t *num_nodes_out,
                      jtx_mi_tri_ref *refs_out, int32_t *max_depth_out);
 
+/* Host-only: JPEG (baseline + progressive Huffman, 8 bit) -> interleaved 8-bit samples with the arithmetic of the decoder
+ * the reference uses for textures (stbi_load_from_memory, image.cpp:97: its fixed-point IDCT, chroma filters and YCbCr
+ * conversion), so that texel values are the reference's.  components: 3 for a colour image, 1 for greyscale.
+ * out == NULL: only width / height / components are filled in.  No GPU needed. */
+int jtx_mi_decode_jpeg(const uint8_t *bytes, int64_t num_bytes, int32_t *width, int32_t *height, int32_t *components,
+                       uint8_t *out, int64_t capacity);
+
 /* Host-only: the 8-ary quantised node set the uncounted kernels walk for HBM-resident scenes, derived from the
  * flat nodes of jtx_mi_bvh_build (layout: DESIGN.md "Data layout", 16-byte granules = 4 uint32 each; 0 granules
  * when the tree is a single leaf or cannot be quantised).  granules_out may be NULL to query the size.  No GPU needed. */

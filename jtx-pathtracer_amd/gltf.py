@@ -19,8 +19,9 @@ glTF file, as far as the hot path can see it:
     material gets DIFFUSE (1, 0.3, 0.5) (loader.cpp:206-209);
   * textures (src/image.cpp:59-101 -> stbi_loadf): 8-bit samples become float pow(x / 255, 2.2) per
     colour channel, alpha stays x / 255 (ext/stb/stb_image.h ldr_to_hdr); the file's own channel count
-    is kept.  PNG (8/16-bit, grey/RGB/palette, +alpha, non-interlaced) is decoded here with zlib; JPEG
-    needs a codec this package does not have: `allow_missing_textures=True` loads the scene without
+    is kept.  PNG (8/16-bit, grey/RGB/palette, +alpha, non-interlaced) is decoded here with zlib; JPEG (baseline and
+    progressive) by the library's host decoder (csrc/jtx_jpeg.cpp), which reproduces stb_image's arithmetic byte for
+    byte (tests/test_jpeg_cpu.py).  Other formats (EXR ...): `allow_missing_textures=True` loads the scene without
     those maps (texture id -1), otherwise a ValueError says which image it was.
 
 Parity of this step cannot be pinned (no Assimp, no stb in the image): it is host-side data preparation,
@@ -119,6 +120,19 @@ def decode_png(data):
     return np.ascontiguousarray(px)
 
 
+def decode_jpeg(data):
+    """JPEG bytes -> uint8 (H, W, C), C = 3 or 1: what stbi_load_from_memory(.., req_comp = 0) returns (jtx_mi_decode_jpeg)."""
+    import ctypes as C
+    from . import _capi as capi
+    lib = capi.load()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    w, h, c = C.c_int32(), C.c_int32(), C.c_int32()
+    capi.check(lib.jtx_mi_decode_jpeg(buf, len(data), C.byref(w), C.byref(h), C.byref(c), None, 0))
+    out = np.zeros((h.value, w.value, c.value), np.uint8)
+    capi.check(lib.jtx_mi_decode_jpeg(buf, len(data), C.byref(w), C.byref(h), C.byref(c), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
+    return out
+
+
 def encode_png(img):
     """uint8 (H, W, C) -> PNG bytes (filter 0, C in 1..4)."""
     img = np.ascontiguousarray(img, np.uint8)
@@ -139,7 +153,11 @@ def ldr_to_float(px):
     c = px.shape[-1]
     out = np.empty(px.shape, np.float32)
     ncol = c if c in (1, 3) else c - 1
-    out[..., :ncol] = np.power(px[..., :ncol].astype(np.float32) / np.float32(255.0), 2.2).astype(np.float32)
+    # (float) (pow(data / 255.0f, stbi__l2h_gamma) * stbi__l2h_scale) with float gamma 2.2f, scale 1.0f (stb_image.h:1573,1869):
+    # the quotient is a float, pow runs in double on the promoted operands, the product is rounded to float once
+    lut = (np.power((np.arange(256, dtype=np.float32) / np.float32(255.0)).astype(np.float64), np.float64(np.float32(2.2)))
+           * np.float64(np.float32(1.0))).astype(np.float32)
+    out[..., :ncol] = lut[px[..., :ncol]]
     if ncol < c:
         out[..., ncol:] = px[..., ncol:].astype(np.float32) / np.float32(255.0)
     return out
@@ -268,10 +286,16 @@ def load_gltf(path, background=scenes.SKY_BLUE, allow_missing_textures=False):
                 raise ValueError(f"image {src}: {px.shape[-1]}-channel texture; getTexel (image.hpp:140-153) reads 3 channels")
             s.textures.append(ldr_to_float(px))
             tex_of_image[src] = len(s.textures) - 1
+        elif data[:2] == b"\xff\xd8":
+            px = decode_jpeg(data)
+            if px.shape[-1] < 3:
+                raise ValueError(f"image {src}: {px.shape[-1]}-channel texture; getTexel (image.hpp:140-153) reads 3 channels")
+            s.textures.append(ldr_to_float(px))
+            tex_of_image[src] = len(s.textures) - 1
         elif allow_missing_textures:
             tex_of_image[src] = -1
         else:
-            raise ValueError(f"image {src} ({mime or 'unknown type'}): only PNG can be decoded here "
+            raise ValueError(f"image {src} ({mime or 'unknown type'}): only PNG and JPEG can be decoded here "
                              "(pass allow_missing_textures=True to load the scene without it)")
         return tex_of_image[src]
 

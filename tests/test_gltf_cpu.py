@@ -155,12 +155,11 @@ def test_gen_normals_and_default_material(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HELMET), reason="reference assets are only present in the build container")
 def test_reference_helmet_glb_structure():
-    with pytest.raises(ValueError, match="only PNG"):
-        gltf.load_gltf(HELMET)                               # its five maps are JPEG
-    s = gltf.load_gltf(HELMET, allow_missing_textures=True)
+    s = gltf.load_gltf(HELMET)                               # its five maps are JPEG (one progressive): decoded since round 2
     assert len(s.meshes) == 1 and s.num_triangles == 46356 // 3 and len(s.meshes[0]["vertices"]) == 14556
     m = s.materials[s.meshes[0]["material"]]
-    assert m["type"] == scenes.METALLIC_ROUGHNESS and (m["alpha_x"], m["alpha_y"]) == (1.0, 1.0) and m["albedo_tex"] == -1
+    assert m["type"] == scenes.METALLIC_ROUGHNESS and (m["alpha_x"], m["alpha_y"]) == (1.0, 1.0)
+    assert m["albedo_tex"] == 0 and m["mr_tex"] == 1 and len(s.textures) == 2      # baseColor + metallicRoughness (loader.cpp:115-126)
     v, n = s.meshes[0]["vertices"], s.meshes[0]["normals"]
     assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-4)
     # the node rotates by 90 degrees about x: the helmet's long axis ends up along z... just check the bake happened
