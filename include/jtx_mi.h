@@ -135,6 +135,7 @@ typedef struct {
     uint64_t device_bytes;
     int32_t wide_depth;       /* levels of the 8-ary quantised BVH the uncounted kernels walk (0 = not built) */
     int32_t wide_bytes;       /* its size in bytes */
+    int32_t refitted;         /* != 0: boxes / triangles come from jtx_mi_scene_refit (topology of the last build), not from a build */
 } jtx_mi_scene_info;
 
 typedef struct jtx_mi_scene jtx_mi_scene;
@@ -169,6 +170,15 @@ int jtx_mi_wide_build(const jtx_mi_bvh_node *nodes, int32_t num_nodes, uint32_t 
  * shading records out for the kernels and copies them to the current device. */
 int  jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out);
 void jtx_mi_scene_destroy(jtx_mi_scene *scene);                      /* Scene::destroy */
+/* Transform edits (Display::renderScene's edit loop: recalculateTransform -> rebuildBVH_, display.cpp:545-588, 902-905).
+ * set_transform stores a mesh's new row-major Mesh::transform; refit recomputes, ON THE DEVICE and with the topology of the
+ * last build kept, every position-dependent record -- triangles, shading normals, all node boxes (binary, the 8 stackless
+ * orderings, the re-quantised 8-ary nodes), scene radius -- in a fraction of a host rebuild.  Boxes are bit for bit what a
+ * build computes for the same primitive sets; the TOPOLOGY is not re-chosen, so the frame is a correct render of the edited
+ * scene but is not claimed bit-identical to the reference's frame after Scene::rebuildBVH (scene_info.refitted says so;
+ * jtx_mi_scene_create on the edited description gives the reference-identical tree). */
+int  jtx_mi_scene_set_transform(jtx_mi_scene *scene, int32_t mesh, const float *m16);
+int  jtx_mi_scene_refit(jtx_mi_scene *scene);
 int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
 int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
 

@@ -76,7 +76,7 @@ class Counters(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("num_prims", C.c_int32), ("max_depth", C.c_int32),
                 ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("auto_integrator", C.c_int32),
-                ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32)]
+                ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32), ("refitted", C.c_int32)]
 
 
 CANCELLED = 2          # JTX_MI_CANCELLED
@@ -100,6 +100,8 @@ SYMBOLS = {
     "jtx_mi_scene_get_bvh": (C.c_int, [_scene, P(BvhNode), P(TriRef)]),
     "jtx_mi_render": (C.c_int, [_scene, P(CameraDesc), P(RenderOpts), _f, _u8, PROGRESS_CB, C.c_void_p]),
     "jtx_mi_decode_jpeg": (C.c_int, [_u8, C.c_int64, P(C.c_int32), P(C.c_int32), P(C.c_int32), _u8, C.c_int64]),
+    "jtx_mi_scene_set_transform": (C.c_int, [_scene, C.c_int32, _f]),
+    "jtx_mi_scene_refit": (C.c_int, [_scene]),
     "jtx_mi_cancel": (C.c_int, [_scene]),
     "jtx_mi_pin_host": (C.c_int, [C.c_void_p, C.c_uint64]),
     "jtx_mi_unpin_host": (C.c_int, [C.c_void_p]),

@@ -72,7 +72,16 @@ class Scene:
         return dict(num_nodes=i.num_nodes, num_prims=i.num_prims, max_depth=i.max_depth,
                     lds_resident=bool(i.lds_resident), scene_radius=float(i.scene_radius),
                     auto_integrator=int(i.auto_integrator), wide_depth=int(i.wide_depth), wide_bytes=int(i.wide_bytes),
-                    device_bytes=int(i.device_bytes))
+                    device_bytes=int(i.device_bytes), refitted=bool(i.refitted))
+
+    # -- transform edits (display.cpp:545-588): new Mesh::transform per mesh, then a device refit (topology kept)
+    def setTransform(self, mesh, transform):
+        m = np.ascontiguousarray(transform, np.float32).reshape(16)
+        check(self._lib.jtx_mi_scene_set_transform(self.handle, int(mesh), m.ctypes.data_as(C.POINTER(C.c_float))))
+        self.data.meshes[mesh]["transform"] = m.reshape(4, 4).copy()
+
+    def refit(self):
+        check(self._lib.jtx_mi_scene_refit(self.handle))
 
     def bvh(self):
         i = self.info()

@@ -10,8 +10,11 @@
 #include "jtx_host.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
+#include <future>
 #include <limits>
+#include <thread>
 
 namespace jtxh {
 
@@ -49,46 +52,61 @@ struct Prim {
 
 constexpr int kBuckets = 12;
 
-struct Builder {
-    std::vector<jtx_mi_bvh_node> &nodes;
-    std::vector<Prim> &ordered;
-    int orderedCount = 0;
-    int maxPrims;
+// A subtree is built into arrays of its OWN (node indices and primitive offsets relative to the subtree), so that the two
+// children of a big node can be built on different threads and stitched behind their parent: buildTree's recursion order IS
+// the flattened pre-order, the left subtree's nodes follow the parent and the right subtree's follow those.  The tree is
+// the sequential one node for node -- the threads only decide who computes which part.
+struct Subtree {
+    std::vector<jtx_mi_bvh_node> nodes;
+    std::vector<Prim> ordered;
     int maxDepth = 0;
+};
 
-    int emitLeaf(int slot, Prim *p, size_t n, const Bounds &bounds) {
-        jtx_mi_bvh_node &ln = nodes[slot];
-        ln.offset = orderedCount;
-        ln.num_prims = (uint16_t) n;
+struct Builder {
+    int maxPrims;
+    int threadsLeft;                                  // spawn budget (decremented on the spawning thread only: deterministic shape is irrelevant, results are)
+
+    static void emitLeaf(Subtree &t, int slot, Prim *p, size_t n) {
+        jtx_mi_bvh_node &ln = t.nodes[slot];
+        ln.offset = (int) t.ordered.size();
         if (n > 65535) throw std::runtime_error("BVH leaf with more than 65535 primitives (uint16 numPrimitives, bvh.hpp:13)");
-        for (size_t i = 0; i < n; ++i) ordered[orderedCount + i] = p[i];
-        orderedCount += (int) n;
-        (void) bounds;
-        return slot;
+        ln.num_prims = (uint16_t) n;
+        t.ordered.insert(t.ordered.end(), p, p + n);
     }
 
-    int bucketOf(const Bounds &cb, const Prim &q, int dim) const {
+    static int bucketOf(const Bounds &cb, const Prim &q, int dim) {
         float c[3] = {q.centroid(0), q.centroid(1), q.centroid(2)};
         int b = (int) (kBuckets * cb.offset(c, dim));
         if (b == kBuckets) b = kBuckets - 1;
         return b;
     }
 
-    int build(Prim *p, size_t n, int depth) {
-        const int slot = (int) nodes.size();
-        nodes.push_back(jtx_mi_bvh_node{});
-        if (depth > maxDepth) maxDepth = depth;
+    // appends `sub` (built with indices relative to itself) behind the nodes already in `t`
+    static void append(Subtree &t, Subtree &&sub) {
+        const int nodeBase = (int) t.nodes.size(), primBase = (int) t.ordered.size();
+        for (jtx_mi_bvh_node n : sub.nodes) {
+            n.offset += n.num_prims ? primBase : nodeBase;
+            t.nodes.push_back(n);
+        }
+        t.ordered.insert(t.ordered.end(), sub.ordered.begin(), sub.ordered.end());
+        if (sub.maxDepth > t.maxDepth) t.maxDepth = sub.maxDepth;
+    }
+
+    void build(Subtree &t, Prim *p, size_t n, int depth) {
+        const int slot = (int) t.nodes.size();
+        t.nodes.push_back(jtx_mi_bvh_node{});
+        if (depth > t.maxDepth) t.maxDepth = depth;
 
         Bounds bounds;
         for (size_t i = 0; i < n; ++i) bounds.grow(p[i].b);
-        for (int a = 0; a < 3; ++a) { nodes[slot].pmin[a] = bounds.lo[a]; nodes[slot].pmax[a] = bounds.hi[a]; }
+        for (int a = 0; a < 3; ++a) { t.nodes[slot].pmin[a] = bounds.lo[a]; t.nodes[slot].pmax[a] = bounds.hi[a]; }
 
-        if (bounds.area() == 0 || n == 1) return emitLeaf(slot, p, n, bounds);          // bvh.cpp:18-28
+        if (bounds.area() == 0 || n == 1) return emitLeaf(t, slot, p, n);                // bvh.cpp:18-28
 
         Bounds cb;
         for (size_t i = 0; i < n; ++i) { float c[3] = {p[i].centroid(0), p[i].centroid(1), p[i].centroid(2)}; cb.grow(c); }
         const int dim = cb.longestAxis();
-        if (cb.lo[dim] == cb.hi[dim]) return emitLeaf(slot, p, n, bounds);              // bvh.cpp:36-46
+        if (cb.lo[dim] == cb.hi[dim]) return emitLeaf(t, slot, p, n);                    // bvh.cpp:36-46
 
         size_t mid = n / 2;
         if (n == 2) {                                                                   // bvh.cpp:50-57
@@ -110,15 +128,27 @@ struct Builder {
                 Prim *m = std::partition(p, p + n, [&](const Prim &q) { return bucketOf(cb, q, dim) <= best; });
                 mid = (size_t) (m - p);
             } else {
-                return emitLeaf(slot, p, n, bounds);
+                return emitLeaf(t, slot, p, n);
             }
         }
-        nodes[slot].axis = (uint8_t) dim;
-        nodes[slot].num_prims = 0;
-        build(p, mid, depth + 1);                                   // first child lands at slot + 1
-        const int second = build(p + mid, n - mid, depth + 1);
-        nodes[slot].offset = second;                                // secondChildOffset (bvh.cpp:146)
-        return slot;
+        t.nodes[slot].axis = (uint8_t) dim;
+        t.nodes[slot].num_prims = 0;
+        if (n >= 16384 && threadsLeft > 0) {
+            // big node: the right subtree on another thread, into arrays of its own, stitched behind the left one
+            --threadsLeft;
+            Builder other{maxPrims, threadsLeft / 2};
+            threadsLeft -= other.threadsLeft;
+            auto fut = std::async(std::launch::async, [&other, p, mid, n, depth] {
+                Subtree r; other.build(r, p + mid, n - mid, depth + 1); return r; });
+            build(t, p, mid, depth + 1);                             // first child lands at slot + 1
+            Subtree right = fut.get();
+            t.nodes[slot].offset = (int) t.nodes.size();            // secondChildOffset (bvh.cpp:146)
+            append(t, std::move(right));
+        } else {
+            build(t, p, mid, depth + 1);
+            t.nodes[slot].offset = (int) t.nodes.size();
+            build(t, p + mid, n - mid, depth + 1);
+        }
     }
 };
 
@@ -137,7 +167,7 @@ void meshVertices(const jtx_mi_mesh &m, int tri, float v0[3], float v1[3], float
 
 void buildBVH(const jtx_mi_scene_desc &d, BvhResult &out) {
     const size_t n = (size_t) d.num_tri_refs;
-    std::vector<Prim> work(n), ordered(n);
+    std::vector<Prim> work(n);
     for (size_t i = 0; i < n; ++i) {
         const jtx_mi_tri_ref &r = d.tri_refs[i];
         if (r.mesh_index < 0 || r.mesh_index >= d.num_meshes) throw std::runtime_error("tri_ref.mesh_index out of range");
@@ -152,14 +182,16 @@ void buildBVH(const jtx_mi_scene_desc &d, BvhResult &out) {
         work[i].index = r.index; work[i].mesh = r.mesh_index;
         work[i].b = Bounds(); work[i].b.grow(v0); work[i].b.grow(v1); work[i].b.grow(v2);   // tBounds mesh.hpp:79-84
     }
-    out.nodes.clear();
-    out.nodes.reserve(2 * n + 1);
-    Builder b{out.nodes, ordered};
-    b.maxPrims = d.max_prims_in_node > 0 ? d.max_prims_in_node : 1;
-    if (n) b.build(work.data(), n, 0);
-    out.max_depth = b.maxDepth;
+    Subtree tree;
+    tree.nodes.reserve(2 * n + 1); tree.ordered.reserve(n);
+    int hw = (int) std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    Builder b{d.max_prims_in_node > 0 ? d.max_prims_in_node : 1, (getenv("JTX_BVH_THREADS") ? atoi(getenv("JTX_BVH_THREADS")) : (hw > 32 ? 32 : hw)) - 1};
+    if (n) b.build(tree, work.data(), n, 0);
+    out.nodes = std::move(tree.nodes);
+    out.max_depth = tree.maxDepth;
     out.refs.resize(n);
-    for (size_t i = 0; i < n; ++i) out.refs[i] = jtx_mi_tri_ref{ordered[i].index, ordered[i].mesh};
+    for (size_t i = 0; i < n; ++i) out.refs[i] = jtx_mi_tri_ref{tree.ordered[i].index, tree.ordered[i].mesh};
     out.scene_radius = 0;
     if (!out.nodes.empty()) {                                        // getSceneRadius scene.hpp:81-84
         const jtx_mi_bvh_node &r = out.nodes[0];

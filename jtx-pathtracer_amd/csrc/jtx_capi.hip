@@ -5,6 +5,7 @@
 // camera.cpp:7-31), launch, and move the film.  There is deliberately no CPU rendering path.
 #include "jtx_host.hpp"
 #include "jtx_launch.hpp"
+#include "jtx_wide_quant.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -13,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 using namespace jtx;
 
@@ -73,6 +75,14 @@ struct jtx_mi_scene {
     DevBuf<DTexture> textures;
     DevBuf<float> texels;
     DevBuf<unsigned long long> counters;
+    // device refit (jtx_refit.hip): what a transform edit needs to recompute every position-dependent record in place
+    DevBuf<float4> prim_src, pbox, nbox;
+    DevBuf<float> mesh_xf;
+    DevBuf<int> leaf_nodes, level_nodes, rec_node, wide_map, wide_fail;
+    std::vector<float> mesh_xf_host;
+    std::vector<int> level_begin;    // per interior depth: offsets into level_nodes
+    int num_leaves = 0, num_wide = 0, refitted = 0;
+    bool xf_dirty = false;
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (64, used round-robin)
     unsigned work_slot = 0;
@@ -141,7 +151,6 @@ void validate(const jtx_mi_scene_desc &d) {
 }
 
 // ---- wide-node builder (layout + proof sketch: traverseWide in jtx_scene_dev.hpp) ----
-constexpr int kWideMinExp = -60, kWideMaxExp = 40;   // cell = 2^e; with |1/d| in [2^-40, 2^40] (WIDE_RANGE) cell / d is exact
 constexpr int kMaxWideDepth = 24;          // stack = depth x 8 B x 256 lanes of LDS per workgroup: 11 levels (22 KB) still run 7 workgroups / CU,
                                            // 24 levels (48 KB) 3; deeper trees (degenerate input) keep the binary records
 
@@ -149,17 +158,10 @@ struct WideBuilder {
     const std::vector<jtx_mi_bvh_node> &nodes;
     std::vector<uint4> &out;
     std::vector<int> leaves;           // leaf count of every binary subtree
+    std::vector<int32_t> *refit = nullptr;   // optional: 16 ints per wide node {granule, binary node, #interior, #leaves, leaf-record granule, -, -, -, children[8]}
     int depth = 0;
     bool ok = true;
 
-    // sign of (p + q * cell) - x in exact arithmetic (q * cell is exact in double; two-sum for the addition)
-    static int gridCmp(float p, int q, float cell, float x) {
-        const double a = (double) p, b = (double) q * (double) cell;
-        const double t = a + b, bb = t - a, err = (a - (t - bb)) + (b - bb);
-        if (t != (double) x) return t < (double) x ? -1 : 1;
-        return err < 0 ? -1 : (err > 0 ? 1 : 0);
-    }
-    static bool finite3(const float v[3]) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
     bool leaf(int i) const { return nodes[i].num_prims != 0; }
 
     void writeLeaf(size_t at, int i) {
@@ -220,36 +222,16 @@ struct WideBuilder {
         int child[8], ni = 0, nl = 0;
         for (int k = 0; k < n; ++k) if (!leaf(t[order[k]].node)) { slotOf[order[k]] = ni; child[ni++] = t[order[k]].node; }
         for (int k = 0; k < n; ++k) if (leaf(t[order[k]].node)) { slotOf[order[k]] = ni + nl; child[ni + nl] = t[order[k]].node; ++nl; }
-        if (!finite3(nb.pmin) || !finite3(nb.pmax)) { ok = false; return; }
-        // grid: origin = the node's min corner, cell = 2^e per axis with origin + 255 * 2^e >= max corner (exactly)
+        // grid: origin = the node's min corner, cell = 2^e per axis with origin + 255 * 2^e >= max corner (exactly);
+        // children rounded outward on it (jtx_wide_quant.hpp: the same code refits the node on the device)
         uint32_t ebyte[3]; float cell[3];
-        for (int k = 0; k < 3; ++k) {
-            const double ext = (double) nb.pmax[k] - (double) nb.pmin[k];
-            int e = ext > 0 ? std::ilogb(ext / 255.0) : kWideMinExp;
-            if (e < kWideMinExp) e = kWideMinExp;              // cell / d must stay a normal float (exact scaling)
-            while (e <= kWideMaxExp && gridCmp(nb.pmin[k], 255, std::ldexp(1.0f, e), nb.pmax[k]) < 0) ++e;
-            if (e > kWideMaxExp || std::fabs(nb.pmin[k]) > 1099511627776.0f || std::fabs(nb.pmax[k]) > 1099511627776.0f) { ok = false; return; }
-            ebyte[k] = (uint32_t) (e + 127); cell[k] = std::ldexp(1.0f, e);
-        }
+        if (!jtxq::nodeGrid(nb.pmin, nb.pmax, ebyte, cell)) { ok = false; return; }
         uint8_t qlo[3][8] = {}, qhi[3][8] = {};
         for (int s = 0; s < ni + nl; ++s) {
             const jtx_mi_bvh_node &c = nodes[child[s]];
-            for (int k = 0; k < 3; ++k) {
-                if (!(c.pmin[k] >= nb.pmin[k] && c.pmax[k] <= nb.pmax[k] && c.pmin[k] <= c.pmax[k])) { ok = false; return; }   // nesting is the premise
-                const float p = nb.pmin[k], sc = cell[k];
-                int q = (int) std::floor(((double) c.pmin[k] - (double) p) / (double) sc);
-                q = q < 0 ? 0 : (q > 255 ? 255 : q);
-                while (q > 0 && gridCmp(p, q, sc, c.pmin[k]) > 0) --q;
-                while (q < 255 && gridCmp(p, q + 1, sc, c.pmin[k]) <= 0) ++q;
-                if (gridCmp(p, q, sc, c.pmin[k]) > 0) { ok = false; return; }
-                qlo[k][s] = (uint8_t) q;
-                q = (int) std::ceil(((double) c.pmax[k] - (double) p) / (double) sc);
-                q = q < 0 ? 0 : (q > 255 ? 255 : q);
-                while (q < 255 && gridCmp(p, q, sc, c.pmax[k]) < 0) ++q;
-                while (q > 0 && gridCmp(p, q - 1, sc, c.pmax[k]) >= 0) --q;
-                if (gridCmp(p, q, sc, c.pmax[k]) < 0) { ok = false; return; }
-                qhi[k][s] = (uint8_t) q;
-            }
+            uint8_t lo3[3], hi3[3];
+            if (!jtxq::quantiseChild(nb.pmin, nb.pmax, cell, c.pmin, c.pmax, lo3, hi3)) { ok = false; return; }
+            for (int k = 0; k < 3; ++k) { qlo[k][s] = lo3[k]; qhi[k][s] = hi3[k]; }
         }
         // visiting order per octant: the reference's near-first rule (scene.cpp:40-46) applied inside the treelet
         uint32_t perm[8];
@@ -269,7 +251,7 @@ struct WideBuilder {
         if (base + 6 * (size_t) ni + 2 * (size_t) nl >= (1ull << 28)) { ok = false; return; }
         out.resize(base + 6 * (size_t) ni + 2 * (size_t) nl);
         auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-        auto pack = [](const uint8_t *q) { return (uint32_t) q[0] | (uint32_t) q[1] << 8 | (uint32_t) q[2] << 16 | (uint32_t) q[3] << 24; };
+        auto pack = [](const uint8_t *q) { return jtxq::pack4(q); };
         // 24-bit orders of the 8 octants, packed back to back into 6 words
         uint32_t pw[6] = {0, 0, 0, 0, 0, 0};
         for (int o = 0; o < 8; ++o) {
@@ -284,15 +266,22 @@ struct WideBuilder {
         out[at + 3] = make_uint4(pack(qhi[1]), pack(qhi[1] + 4), pack(qhi[2]), pack(qhi[2] + 4));
         out[at + 4] = make_uint4((uint32_t) base, pw[0], pw[1], pw[2]);
         out[at + 5] = make_uint4(pw[3], pw[4], pw[5], 0u);
+        if (refit) {
+            int32_t rec[16] = {(int32_t) at, b, ni, nl, (int32_t) (base + 6 * (size_t) ni), 0, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1};
+            for (int s2 = 0; s2 < ni + nl; ++s2) rec[8 + s2] = child[s2];
+            refit->insert(refit->end(), rec, rec + 16);
+        }
         for (int s = ni; s < ni + nl; ++s) writeLeaf(base + 6 * (size_t) ni + 2 * (size_t) (s - ni), child[s]);
         for (int s = 0; s < ni; ++s) fill(child[s], base + 6 * (size_t) s, level + 1);
     }
 };
 
-bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &out, int &depth) {
+bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &out, int &depth, std::vector<int32_t> *refitMap = nullptr) {
     out.clear(); depth = 0;
+    if (refitMap) refitMap->clear();
     if (nodes.size() < 2 || nodes[0].num_prims != 0) return false;      // a single leaf: nothing to collapse
     WideBuilder wb{nodes, out};
+    wb.refit = refitMap;
     wb.leaves.assign(nodes.size(), 1);
     for (size_t i = nodes.size(); i-- > 0;)
         if (nodes[i].num_prims == 0) {
@@ -336,62 +325,118 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         shade[4 * i + 3] = make_float4(uv[3], uv[4], uv[5], fmat);
     }
     s.tris.upload(tris); s.shade.upload(shade);
+    // ---- refit sources: object-space vertices / normals per BVH-ordered primitive, the mesh transforms, node lists ----
+    {
+        std::vector<float4> src(5 * np);
+        for (size_t i = 0; i < np; ++i) {
+            const jtx_mi_mesh &m = d.meshes[b.refs[i].mesh_index];
+            const int32_t *ix = m.indices + 3 * (size_t) b.refs[i].index;
+            const float *p0 = m.vertices + 3 * (size_t) ix[0], *p1 = m.vertices + 3 * (size_t) ix[1], *p2 = m.vertices + 3 * (size_t) ix[2];
+            const float *q0 = m.normals + 3 * (size_t) ix[0], *q1 = m.normals + 3 * (size_t) ix[1], *q2 = m.normals + 3 * (size_t) ix[2];
+            float fm; const int mi = b.refs[i].mesh_index; std::memcpy(&fm, &mi, 4);
+            src[5 * i + 0] = make_float4(p0[0], p0[1], p0[2], p1[0]);
+            src[5 * i + 1] = make_float4(p1[1], p1[2], p2[0], p2[1]);
+            src[5 * i + 2] = make_float4(p2[2], q0[0], q0[1], q0[2]);
+            src[5 * i + 3] = make_float4(q1[0], q1[1], q1[2], q2[0]);
+            src[5 * i + 4] = make_float4(q2[1], q2[2], fm, 0.f);
+        }
+        s.prim_src.upload(src);
+        s.pbox.alloc(2 * np);
+        s.mesh_xf_host.assign((size_t) 16 * d.num_meshes, 0.f);
+        for (int i = 0; i < d.num_meshes; ++i) std::memcpy(&s.mesh_xf_host[16 * (size_t) i], d.meshes[i].transform, 16 * sizeof(float));
+        s.mesh_xf.upload(s.mesh_xf_host);
+        std::vector<float4> nb(2 * nn);
+        std::vector<int> leaves, depth(nn, 0);
+        for (size_t i = 0; i < nn; ++i) {
+            const jtx_mi_bvh_node &n = b.nodes[i];
+            const int z = n.offset, w = n.num_prims;
+            float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
+            nb[2 * i] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
+            nb[2 * i + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+            if (n.num_prims) leaves.push_back((int) i);
+            else { depth[i + 1] = depth[i] + 1; depth[n.offset] = depth[i] + 1; }
+        }
+        int maxd = 0;
+        for (size_t i = 0; i < nn; ++i) if (!b.nodes[i].num_prims && depth[i] > maxd) maxd = depth[i];
+        s.level_begin.assign(nn ? maxd + 2 : 1, 0);
+        for (size_t i = 0; i < nn; ++i) if (!b.nodes[i].num_prims) s.level_begin[depth[i] + 1]++;
+        for (size_t l = 1; l < s.level_begin.size(); ++l) s.level_begin[l] += s.level_begin[l - 1];
+        std::vector<int> lv(s.level_begin.empty() ? 0 : s.level_begin.back()), cursor(s.level_begin.begin(), s.level_begin.end());
+        for (size_t i = 0; i < nn; ++i) if (!b.nodes[i].num_prims) lv[cursor[depth[i]]++] = (int) i;
+        s.nbox.upload(nb); s.leaf_nodes.upload(leaves); s.level_nodes.upload(lv);
+        s.num_leaves = (int) leaves.size();
+    }
 
     // ---- threaded node records: one near-first depth-first ordering per direction-sign octant ----
-    // (layout and rationale: traverseThreaded in jtx_scene_dev.hpp)
+    // (layout and rationale: traverseThreaded in jtx_scene_dev.hpp).  The 8 orderings are independent of each other and of
+    // the wide-node build: one host thread each.
+    std::vector<float4> tn(2 * 8 * nn);
+    std::vector<int> recNode(8 * nn);
+    std::vector<int32_t> wideMap;
+    std::vector<uint4> wide; int wideDepth = 0; bool wideOk = false;
     {
-        std::vector<float4> tn(2 * 8 * nn);
-        if (nn) {
-            std::vector<int> size(nn, 1);                               // subtree sizes (children follow their parent in b.nodes)
-            for (size_t i = nn; i-- > 0;)
-                if (b.nodes[i].num_prims == 0) size[i] = 1 + size[i + 1] + size[b.nodes[i].offset];
+        std::vector<int> size(nn, 1);                               // subtree sizes (children follow their parent in b.nodes)
+        for (size_t i = nn; i-- > 0;)
+            if (b.nodes[i].num_prims == 0) size[i] = 1 + size[i + 1] + size[b.nodes[i].offset];
+        auto ordering = [&](int k) {
+            // near-first DFS: dirIsNeg[axis] ? (second, first) : (first, second)   (scene.cpp:40-46)
             std::vector<int> order(nn);
-            for (int k = 0; k < 8; ++k) {
-                // near-first DFS: dirIsNeg[axis] ? (second, first) : (first, second)   (scene.cpp:40-46)
-                std::vector<int> st{0}; size_t pos = 0;
-                while (!st.empty()) {
-                    const int g = st.back(); st.pop_back();
-                    order[pos++] = g;
-                    const jtx_mi_bvh_node &n = b.nodes[g];
-                    if (n.num_prims == 0) {
-                        const int first = g + 1, second = n.offset;
-                        const bool neg = (k >> n.axis) & 1;
-                        st.push_back(neg ? first : second);                // far child: visited after the near subtree
-                        st.push_back(neg ? second : first);
-                    }
-                }
-                for (size_t i = 0; i < nn; ++i) {
-                    const jtx_mi_bvh_node &n = b.nodes[order[i]];
-                    int z, w;
-                    if (n.num_prims == 0) {
-                        const size_t behind = i + (size_t) size[order[i]];
-                        z = behind < nn ? (int) ((size_t) k * nn + behind) : -1;
-                        w = 0;
-                    } else {
-                        z = n.offset;
-                        w = (int) n.num_prims | (i + 1 == nn ? (int) 0x80000000u : 0);
-                    }
-                    float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
-                    const size_t r = (size_t) k * nn + i;
-                    tn[2 * r + 0] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
-                    tn[2 * r + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+            std::vector<int> st{0}; size_t pos = 0;
+            while (!st.empty()) {
+                const int g = st.back(); st.pop_back();
+                order[pos++] = g;
+                const jtx_mi_bvh_node &n = b.nodes[g];
+                if (n.num_prims == 0) {
+                    const int first = g + 1, second = n.offset;
+                    const bool neg = (k >> n.axis) & 1;
+                    st.push_back(neg ? first : second);                // far child: visited after the near subtree
+                    st.push_back(neg ? second : first);
                 }
             }
+            for (size_t i = 0; i < nn; ++i) {
+                const jtx_mi_bvh_node &n = b.nodes[order[i]];
+                int z, w;
+                if (n.num_prims == 0) {
+                    const size_t behind = i + (size_t) size[order[i]];
+                    z = behind < nn ? (int) ((size_t) k * nn + behind) : -1;
+                    w = 0;
+                } else {
+                    z = n.offset;
+                    w = (int) n.num_prims | (i + 1 == nn ? (int) 0x80000000u : 0);
+                }
+                float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
+                const size_t r = (size_t) k * nn + i;
+                recNode[r] = order[i];
+                tn[2 * r + 0] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
+                tn[2 * r + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+            }
+        };
+        const char *off = getenv("JTX_NO_WIDE");
+        const bool wantWide = !(off && atoi(off));
+        std::vector<std::thread> pool;
+        std::exception_ptr err = nullptr; std::mutex errMu;
+        auto guarded = [&](auto fn) { return [&, fn] { try { fn(); } catch (...) { std::lock_guard<std::mutex> g(errMu); err = std::current_exception(); } }; };
+        if (nn) {
+            if (wantWide) pool.emplace_back(guarded([&] { wideOk = buildWide(b.nodes, wide, wideDepth, &wideMap) && wideDepth <= kMaxWideDepth; }));
+            for (int k = 1; k < 8; ++k) pool.emplace_back(guarded([&, k] { ordering(k); }));
+            ordering(0);
         }
-        s.tnodes.upload(tn);
-        s.dev.tnodes = s.tnodes.p;
+        for (auto &t : pool) t.join();
+        if (err) std::rethrow_exception(err);
     }
+    s.tnodes.upload(tn);
+    s.dev.tnodes = s.tnodes.p;
+    s.rec_node.upload(recNode);
 
     // ---- wide (8-ary, quantised) nodes for the uncounted kernels of HBM-resident scenes (traverseWide) ----
     s.wide.release(); s.dev.wide = nullptr; s.dev.wide_depth = 0;
-    {
-        std::vector<uint4> wide; int depth = 0;
-        const char *off = getenv("JTX_NO_WIDE");
-        if (!(off && atoi(off)) && buildWide(b.nodes, wide, depth) && depth <= kMaxWideDepth) {
-            s.wide.upload(wide);
-            s.dev.wide = s.wide.p; s.dev.wide_depth = depth;
-        }
+    s.num_wide = 0;
+    if (wideOk) {
+        s.wide.upload(wide);
+        s.dev.wide = s.wide.p; s.dev.wide_depth = wideDepth;
+        s.wide_map.upload(wideMap); s.num_wide = (int) (wideMap.size() / 16);
     }
+    if (!s.wide_fail.p) s.wide_fail.alloc(1);
 
     std::vector<DMaterial> mats(d.num_materials);
     std::vector<char> usedAsAlbedo(d.num_textures, 0);
@@ -788,12 +833,68 @@ void jtx_mi_scene_destroy(jtx_mi_scene *scene) {
     if (sw) (void) hipSetDevice(prev);
 }
 
+// Mesh::transform after Display's edit (recalculateTransform, display.cpp:547,568,586); takes effect at the next jtx_mi_scene_refit
+int jtx_mi_scene_set_transform(jtx_mi_scene *s, int32_t mesh, const float *m16) {
+    if (!s || !m16) return fail("null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (mesh < 0 || (size_t) mesh * 16 >= s->mesh_xf_host.size()) return fail("mesh index out of range");
+    std::memcpy(&s->mesh_xf_host[16 * (size_t) mesh], m16, 16 * sizeof(float));
+    s->xf_dirty = true;
+    return 0;
+}
+
+// Scene::rebuildBVH's place in the edit loop (display.cpp:902-905), on the device and with the topology kept (jtx_refit.hip)
+int jtx_mi_scene_refit(jtx_mi_scene *s) {
+    try {
+        if (!s) throw std::runtime_error("null scene");
+        DeviceGuard dg(s->device);
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (s->dev.num_nodes == 0) return 0;
+        HIPCHK(hipMemcpyAsync(s->mesh_xf.p, s->mesh_xf_host.data(), s->mesh_xf_host.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemsetAsync(s->wide_fail.p, 0, sizeof(int), s->stream));
+        RefitArgs a{};
+        a.prim_src = s->prim_src.p; a.mesh_xf = s->mesh_xf.p; a.tris = s->tris.p; a.shade = s->shade.p; a.pbox = s->pbox.p;
+        a.nbox = s->nbox.p; a.leaf_nodes = s->leaf_nodes.p; a.level_nodes = s->level_nodes.p;
+        a.tnodes = s->tnodes.p; a.rec_node = s->rec_node.p;
+        a.wide = s->wide.p; a.wide_map = s->wide_map.p; a.wide_fail = s->wide_fail.p;
+        a.num_prims = s->dev.num_prims; a.num_nodes = s->dev.num_nodes; a.num_leaves = s->num_leaves; a.num_wide = s->wide.p ? s->num_wide : 0;
+        HIPCHK(jtx_launch_refit(a, s->level_begin.data(), (int) s->level_begin.size() - 1, s->stream));
+        // the host's copy of the nodes, the scene radius (scene.hpp:81-84) and with it the DISTANT lights (scene.cpp:128-134)
+        std::vector<float4> nb(2 * (size_t) s->dev.num_nodes);
+        HIPCHK(hipMemcpyAsync(nb.data(), s->nbox.p, nb.size() * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        int wfail = 0;
+        HIPCHK(hipMemcpyAsync(&wfail, s->wide_fail.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        for (size_t i = 0; i < s->bvh.nodes.size(); ++i) {
+            jtx_mi_bvh_node &n = s->bvh.nodes[i];
+            n.pmin[0] = nb[2 * i].x; n.pmax[0] = nb[2 * i].y; n.pmin[1] = nb[2 * i].z; n.pmax[1] = nb[2 * i].w;
+            n.pmin[2] = nb[2 * i + 1].x; n.pmax[2] = nb[2 * i + 1].y;
+        }
+        {
+            const jtx_mi_bvh_node &r = s->bvh.nodes[0];
+            const float dx = r.pmax[0] - r.pmin[0], dy = r.pmax[1] - r.pmin[1], dz = r.pmax[2] - r.pmin[2];
+            s->bvh.scene_radius = std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
+            if (s->lights.n) {
+                std::vector<DLight> ls(s->lights.n);
+                HIPCHK(hipMemcpy(ls.data(), s->lights.p, ls.size() * sizeof(DLight), hipMemcpyDeviceToHost));
+                bool any = false;
+                for (auto &l : ls) if (l.type == 1) { l.scene_radius = s->bvh.scene_radius; any = true; }
+                if (any) HIPCHK(hipMemcpy(s->lights.p, ls.data(), ls.size() * sizeof(DLight), hipMemcpyHostToDevice));
+            }
+        }
+        if (wfail) { s->dev.wide = nullptr; s->dev.wide_depth = 0; }          // a node lost its grid (coordinates out of range): binary records only
+        s->refitted = 1; s->xf_dirty = false;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
 int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     if (!s || !out) return fail("null argument");
     out->num_nodes = s->dev.num_nodes; out->num_prims = s->dev.num_prims; out->max_depth = s->bvh.max_depth;
     out->lds_resident = s->dev.lds_threaded; out->scene_radius = s->bvh.scene_radius; out->device_bytes = s->device_bytes;
     out->auto_integrator = autoIntegrator(*s);
     out->wide_depth = s->dev.wide_depth; out->wide_bytes = (int32_t) (s->wide.n * sizeof(uint4));
+    out->refitted = s->refitted;
     return 0;
 }
 int jtx_mi_scene_get_bvh(const jtx_mi_scene *s, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out) {

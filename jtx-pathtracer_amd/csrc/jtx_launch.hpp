@@ -61,8 +61,26 @@ struct WfParams {
     unsigned long long *counters;
 };
 
+// ---- device refit after a transform edit (jtx_refit.hip) ----
+struct RefitArgs {
+    // geometry
+    const float4 *prim_src;    // 5 float4 per BVH-ordered primitive: [v0.xyz v1.x][v1.yz v2.xy][v2.z n0.xyz][n1.xyz n2.x][n2.yz asfloat(mesh) -]
+    const float  *mesh_xf;     // 16 floats per mesh, row-major Mesh::transform
+    float4 *tris, *shade;      // the kernels' records (jtx_scene_dev.hpp)
+    float4 *pbox;              // 2 float4 per primitive [min.xyz -][max.xyz -]
+    // binary nodes
+    float4 *nbox;              // 2 float4 per node [min.x max.x min.y max.y][min.z max.z asfloat(offset) asfloat(numPrims)]
+    const int *leaf_nodes, *level_nodes;
+    // derived structures
+    float4 *tnodes; const int *rec_node;   // 8 * num_nodes threaded records and their binary nodes
+    uint4 *wide; const int *wide_map;      // 16 ints per wide node (WideBuilder::fill)
+    int *wide_fail;
+    int num_prims, num_nodes, num_leaves, num_wide;
+};
+
 } // namespace jtx
 
+hipError_t jtx_launch_refit(const jtx::RefitArgs &a, const int *level_begin, int num_levels, hipStream_t st);
 hipError_t jtx_wf_generate(const jtx::WfParams &p, int s0, int nstrata, hipStream_t st);
 hipError_t jtx_wf_trace(const jtx::WfParams &p, int any, int grid, bool count, hipStream_t st);
 hipError_t jtx_wf_shade(const jtx::WfParams &p, int grid, bool count, int typeCode, int matMask, hipStream_t st);

@@ -111,6 +111,16 @@ public:
     void destroyBVH() { if (multi_) { jtx_mi_multi_destroy(multi_); multi_ = nullptr; } if (handle_) { jtx_mi_scene_destroy(handle_); handle_ = nullptr; } }
     jtx_mi_multi *multiHandle() const { return multi_; }
     void rebuildBVH(int maxPrimsInNode = 1) { destroyBVH(); buildBVH(maxPrimsInNode); }
+    // The edit loop's cheap path (display.cpp:545-588 set rebuildBVH_ after every transform edit): push every Mesh::transform
+    // and refit the device scene in place, topology kept (jtx_mi_scene_refit; a correct render of the edited scene, flagged
+    // `refitted`; rebuildBVH() gives the reference's own tree again).  Single-device scenes only.
+    void refitBVH() {
+        if (!handle_) { buildBVH(); return; }
+        for (size_t i = 0; i < meshes.size(); ++i) check(jtx_mi_scene_set_transform(handle_, (int) i, &meshes[i].transform.m[0][0]));
+        check(jtx_mi_scene_refit(handle_));
+        jtx_mi_scene_info info; check(jtx_mi_scene_get_info(handle_, &info));
+        for (auto &l : lights) if (l.type == Light::DISTANT) l.sceneRadius = info.scene_radius;
+    }
     void destroy() { destroyBVH(); }                                  // mesh arrays stay with the caller
     float getSceneRadius() const { if (!handle_) return 0; jtx_mi_scene_info i; check(jtx_mi_scene_get_info(handle_, &i)); return i.scene_radius; }
 

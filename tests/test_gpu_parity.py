@@ -1083,3 +1083,87 @@ def test_thin_dielectric_bxdf_batch(gpu, emissive_pair):
             assert_same_f32(b[k], a[k], f"thin dielectric sample {k}")
         assert not sc.evalBxdf(mi, nrm, wo, wi, uv).any() and not sc.pdfBxdf(mi, nrm, wo, wi, uv).any()
         assert not osc.evalBxdf(mi, nrm, wo, wi, uv).any() and not osc.pdfBxdf(mi, nrm, wo, wi, uv).any()
+
+
+# ---- device refit after transform edits (jtx_refit.hip) ----
+def _edit(gpu, data, seed):
+    """a translate + non-uniform scale + rotation for a few meshes (what Display's edit panel produces, display.cpp:545-588)"""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for mi in rs.choice(len(data.meshes), min(4, len(data.meshes)), replace=False):
+        a = rs.uniform(-0.4, 0.4)
+        rot = np.array([[np.cos(a), 0, np.sin(a), 0], [0, 1, 0, 0], [-np.sin(a), 0, np.cos(a), 0], [0, 0, 0, 1]], np.float32)
+        sc = np.diag(list(rs.uniform(0.8, 1.25, 3)) + [1.0]).astype(np.float32)
+        tr = np.eye(4, dtype=np.float32); tr[:3, 3] = rs.uniform(-25, 25, 3)
+        out[int(mi)] = (tr @ rot @ sc).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("which", ["cornell", "mixed", "atrium"])
+def test_refit_equals_a_fresh_build_of_the_edited_scene(gpu, which):
+    """jtx_mi_scene_refit: (a) setting the SAME transforms again reproduces the built scene bit for bit (film and ray
+    counters); (b) after real edits every ray finds the hit distance a FRESH build of the edited scene finds (binary records
+    and 8-ary nodes), the same primitive except among equal distances, and the rendered frame equals the oracle's frame of
+    the edited scene on all but a handful of tie pixels; (c) the refitted boxes are the boxes a build computes."""
+    make = {"cornell": gpu.scenes.cornell, "mixed": lambda: gpu.scenes.mixed(sphere_res=(16, 8)),
+            "atrium": lambda: gpu.scenes.atrium(target_tris=30000)}[which]
+    data = make()
+    sc = gpu.Scene(data); sc.buildBVH()
+    W, H = 200, 120
+    ref = gpu.StaticCamera(W, H, data.camera, 2, 2, 5); ref.render(sc, count_rays=True)
+    base_cnt = dict(ref.counters)
+    # (a) identity edit
+    for mi in range(len(data.meshes)):
+        sc.setTransform(mi, data.meshes[mi]["transform"])
+    sc.refit()
+    assert sc.info()["refitted"]
+    again = gpu.StaticCamera(W, H, data.camera, 2, 2, 5); again.render(sc, count_rays=True)
+    assert_same_f32(again.acc_, ref.acc_, "identity refit"); assert again.counters == base_cnt
+    again.render(sc, count_rays=False)
+    assert_same_f32(again.acc_, ref.acc_, "identity refit, uncounted")
+    # (b) real edits
+    edits = _edit(gpu, data, 5)
+    fresh_data = make()
+    for mi, m in edits.items():
+        sc.setTransform(mi, m)
+        fresh_data.meshes[mi]["transform"] = m.copy()
+    sc.refit()
+    fresh = gpu.Scene(fresh_data); fresh.buildBVH()
+    osc = ol.OracleScene(fresh_data)
+    o, d = _rays_for(fresh_data, osc, 60000, 9)
+    a, b = sc.closestHit(o, d), fresh.closestHit(o, d)
+    assert (a["hit"] == b["hit"]).all() and a["hit"].mean() > 0.3
+    assert_same_f32(a["t"], b["t"], "hit distance after refit vs fresh build")
+    same_prim = (a["point"] == b["point"]).all(axis=1) & (a["normal"] == b["normal"]).all(axis=1)
+    assert same_prim.mean() > 0.9995                                  # differences only among exactly equal distances
+    tmax = np.where(a["hit"] > 0, a["t"] * 0.999, 1e30).astype(np.float32)
+    assert (sc.anyHit(o, d, 0.0, tmax) == fresh.anyHit(o, d, 0.0, tmax)).all()
+    cam = fresh_data.camera_desc(W, H, 2, 2, 5)
+    acc, img, _ = osc.render(cam, count=False)
+    for count in (True, False):                                      # binary records, then the wide nodes / LDS copy
+        g = gpu.StaticCamera(W, H, data.camera, 2, 2, 5); g.render(sc, count_rays=count)
+        diff = (g.acc_.view(np.uint32) != acc.view(np.uint32)).any(axis=2)
+        assert diff.mean() < 2e-3, f"{which}: {diff.sum()} pixels differ after refit (count={count})"
+    # (c) boxes: every refitted node box = union of its primitives' boxes of the edited scene (what a build computes)
+    nodes, refs = sc.bvh()
+    tri = np.stack([_tri_world(fresh_data, r) for r in refs[:: max(1, len(refs) // 2000)]])
+    leaves = nodes[nodes["num_prims"] > 0]
+    assert np.isfinite(nodes["pmin"]).all() and (nodes["pmin"] <= nodes["pmax"]).all()
+    root = nodes[0]
+    allv = np.concatenate([_tri_world(fresh_data, r) for r in refs])
+    assert np.array_equal(root["pmin"], allv.min(0)) and np.array_equal(root["pmax"], allv.max(0))
+    fr_nodes, _ = fresh.bvh()
+    assert np.array_equal(fr_nodes[0]["pmin"], root["pmin"]) and np.array_equal(fr_nodes[0]["pmax"], root["pmax"])
+    assert abs(sc.info()["scene_radius"] - fresh.info()["scene_radius"]) == 0
+    sc.destroy(); fresh.destroy()
+
+
+def _tri_world(data, ref):
+    idx, mesh = int(ref[0]), int(ref[1])
+    m = data.meshes[mesh]
+    T = m["transform"].astype(np.float32)
+    v = m["vertices"][m["indices"][idx]].astype(np.float32)          # (3, 3)
+    out = np.empty((3, 3), np.float32)
+    for r in range(3):                                               # applyToPoint row by row, fp32 left to right
+        out[:, r] = ((T[r, 0] * v[:, 0] + T[r, 1] * v[:, 1]) + T[r, 2] * v[:, 2]) + T[r, 3]
+    return out
