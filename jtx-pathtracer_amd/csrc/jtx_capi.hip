@@ -83,6 +83,7 @@ struct jtx_mi_scene {
     std::vector<int> level_begin;    // per interior depth: offsets into level_nodes
     int num_leaves = 0, num_wide = 0, refitted = 0;
     bool xf_dirty = false;
+    DevBuf<float4> lw_box; DevBuf<unsigned> lw_tab;   // flat leaf list of tiny scenes (traverseLeaves)
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (64, used round-robin)
     unsigned work_slot = 0;
@@ -427,6 +428,37 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     s.tnodes.upload(tn);
     s.dev.tnodes = s.tnodes.p;
     s.rec_node.upload(recNode);
+    // ---- tiny scenes: the flat leaf list of traverseLeaves (leaves in b.nodes order; per octant: leaf at position p,
+    //      position of leaf l -- read off the threaded orderings) ----
+    s.lw_box.release(); s.lw_tab.release(); s.dev.lw_box = nullptr; s.dev.lw_tab = nullptr; s.dev.lw_leaves = 0;
+    {
+        std::vector<int> leafId(nn, -1); int nl = 0;
+        for (size_t i = 0; i < nn; ++i) if (b.nodes[i].num_prims) leafId[i] = nl++;
+        if (nl > 0 && nl <= 32 && nn > 1) {
+            const int npad = (nl + 3) & ~3;                                     // phase A of traverseLeaves runs in groups of four
+            std::vector<float4> lb(2 * (size_t) npad, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (size_t i = 0; i < nn; ++i) if (leafId[i] >= 0) {
+                const jtx_mi_bvh_node &n = b.nodes[i];
+                const int z = n.offset, w = n.num_prims; float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
+                lb[2 * (size_t) leafId[i]] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
+                lb[2 * (size_t) leafId[i] + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+            }
+            std::vector<unsigned> tab(128, 0u);
+            for (int k = 0; k < 8; ++k) {
+                int p2 = 0;
+                for (size_t i = 0; i < nn; ++i) {
+                    const int l = leafId[recNode[(size_t) k * nn + i]];
+                    if (l < 0) continue;
+                    tab[16 * k + (p2 >> 2)] |= (unsigned) l << (8 * (p2 & 3));                    // leaf visited at position p2
+                    tab[16 * k + 8 + (l >> 2)] |= (unsigned) p2 << (8 * (l & 3));                 // position of leaf l
+                    ++p2;
+                }
+                for (int l = nl; l < npad; ++l) tab[16 * k + 8 + (l >> 2)] |= (unsigned) l << (8 * (l & 3));   // padding: positions >= nl
+            }
+            s.lw_box.upload(lb); s.lw_tab.upload(tab);
+            s.dev.lw_box = s.lw_box.p; s.dev.lw_tab = s.lw_tab.p; s.dev.lw_leaves = nl;
+        }
+    }
 
     // ---- wide (8-ary, quantised) nodes for the uncounted kernels of HBM-resident scenes (traverseWide) ----
     s.wide.release(); s.dev.wide = nullptr; s.dev.wide_depth = 0;
@@ -881,6 +913,16 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
                 for (auto &l : ls) if (l.type == 1) { l.scene_radius = s->bvh.scene_radius; any = true; }
                 if (any) HIPCHK(hipMemcpy(s->lights.p, ls.data(), ls.size() * sizeof(DLight), hipMemcpyHostToDevice));
             }
+        }
+        if (s->dev.lw_leaves) {                                                 // tiny scenes: the flat leaf list follows the refitted nodes
+            std::vector<float4> lb(s->lw_box.n, make_float4(0.f, 0.f, 0.f, 0.f)); int l = 0;
+            for (const jtx_mi_bvh_node &n : s->bvh.nodes) if (n.num_prims) {
+                const int z = n.offset, w = n.num_prims; float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
+                lb[2 * (size_t) l] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
+                lb[2 * (size_t) l + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+                ++l;
+            }
+            HIPCHK(hipMemcpy(s->lw_box.p, lb.data(), lb.size() * sizeof(float4), hipMemcpyHostToDevice));
         }
         if (wfail) { s->dev.wide = nullptr; s->dev.wide_depth = 0; }          // a node lost its grid (coordinates out of range): binary records only
         s->refitted = 1; s->xf_dirty = false;

@@ -15,6 +15,7 @@
 // Compiled with -ffp-contract=off: results must equal the CPU oracle bit for bit.
 #include "jtx_scene_dev.hpp"
 #include "jtx_launch.hpp"
+#include <cstdlib>
 
 namespace jtx {
 
@@ -274,12 +275,19 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 // of the launch (a wave of 4 paths per lane lost ~12 % to its own drain), and the scene is staged once per workgroup.
 template <int SRC, int MASK, int BS>
 __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) k_render_paths(RenderParams p) {
-    static_assert(SRC != SRC_LDS || BS == BLOCK, "stageScene strides by BLOCK");
+    static_assert((SRC != SRC_LDS && SRC != SRC_LEAF) || BS == BLOCK, "stageScene strides by BLOCK");
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    constexpr bool LDS_SCENE = SRC == SRC_LDS;
+    constexpr bool LDS_SCENE = SRC == SRC_LDS || SRC == SRC_LEAF;
     const DevScene &sc = p.scene;
     float4 *lds_tnodes = (float4 *) smem;
     float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
+    float4 *lds_lbox = lds_tris + 3 * sc.num_prims;                     // SRC_LEAF: [leaf list][order / position tables]
+    const int lwPad = (sc.lw_leaves + 3) & ~3;
+    unsigned *lds_tab = (unsigned *) (lds_lbox + 2 * lwPad);
+    if (SRC == SRC_LEAF) {
+        for (int i = threadIdx.x; i < 2 * lwPad; i += BS) lds_lbox[i] = sc.lw_box[i];
+        for (int i = threadIdx.x; i < 128; i += BS) lds_tab[i] = sc.lw_tab[i];
+    }
     if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -352,6 +360,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
         if (alive) {
             bool done;
             if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
+            else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
+                                  src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
             else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS;
@@ -557,7 +568,10 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, i
     const bool wide = !lds && p.scene.wide != nullptr;
     constexpr int SMALL = 64;                                            // workgroup of the kernels that stage nothing
     const int bs = lds ? BLOCK : SMALL;
-    const size_t shmem = wide ? (size_t) p.scene.wide_depth * bs * sizeof(uint2) : ldsBytes(p.scene, lds);
+    static const int leafWalk = [] { const char *e = getenv("JTX_LEAF_WALK"); return e ? atoi(e) : 1; }();
+    const bool leaf = lds && p.scene.lw_leaves > 0 && leafWalk;
+    const size_t shmem = wide ? (size_t) p.scene.wide_depth * bs * sizeof(uint2)
+                              : ldsBytes(p.scene, lds) + (leaf ? (size_t) 2 * ((p.scene.lw_leaves + 3) & ~3) * sizeof(float4) + 128 * sizeof(unsigned) : 0);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
     // persistent grid: the waves the GPU can hold (occupancy of the launch bounds), no more than there are chunks
     const int occ = wide ? JTX_WIDE_OCC : JTX_RP_OCC;
@@ -566,7 +580,8 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, i
     if (waves > chunks) waves = chunks;
     const dim3 grid((unsigned) ((waves * 64 + bs - 1) / bs)), block(bs);
 #define LAUNCH_PA(L, M, B) hipLaunchKernelGGL((k_render_paths<L, M, B>), grid, block, shmem, stream, p)
-    if (lambert) { if (lds) LAUNCH_PA(SRC_LDS, MAT_DIFFUSE_ONLY, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_DIFFUSE_ONLY, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_DIFFUSE_ONLY, SMALL); }
+    if (leaf) { if (lambert) LAUNCH_PA(SRC_LEAF, MAT_DIFFUSE_ONLY, BLOCK); else LAUNCH_PA(SRC_LEAF, MAT_ALL, BLOCK); }
+    else if (lambert) { if (lds) LAUNCH_PA(SRC_LDS, MAT_DIFFUSE_ONLY, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_DIFFUSE_ONLY, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_DIFFUSE_ONLY, SMALL); }
     else         { if (lds) LAUNCH_PA(SRC_LDS, MAT_ALL, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_ALL, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_ALL, SMALL); }
 #undef LAUNCH_PA
     return hipGetLastError();

@@ -34,6 +34,10 @@ struct DevScene {
     float sky[3];
     int wide_depth;               // levels of the wide tree = LDS stack entries per lane
     const uint4     *wide;        // 8-ary quantised nodes + leaf records (traverseWide), or null
+    // tiny scenes (<= 32 leaves, LDS-resident): the flat leaf list of traverseLeaves
+    const float4    *lw_box;      // 2 float4 per leaf, leaves in b.nodes order: [min.x max.x min.y max.y][min.z max.z primitivesOffset numPrimitives]
+    const unsigned  *lw_tab;      // per direction-sign octant 16 words: bytes 0..31 = leaf visited at position p, bytes 32..63 = position of leaf l
+    int lw_leaves;                // 0: no leaf list
 };
 
 struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode only)
@@ -60,7 +64,7 @@ struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode
 #define WSTAT(x)
 #endif
 
-enum { SRC_GLOBAL = 0, SRC_LDS = 1, SRC_WIDE = 2 };
+enum { SRC_GLOBAL = 0, SRC_LDS = 1, SRC_WIDE = 2, SRC_LEAF = 3 };
 
 struct GlobalSrc {
     const float4 *tnodes, *tris;
@@ -435,7 +439,111 @@ JD bool traverseNoStack(const Src &src, int num_nodes, f3 o, f3 d, float tmin, f
     return traverseThreaded<ANY, COUNT, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);   // axis-parallel & co.
 }
 
+// ---- flat leaf list for tiny scenes (uncounted kernels, <= 32 leaves, everything in LDS) ---------------------------
+// For a REGULAR ray the reference's result is a function of the LEAVES alone (see the wide traversal above): walk the
+// leaves in the octant's near-first order; test the leaf's own box against the current interval; if it passes, test its
+// triangles.  With a few dozen leaves the interior nodes are not worth their divergence -- a wave sits through 38
+// interior iterations for 15.7 node visits per ray on the Cornell box, a third of the lanes working -- so:
+//   phase A  every leaf's box against the ray's INITIAL interval, leaf by leaf, the same leaf for all 64 lanes: no
+//            divergence, no votes, boxes as scalar operands; the passes land in a 32-bit candidate mask, bit = the leaf's
+//            position in this octant's visiting order.  (t.max only shrinks and the slab test is monotone in it: the
+//            leaves that pass later form a subset.)
+//   phase B  the candidates in visiting order; once the lane has accepted a hit (t.max shrank) a candidate's box is
+//            re-tested against the current interval -- the reference's own leaf test -- before its triangles.
+// Same leaves tested against the same intervals in the same order as Scene::closestHit / anyHit => same hits bit for bit.
+#ifndef JTX_LEAF_TRI_VOTE
+#define JTX_LEAF_TRI_VOTE 24
+#endif
+struct LeafSrc {
+    const float4 *tnodes, *tris; int half;          // the LDS copy of the binary records (irregular rays) and triangles
+    const float4 *lbox;                             // LDS copy of the leaf list
+    const float4 *gbox;                             // the same in HBM: read with wave-uniform indices -> scalar loads
+    const unsigned *tab;                            // LDS copy of the order / position tables
+    int nleaf;
+    JD float4 tnode(int i, int h) const { return tnodes[h * half + i]; }
+    JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
+};
+
+template <bool ANY>
+JD bool traverseLeaves(const LeafSrc &src, f3 o, f3 d, f3 inv, int negmask, float tmin, float tmax, HitRec &rec) {
+    const unsigned *row = src.tab + 16 * negmask;
+    unsigned pos[8];
+    if (!ANY) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) pos[w] = row[8 + w];
+    }
+    unsigned pm = 0u;
+    const int n = src.nleaf;
+    // the list is padded to a multiple of 4 (dummy boxes at positions >= n, masked off below); the boxes are read through the
+    // constant address space with wave-uniform indices: scalar loads, SGPR operands, no LDS / vector-memory traffic
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) float *CBox;
+#else
+    typedef const float *CBox;
+#endif
+    const CBox cb = (CBox) (const void *) src.gbox;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (4 * g < n) {                                                         // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * g + j;
+                const float4 na = make_float4(cb[8 * i], cb[8 * i + 1], cb[8 * i + 2], cb[8 * i + 3]);
+                const float4 nb = make_float4(cb[8 * i + 4], cb[8 * i + 5], 0.0f, 0.0f);
+                const bool pass = slabRegular(na, nb, o, inv, tmin, tmax);
+                const unsigned at = ANY ? (unsigned) i : (pos[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                pm |= (pass ? 1u : 0u) << at;
+            }
+        }
+    }
+    pm &= n >= 32 ? 0xffffffffu : (1u << n) - 1u;
+    bool hitAnything = false, shrunk = false;
+    int leafOff = 0, leafN = 0;
+    while (true) {
+        while (true) {
+            if (leafN == 0 && pm != 0u) {
+                const int k = __builtin_ctz(pm);
+                pm &= pm - 1u;
+                const int leaf = ANY ? k : (int) ((row[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                const float4 la = src.lbox[2 * leaf], lb = src.lbox[2 * leaf + 1];
+                bool pass = true;
+                if (!ANY && shrunk) pass = slabRegular(la, lb, o, inv, tmin, tmax);
+                if (pass) { leafOff = __float_as_int(lb.z); leafN = __float_as_int(lb.w); }
+            }
+            const unsigned long long walking = __ballot(leafN == 0 && pm != 0u);
+            if (walking == 0ull || __popcll(__ballot(leafN != 0)) >= JTX_LEAF_TRI_VOTE) break;
+        }
+        if (__ballot(leafN != 0) == 0ull) break;
+        if (leafN != 0) {
+            for (int i = 0; i < leafN; ++i) {
+                const int prim = leafOff + i;
+                float b1, b2, root;
+                if (!triTest(src, prim, o, d, tmin, tmax, b1, b2, root)) continue;
+                hitAnything = true;
+                if (ANY) break;
+                tmax = root; shrunk = true;
+                rec.t = root; rec.prim = prim; rec.b1 = b1; rec.b2 = b2;
+            }
+            if (ANY && hitAnything) pm = 0u;
+            leafN = 0;
+        }
+    }
+    return hitAnything;
+}
+
+template <bool ANY, bool COUNT>
+JD bool traverseNoStack(const LeafSrc &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
+    static_assert(!COUNT, "the counted kernels reproduce the reference's node visits: binary records only");
+    if (num_nodes == 0) return false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+    if (__builtin_expect(__ballot(!regularRay(o, inv, tmin, tmax)) == 0ull, 1))
+        return traverseLeaves<ANY>(src, o, d, inv, negmask, tmin, tmax, rec);
+    return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
+}
+
 struct Surface { f3 point, normal; f2 uv; int material; };
+
 
 // The accept branch of Mesh::tClosestHit (mesh.hpp:129-145) + setFaceNormal (material.hpp:36-39)
 JD Surface makeSurface(const float4 *shade, const HitRec &h, f3 o, f3 d) {
