@@ -452,7 +452,7 @@ JD bool traverseNoStack(const Src &src, int num_nodes, f3 o, f3 d, float tmin, f
 //            re-tested against the current interval -- the reference's own leaf test -- before its triangles.
 // Same leaves tested against the same intervals in the same order as Scene::closestHit / anyHit => same hits bit for bit.
 #ifndef JTX_LEAF_TRI_VOTE
-#define JTX_LEAF_TRI_VOTE 24
+#define JTX_LEAF_TRI_VOTE 1     // lanes parked on a leaf that end the candidate walk (C2: 1 -> 27.9 ms, 8 -> 28.4, 24 -> 29.1, 40 -> 29.4)
 #endif
 struct LeafSrc {
     const float4 *tnodes, *tris; int half;          // the LDS copy of the binary records (irregular rays) and triangles
