@@ -232,7 +232,7 @@ def main():
     lib = jtx._capi.load()
 
     integrator = scene.info()["auto_integrator"]
-    INTEG_NAMES = {1: "pixel-persistent", 2: "hbm-wavefront", 3: "re-entrant-stream"}
+    INTEG_NAMES = {1: "pixel-persistent", 2: "hbm-wavefront"}
 
     # per-frame exchange: compact own-pixel slabs gathered to rank 0 (default) or one sum-reduce of the full buffers
     collective = os.environ.get("JTX_FRAME_COLLECTIVE", "gather")
@@ -336,7 +336,7 @@ def main():
 
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
-        kernel_name = {1: "k_render_paths", 3: "k_render_stream"}.get(integrator)
+        kernel_name = "k_render_paths"
         launches_per_frame = 1
         info = scene.info()
         sinfo = {"lds_resident": bool(info["lds_resident"]), "lds_bytes": 8 * 32 * info["num_nodes"] + 48 * info["num_prims"],

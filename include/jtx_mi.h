@@ -108,8 +108,7 @@ typedef struct {
     int32_t tile_rank;        /* multi-GPU pixel-tile sharding: this process owns 32x32 tiles k with */
     int32_t tile_world;       /*   k % tile_world == tile_rank (0/0 or 0/1 => whole frame) */
     int32_t integrator;       /* 0 auto = the measured policy of DESIGN.md section 5 (1 in practice; env JTX_INTEGRATOR overrides);
-                               * 1 pixel-persistent (the timed one), 2 HBM-queued wavefront, 3 re-entrant stream kernel (experimental;
-                               * counting launches of 3 run as 1).  All give the same film bit for bit. */
+                               * 1 pixel-persistent (the timed one), 2 HBM-queued wavefront.  Both give the same film bit for bit. */
     int32_t count_rays;       /* != 0: accumulate jtx_mi_counters on the device (slower); the counting kernels walk the
                                * reference's binary BVH node by node, so the counters are Scene::closestHit / anyHit's own.
                                * 0: same film bit for bit; scenes that do not fit LDS walk an 8-ary quantised BVH instead
@@ -210,7 +209,7 @@ int jtx_mi_last_completed_sample(const jtx_mi_scene *scene, int32_t *out);  /* c
 int jtx_mi_render_device(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
                          void *d_acc_rgb, void *d_img_rgb, void *stream);
 /* for jtx_mi_render_device users: the cancellation word of jtx_mi_cancel is sticky; jtx_mi_render clears it itself */
-int jtx_mi_cancel_pending(const jtx_mi_scene *scene, int32_t *out);
+int jtx_mi_cancel_pending(jtx_mi_scene *scene, int32_t *out);   /* after a sync: 0 none, 1 pending (the last pass completed), 2 pending and the last pass was abandoned */
 int jtx_mi_cancel_reset(jtx_mi_scene *scene);
 int jtx_mi_sync(jtx_mi_scene *scene);
 /* GPU time of the integrator kernel(s) of the last render call(s) since the previous query,

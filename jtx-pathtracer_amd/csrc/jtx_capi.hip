@@ -66,6 +66,13 @@ bool hostPinned(const void *p) {
 
 int jtx_capi_fail(const std::string &msg) { return fail(msg); }     // for the other translation units of the library
 
+namespace {
+// after the stream has drained: did the last persistent launch stop on the cancellation flag (k_render_paths pushes its
+// chunk counter past 2^30 then, and k_resolve_samples skips the pass)?  Launches that never poll (counting, alternate
+// integrators, wavefront) complete, and a cancellation is honoured between their passes.
+bool passAbandoned(jtx_mi_scene &s);
+}
+
 struct jtx_mi_scene {
     jtxh::BvhResult bvh;
     DevBuf<float4> tnodes, tris, shade;
@@ -87,6 +94,7 @@ struct jtx_mi_scene {
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (64, used round-robin)
     unsigned work_slot = 0;
+    unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;
     DevScene dev{};
@@ -570,7 +578,7 @@ std::pair<hipEvent_t, hipEvent_t> takeEvents(jtx_mi_scene &s) {
 int autoIntegrator(const jtx_mi_scene &s) {
     const char *e = getenv("JTX_INTEGRATOR");
     const int v = e ? atoi(e) : 0;
-    if (v >= 1 && v <= 3) return v;
+    if (v >= 1 && v <= 2) return v;
     return (s.dev.lds_threaded || s.dev.material_mask == MAT_DIFFUSE_ONLY || s.dev.wide) ? 1 : 2;
 }
 
@@ -701,7 +709,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     if (s.counters.n < 64 + 2 * 65536) { s.counters.alloc(64 + 2 * 65536); HIPCHK(hipMemsetAsync(s.counters.p, 0, (64 + 2 * 65536) * sizeof(unsigned long long), stream)); }
 #endif
     p.counters = s.counters.p;
-    if (o.integrator < 0 || o.integrator > 3) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent), 2 (HBM wavefront) or 3 (re-entrant stream kernel, experimental)");
+    if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (HBM wavefront)");
     int integ = o.integrator;
     if (integ == 0) integ = autoIntegrator(s);
     // timing pairs are only drained by jtx_mi_kernel_time (bench / tools): a UI that never asks keeps the newest 64
@@ -719,7 +727,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     HIPCHK(hipEventRecord(ev.first, stream));
     if (alt) {
         HIPCHK(jtx_launch_render_alt(p, owned, count, o.path_integrator, stream));
-    } else if (integ == 1 || integ == 3) {
+    } else if (integ == 1) {
         // strata groups: the strata of a pixel block are spread over `groups` waves (gridDim.y); every path's clamped
         // radiance goes to rad[stratum][pixel] and k_resolve_samples adds them to the film in sample order.
         // One-lane-per-pixel launches (counting, JTX_DYNAMIC_PATHS=0) split only small shards / frames: 32 or 64 ways.
@@ -759,8 +767,8 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 if (!s.work.p) s.work.alloc(64);
                 q.work = s.work.p + (s.work_slot++ & 63);                 // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
-                if (integ == 3) HIPCHK(jtx_launch_render_stream(q, owned, s.num_cus, stream));       // re-entrant path kernel (jtx_stream.hip)
-                else HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
+                s.last_work = q.work;
+                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }
@@ -1033,13 +1041,6 @@ int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
     return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
-#ifdef JTX_PROFILE_STREAM
-int jtx_mi_debug_stream(jtx_mi_scene *s, unsigned long long *out8) {   // diagnostic builds only: trips and active lanes per block kind
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out8, s->counters.p + 32, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
 #ifdef JTX_PROFILE_TIMELINE
 int jtx_mi_debug_timeline(jtx_mi_scene *s, unsigned long long *out, int n) {   // diagnostic builds only: (start, end) wall clocks per wave
     if (!s || !s->counters.p) return 1;
@@ -1077,10 +1078,24 @@ int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 
-int jtx_mi_cancel_pending(const jtx_mi_scene *s, int32_t *out) {
-    if (!s || !out || !s->stop_host) return fail("null argument");
-    *out = __atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE) ? 1 : 0;
-    return 0;
+namespace {
+bool passAbandoned(jtx_mi_scene &s) {
+    if (!s.last_work) return false;
+    unsigned v = 0;
+    HIPCHK(hipMemcpy(&v, s.last_work, sizeof v, hipMemcpyDeviceToHost));
+    return v >= 0x40000000u;
+}
+}
+
+// 1: a cancellation is pending (jtx_mi_cancel since the last reset); 2: and the last persistent pass was abandoned by it
+int jtx_mi_cancel_pending(jtx_mi_scene *s, int32_t *out) {
+    try {
+        if (!s || !out || !s->stop_host) throw std::runtime_error("null argument");
+        DeviceGuard dg(s->device);
+        const bool pending = __atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE) != 0;
+        *out = pending ? (passAbandoned(*s) ? 2 : 1) : 0;
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
 }
 int jtx_mi_cancel_reset(jtx_mi_scene *s) {
     if (!s || !s->stop_host) return fail("null scene");
@@ -1152,7 +1167,7 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
             lap("enqueue");
             fetchImg();                                                         // the pass in flight: preview to (pinned) host memory
             lap("pass + img D2H");
-            if (__atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE)) { cancelled = true; break; }   // that pass was abandoned by the kernels
+            if (passAbandoned(*s)) { cancelled = true; break; }               // the kernels saw the cancellation: that pass left no trace
             done = inFlightEnd;
             if (count) {
                 unsigned long long h[9];

@@ -545,7 +545,9 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
     const int row = trow * 32 + (sub >> 2) * 8 + (lane >> 3);
     const int col = tcol * 32 + (sub & 3) * 8 + (lane & 7);
     if (pslot >= p.rad_stride || row >= p.height || col >= p.width) return;
-    if (p.stop && __hip_atomic_load(p.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;   // cancelled pass: its records are incomplete
+    // a cancelled pass has incomplete records: the wave that saw the cancellation pushed the chunk counter past 2^30
+    // (device memory: one cached load per thread, not one PCIe read of the host's flag)
+    if (p.work && *(volatile const unsigned *) p.work >= 0x40000000u) return;
     const size_t pix = (size_t) row * p.width + col;
     f3 acc = mk3(0.0f);
     if (p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);

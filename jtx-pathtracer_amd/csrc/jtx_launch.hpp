@@ -88,7 +88,6 @@ hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
-hipError_t jtx_launch_render_stream(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
 hipError_t jtx_launch_render_alt(const jtx::RenderParams &p, int num_owned_tiles, bool count, int li, hipStream_t stream);
 hipError_t jtx_launch_radiance_samples_alt(const jtx::DevScene &sc, const jtx::DCam &cam, int maxDepth, int li, int n, const int *row,
                                            const int *col, const int *sample, float *rgb, hipStream_t stream);

@@ -249,7 +249,7 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
             // ---- all shards in; a pass that any shard abandoned is void everywhere ----
             int wasCancelled = 0;
             for (int r = 0; r < n; ++r) { SetDev sd(m->shards[r].device); MHIPCHK(hipStreamSynchronize(m->shards[r].stream)); }
-            for (int r = 0; r < n; ++r) { int32_t flag = 0; MCHK(jtx_mi_cancel_pending(m->shards[r].scene, &flag)); wasCancelled |= flag; }
+            for (int r = 0; r < n; ++r) { int32_t flag = 0; MCHK(jtx_mi_cancel_pending(m->shards[r].scene, &flag)); wasCancelled |= flag; }   // pending on any shard: the pass is void everywhere
             if (wasCancelled) { cancelled = true; break; }
             // ---- device 0: scatter the slabs into the frame, preview to the host ----
             {

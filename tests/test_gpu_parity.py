@@ -164,7 +164,7 @@ def _render_both(gpu, data, sc, osc, w, h, xs, ys, depth, **kw):
     return cam_g, acc, img, cnt
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2])
 def test_render_config1_cornell_512(gpu, cornell_pair, integrator):
     """BASELINE config 1: Cornell 512x512, 16 spp (4x4), depth 4 -- whole frame, bit-exact, both integrators."""
     data, sc, osc = cornell_pair
@@ -175,7 +175,7 @@ def test_render_config1_cornell_512(gpu, cornell_pair, integrator):
     assert cnt["n_camera"] == 512 * 512 * 16
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2])
 def test_render_mixed_small(gpu, mixed_pair, integrator):
     data, sc, osc = mixed_pair
     cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 200, 120, 2, 2, 8, integrator=integrator)
@@ -184,7 +184,7 @@ def test_render_mixed_small(gpu, mixed_pair, integrator):
     assert cam_g.counters == cnt
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2])
 def test_render_ragged_sizes(gpu, cornell_pair, integrator):
     """widths/heights that are not multiples of the 8x8 wave block or the 32x32 tile; 1x1 image."""
     data, sc, osc = cornell_pair
@@ -260,7 +260,7 @@ def test_dynamic_camera_on_a_second_device(gpu, cornell_pair):
     sc1.destroy()
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2])
 def test_render_tile_sharding(gpu, cornell_pair, integrator):
     """pixel-tile shards of 3 ranks are disjoint, zero elsewhere, and sum to the 1-GPU frame exactly."""
     data, sc, osc = cornell_pair
@@ -322,7 +322,7 @@ def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
     assert kv["multihash"] == "1af9ba89" and kv["multisamples"] == "4"      # 3 shards through jtx_mi_multi_render
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2])
 def test_render_atrium_small(gpu, integrator):
     """config C3's scene family (deep BVH in HBM, DISTANT light + sky) at a size the oracle renders in seconds."""
     data = gpu.scenes.atrium(target_tris=20000)
@@ -430,7 +430,7 @@ def _edge_scene(gpu):
     return s
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2])
 @pytest.mark.parametrize("max_prims", [1, 4])
 def test_render_edge_cases(gpu, integrator, max_prims):
     """mesh transforms baked on upload, texture wrap with negative uv, 3 lights (Q2), thin lens, maxPrimsInNode > 1."""
@@ -445,7 +445,7 @@ def test_render_edge_cases(gpu, integrator, max_prims):
         assert sc.bvh()[0]["num_prims"].max() > 1
 
 
-@pytest.mark.parametrize("integrator", [1, 2, 3])
+@pytest.mark.parametrize("integrator", [1, 2])
 def test_render_depth_zero_and_no_lights(gpu, cornell_pair, integrator):
     data, sc, osc = cornell_pair
     cam_g, acc, img, cnt = _render_both(gpu, data, sc, osc, 64, 48, 1, 2, 0, integrator=integrator)    # maxDepth 0: one closestHit per path

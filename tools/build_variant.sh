@@ -1,8 +1,8 @@
 #!/bin/bash
-# local: build jtx-pathtracer_amd/libjtx_mi_<tag>.so with extra -D flags applied to ONE source (default jtx_stream.hip);
+# local: build jtx-pathtracer_amd/libjtx_mi_<tag>.so with extra -D flags applied to ONE source (default jtx_kernels.hip);
 # the other objects are compiled once into /tmp/jtxobj.  usage: tools/build_variant.sh <tag> "<flags>" [source.hip]
 cd "$(dirname "$0")/../jtx-pathtracer_amd/csrc" || exit 1
-tag=$1; flags=$2; vsrc=${3:-jtx_stream.hip}
+tag=$1; flags=$2; vsrc=${3:-jtx_kernels.hip}
 OBJ=/tmp/jtxobj; mkdir -p $OBJ
 CF="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function"
 SRCS=$(python3 -c "import re;print(' '.join(re.findall(r'\"(jtx_[a-z_]+\.(?:hip|cpp))\"', open('../build.py').read().split('SOURCES')[1].split(']')[0])))")

@@ -6,7 +6,7 @@ lib = jtx._capi.load()
 which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 data = jtx.scenes.atrium() if which == "atrium" else jtx.scenes.mixed()
 sc = jtx.Scene(data); sc.buildBVH()
-W, H, xs, ys = 960, 540, 4, 4
+W, H, xs, ys = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (960, 540, 4, 4)
 cam = jtx.StaticCamera(W, H, data.camera, xs, ys, 8)
 cam.render(sc, count_rays=True, integrator=1)        # allocates + zeroes the counter block; binary records
 c = cam.counters
@@ -28,3 +28,7 @@ iv = (C.c_uint64 * 4)(); assert g(sc.handle, iv) == 0
 npk, nd, lw, ld = [int(x) for x in iv]
 print(f"node iterations, lane share: walking {nst / (64.0 * nit):.3f} parked {npk / (64.0 * nit):.3f} done {nd / (64.0 * nit):.3f} (rest: lanes without a path)")
 print(f"leaf iterations, lane share: on a leaf {lst / (64.0 * lit):.3f} walking {lw / (64.0 * lit):.3f} done {ld / (64.0 * lit):.3f}")
+import json
+json.dump({"node_steps_per_ray": nst / rays, "leaf_steps_per_ray": lst / rays, "tri_tests_per_ray": (c['n_tri_closest'] + c['n_tri_any']) / rays,
+           "node_iterations_per_call": nit / calls, "node_lane_share": {"walking": nst / (64.0 * nit), "parked": npk / (64.0 * nit), "done": nd / (64.0 * nit)},
+           "frame": f"{W}x{H}x{xs * ys}spp", "rays": rays}, open(f"gpurun_out/wide_stats_{which}.json", "w"))
