@@ -138,7 +138,7 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
     # ---- own-layout algorithmic HBM bytes of this launch ----
     paths = mine["n_camera"]; rays = mine["n_closest"] + mine["n_any"]
     own = 16 * paths                                       # one 16-B radiance record per path (k_resolve_samples reads them back)
-    own += 128 * mine["n_shade"]                           # 64-B shading record + 64-B material per shading event
+    own += (64 + 80) * mine["n_shade"]                     # 64-B shading record + 80-B material per shading event
     ws = (pmc or {}).get("wide_stats")
     if scene_info["lds_resident"]:
         own += scene_info["lds_bytes"] * scene_info.get("workgroups", 0)     # the scene staged once per workgroup
@@ -322,6 +322,8 @@ def main():
     if world == 1:
         import numpy as np
         hacc = np.zeros(H * W * 3, np.float32); himg = np.zeros(H * W * 3, np.uint8)
+        for a in (hacc, himg):                        # page-locked like Camera::acc_ / img_ in the host mirrors (jtx_mi_pin_host)
+            lib.jtx_mi_pin_host(a.ctypes.data_as(C.c_void_p), a.nbytes)
         o = jtx._capi.RenderOpts(); o.integrator = integrator
         def host_frame():
             jtx._capi.check(lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), hacc.ctypes.data_as(C.POINTER(C.c_float)),
@@ -332,6 +334,8 @@ def main():
         for _ in range(nh):
             host_frame()
         host_ms = (time.perf_counter() - th) / nh * 1e3
+        for a in (hacc, himg):
+            lib.jtx_mi_unpin_host(a.ctypes.data_as(C.c_void_p))
         jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))     # drop those events
 
     if rank == 0:
