@@ -92,6 +92,7 @@ struct jtx_mi_scene {
     bool xf_dirty = false;
     DevBuf<float4> lw_box; DevBuf<unsigned> lw_tab;   // flat leaf list of tiny scenes (traverseLeaves)
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
+    DevBuf<float4> qstate;           // k_render_queue: slot records + ray results of the persistent waves
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (64, used round-robin)
     unsigned work_slot = 0;
     unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
@@ -167,6 +168,9 @@ struct WideBuilder {
     const std::vector<jtx_mi_bvh_node> &nodes;
     std::vector<uint4> &out;
     std::vector<int> leaves;           // leaf count of every binary subtree
+    // optimal cut (surface-area cost): F[8 n + k - 1] = the least sum of box areas of all wide nodes needed below binary
+    // node n when n's subtree may occupy at most k child slots of its parent's wide node (k = 1: n itself is the child)
+    std::vector<float> F;
     std::vector<int32_t> *refit = nullptr;   // optional: 16 ints per wide node {granule, binary node, #interior, #leaves, leaf-record granule, -, -, -, children[8]}
     int depth = 0;
     bool ok = true;
@@ -185,6 +189,30 @@ struct WideBuilder {
         return dx * dy + dy * dz + dz * dx;
     }
 
+    float Fk(int n, int k) const { return F[8 * (size_t) n + k - 1]; }
+
+    // bottom-up (children stand behind their parent in the depth-first array): W(n) = area(n) + the best split of
+    // at most 8 slots over n's two subtrees; F(n, k) = min(W(n), best split of at most k slots); leaves cost nothing here
+    // (their boxes are tested whatever the cut).  The classic surface-area collapse of wide-BVH builders, applied to the
+    // reference's binary tree -- any cut gives the same hits (leaf-walk argument in jtx_scene_dev.hpp), this one the fewest node steps.
+    void prepareCuts() {
+        const size_t n = nodes.size();
+        F.assign(8 * n, 0.0f);
+        for (size_t i = n; i-- > 0;) {
+            if (leaf((int) i)) continue;
+            const int L = (int) i + 1, R = nodes[i].offset;
+            float best[9];                                  // best[k]: best split with at most k slots, k >= 2
+            for (int k = 2; k <= 8; ++k) {
+                float c = 3.0e38f;
+                for (int a = 1; a < k; ++a) { const float v = Fk(L, a) + Fk(R, k - a); if (v < c) c = v; }
+                best[k] = c;
+            }
+            const float W = (float) area(nodes[i]) + best[8];
+            F[8 * i] = W;
+            for (int k = 2; k <= 8; ++k) F[8 * i + k - 1] = best[k] < W ? best[k] : W;
+        }
+    }
+
     void fill(int b, size_t at, int level) {
         if (!ok) return;
         if (level + 1 > depth) depth = level + 1;
@@ -195,6 +223,26 @@ struct WideBuilder {
         auto add = [&](int node) { t[nt] = {node, -1, -1}; return nt++; };
         add(b);
         t[0].left = add(b + 1); t[0].right = add(nb.offset);
+        if (!F.empty()) {
+            // the cut of at most 8 subtrees that minimises the summed box area of the wide nodes below (prepareCuts)
+            nt = 1; t[0].left = t[0].right = -1;
+            struct Job { int ti, k; } jobs[16]; int nj = 0;
+            jobs[nj++] = {0, 8};
+            bool root = true;
+            while (nj) {
+                const Job j = jobs[--nj];
+                const int node = t[j.ti].node;
+                if (leaf(node)) continue;
+                const int L = node + 1, R = nodes[node].offset;
+                int bi = 0; float bc = root ? 3.0e38f : Fk(node, 1);            // bi = 0: stays a child of this wide node
+                for (int i = 1; i < j.k; ++i) { const float c = Fk(L, i) + Fk(R, j.k - i); if (c < bc) { bc = c; bi = i; } }
+                root = false;
+                if (bi == 0) continue;
+                const int l = add(L), r = add(R);
+                t[j.ti].left = l; t[j.ti].right = r;
+                jobs[nj++] = {r, j.k - bi}; jobs[nj++] = {l, bi};
+            }
+        } else {
         int nchild = 2;
         // 1. swallow whole subtrees that fit into the free slots, smallest first (a subtree of m leaves costs m - 1
         //    slots and saves a wide node that would test only m boxes); 2. otherwise open the child with the largest box
@@ -222,6 +270,7 @@ struct WideBuilder {
             const int l = add(t[best].node + 1), r = add(nodes[t[best].node].offset);
             t[best].left = l; t[best].right = r;
             ++nchild;
+        }
         }
         // children left to right; slots: wide (interior) children first, then leaf records, each in that order
         int order[8], n = 0;
@@ -256,32 +305,34 @@ struct WideBuilder {
             }
             perm[o] = pm;
         }
-        const size_t base = out.size();
-        if (base + 6 * (size_t) ni + 2 * (size_t) nl >= (1ull << 28)) { ok = false; return; }
-        out.resize(base + 6 * (size_t) ni + 2 * (size_t) nl);
+        constexpr size_t G = jtx::WIDE_NODE_G;                          // granules per interior child (8: the block starts on a 128-byte line)
+        const size_t base = G == 8 ? (out.size() + 7) & ~(size_t) 7 : out.size();
+        if (base + G * (size_t) ni + 2 * (size_t) nl >= (1ull << 28)) { ok = false; return; }
+        out.resize(base + G * (size_t) ni + 2 * (size_t) nl);
         auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
         auto pack = [](const uint8_t *q) { return jtxq::pack4(q); };
-        // 24-bit orders of the 8 octants, packed back to back into 6 words
-        uint32_t pw[6] = {0, 0, 0, 0, 0, 0};
+        // 24-bit orders: octants 0-3 (z >= 0) back to back in 3 words behind the children base in granule 4, octants 4-7 the
+        // same way in granule 5: a lane reads the base AND its order with one 16-byte load
+        uint32_t pw[2][3] = {{0, 0, 0}, {0, 0, 0}};
         for (int o = 0; o < 8; ++o) {
-            const int bit = 24 * o, w = bit >> 5, sh = bit & 31;
-            pw[w] |= perm[o] << sh;
-            if (sh > 8) pw[w + 1] |= perm[o] >> (32 - sh);
+            const int bit = 24 * (o & 3), w = bit >> 5, sh = bit & 31;
+            pw[o >> 2][w] |= perm[o] << sh;
+            if (sh > 8) pw[o >> 2][w + 1] |= perm[o] >> (32 - sh);
         }
         out[at + 0] = make_uint4(fb(nb.pmin[0]), fb(nb.pmin[1]), fb(nb.pmin[2]),
                                  ebyte[0] | ebyte[1] << 8 | ebyte[2] << 16 | (uint32_t) ni << 24 | (uint32_t) (ni + nl) << 28);
         out[at + 1] = make_uint4(pack(qlo[0]), pack(qlo[0] + 4), pack(qlo[1]), pack(qlo[1] + 4));
         out[at + 2] = make_uint4(pack(qlo[2]), pack(qlo[2] + 4), pack(qhi[0]), pack(qhi[0] + 4));
         out[at + 3] = make_uint4(pack(qhi[1]), pack(qhi[1] + 4), pack(qhi[2]), pack(qhi[2] + 4));
-        out[at + 4] = make_uint4((uint32_t) base, pw[0], pw[1], pw[2]);
-        out[at + 5] = make_uint4(pw[3], pw[4], pw[5], 0u);
+        out[at + 4] = make_uint4((uint32_t) base, pw[0][0], pw[0][1], pw[0][2]);
+        out[at + 5] = make_uint4((uint32_t) base, pw[1][0], pw[1][1], pw[1][2]);
         if (refit) {
-            int32_t rec[16] = {(int32_t) at, b, ni, nl, (int32_t) (base + 6 * (size_t) ni), 0, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1};
+            int32_t rec[16] = {(int32_t) at, b, ni, nl, (int32_t) (base + G * (size_t) ni), 0, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1};
             for (int s2 = 0; s2 < ni + nl; ++s2) rec[8 + s2] = child[s2];
             refit->insert(refit->end(), rec, rec + 16);
         }
-        for (int s = ni; s < ni + nl; ++s) writeLeaf(base + 6 * (size_t) ni + 2 * (size_t) (s - ni), child[s]);
-        for (int s = 0; s < ni; ++s) fill(child[s], base + 6 * (size_t) s, level + 1);
+        for (int s = ni; s < ni + nl; ++s) writeLeaf(base + G * (size_t) ni + 2 * (size_t) (s - ni), child[s]);
+        for (int s = 0; s < ni; ++s) fill(child[s], base + G * (size_t) s, level + 1);
     }
 };
 
@@ -298,6 +349,8 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
             if (nodes[i].offset <= (int) i + 1 || (size_t) nodes[i].offset >= nodes.size()) return false;
             wb.leaves[i] = wb.leaves[i + 1] + wb.leaves[nodes[i].offset];
         }
+    static const int sahCut = [] { const char *e = getenv("JTX_WIDE_SAH_CUT"); return e ? atoi(e) : 1; }();
+    if (sahCut) wb.prepareCuts();                                     // JTX_WIDE_SAH_CUT=0: the greedy largest-box cut of round 1
     out.resize(6);
     wb.fill(0, 0, 0);
     depth = wb.depth;
@@ -757,6 +810,16 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             const size_t need = (size_t) p.rad_stride * (size_t) chunk;
             if (s.rad.n < need) s.rad.alloc(need);
             p.rad = s.rad.p;
+            // JTX_QUEUE=1: ray queues per lane for HBM-resident scenes (jtx_queue.hip: bit-identical, lane use 0.36 -> 0.56, but
+            // slower -- the memory system, not the issue slots, is what the 8-ary traversal waits for)
+            static const int queueKernel = [] { const char *e = getenv("JTX_QUEUE"); return e ? atoi(e) : 0; }();
+            const bool queued = queueKernel && !s.dev.lds_threaded && s.dev.wide != nullptr;
+            p.qstate = nullptr;
+            if (queued) {
+                const size_t qn = jtx_queue_state_float4(s.num_cus);
+                if (s.qstate.n < qn) s.qstate.alloc(qn);
+                p.qstate = s.qstate.p;
+            }
             for (int b0 = sb; b0 < se; b0 += chunk) {
                 RenderParams q = p;
                 q.sample_begin = b0; q.sample_end = b0 + chunk < se ? b0 + chunk : se;
@@ -768,7 +831,8 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.work = s.work.p + (s.work_slot++ & 63);                 // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
                 s.last_work = q.work;
-                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
+                if (queued) HIPCHK(jtx_launch_render_queue(q, owned, s.num_cus, stream));
+                else HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }
@@ -1039,6 +1103,13 @@ int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
     if (!s || !s->counters.p) return 1;
     (void) hipDeviceSynchronize();
     return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+#ifdef JTX_PROFILE_QUEUE
+int jtx_mi_debug_queue(jtx_mi_scene *s, unsigned long long *out14) {   // diagnostic builds only (jtx_queue.hip)
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out14, s->counters.p + 24, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
 #ifdef JTX_PROFILE_TIMELINE

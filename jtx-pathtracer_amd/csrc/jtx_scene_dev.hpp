@@ -238,14 +238,19 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 //     (plane = origin + q 2^e, checked in exact arithmetic on the host), so a slab test on it can only
 //     pass more often than on any exact box inside it.
 //       [origin.xyz | ex ey ez, #interior, #children] [lo.x x8 | lo.y x8] [lo.z x8 | hi.x x8] [hi.y x8 | hi.z x8]
-//       [children base | 8 visiting orders x 24 bit ...] [... | 0]
-//     children block (16-B granules): interior children (6 granules each), then leaf records (2 each).
+//       [children base | visiting orders of octants 0-3, 4 x 24 bit] [children base | ... of octants 4-7]
+//     children block (16-B granules): interior children (WIDE_NODE_G granules apart: 8 = one 128-byte line per node, the
+//     block starts on a line), then leaf records (2 each).
 //     visiting order of an octant: the slots in the order the reference's near-first rule (dirIsNeg[axis],
 //     scene.cpp:40-46) walks the treelet, 3 bits per position.
 //   leaf record (32 B): the exact leaf box + primitivesOffset + numPrimitives, tested with slabRegular.
 // The per-lane stack holds one 64-bit entry per wide level {children base, #interior, visiting order,
 // pending positions} in LDS.  A stale hit bit (t.max shrank since the node was tested) only
 // costs a visit.  Irregular rays (a zero / non-finite direction component ...) take the exact binary path.
+#ifndef JTX_WIDE_NODE_G
+#define JTX_WIDE_NODE_G 6         // granules (16 B) from one interior child to the next: 6 = packed, 8 = every node in ONE 128-byte line
+#endif
+constexpr unsigned WIDE_NODE_G = JTX_WIDE_NODE_G;
 #ifndef JTX_WIDE_LEAF_VOTE
 #define JTX_WIDE_LEAF_VOTE 16
 #endif
@@ -274,29 +279,8 @@ struct WideState {
     JD bool walking() const { return pendLeaf < 0 && !done; }
 };
 
-// One interior step of a walking lane: take the next child of the current group (popping the stack when the
-// group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
-// ORDERED = false (anyHit: the answer does not depend on the order): children are taken in slot order.
-template <bool ORDERED>
-JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws) {
-    if ((ws.gbits & 0xffu) == 0u) {                          // group exhausted: pop
-        if (ws.sp == 0) { ws.done = true; return; }
-        --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
-    }
-    const int k = ORDERED ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);   // next position in visiting order (anyHit: leaves first)
-    ws.gbits &= ~(1u << k);
-    const unsigned slot = (ws.gbits >> (8 + 3 * k)) & 7u;
-    const unsigned ni = ws.gbase >> 28, base = ws.gbase & 0x0fffffffu;
-    if (slot >= ni) { ws.pendLeaf = (int) (base + 6u * ni + 2u * (slot - ni)); return; }
-    const unsigned a = base + 6u * slot;
-    if (ws.gbits & 0xffu) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
-    const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
-    const unsigned *tail = (const unsigned *) (wide + a + 4);   // [children base][8 x 24-bit visiting orders][0]
-    const int pbit = 24 * r.negmask;
-    const unsigned cbase = tail[0];
-    unsigned plo = 0u, phi = 0u;
-    if (ORDERED) { plo = tail[1 + (pbit >> 5)]; phi = tail[2 + (pbit >> 5)]; }
-    const f3 o = r.o, inv = r.inv;
+// The 8 child boxes of a wide node against a ray: bit s = slot s may be hit (never misses a box AABB::hit would pass).
+JD unsigned wideNodeHits(const uint4 n0, const uint4 n2, const uint4 n3, const uint4 n4, f3 o, f3 inv, float tmin, float tmax) {
     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
     // per axis: t(q) = q * a + b with a = cell / d (exact: a power-of-two scaling), b = (origin - o) / d,
     // pushed outward by mu >= every rounding difference to AABB::hit on a contained box
@@ -316,16 +300,48 @@ JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, con
     for (int s = 0; s < 8; ++s) {
         const int w = s >> 2, b = s & 3;
         const float t0 = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)),
-                               fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), r.tmin));
+                               fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), tmin));
         const float t1 = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)),
-                               fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), r.tmax));
+                               fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), tmax));
         hits |= (t0 <= t1 ? 1u : 0u) << s;
     }
+    return hits;
+}
+
+// the visiting order of the ray's octant out of a node's tail granule (octant & 3 selects 24 of the 96 bits behind the base)
+JD unsigned wideOrderOf(const uint4 tl, int negmask) {
+    const int q = negmask & 3;
+    const unsigned lo = q < 2 ? tl.y : (q == 2 ? tl.z : tl.w), hi = q < 2 ? tl.z : tl.w;
+    return __funnelshift_r(lo, hi, (24 * q) & 31) & 0x00ffffffu;
+}
+
+// One interior step of a walking lane: take the next child of the current group (popping the stack when the
+// group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
+// ORD = 0 (anyHit: the answer does not depend on the order): children are taken in slot order; 1: the octant's visiting
+// order; 2: per lane, `orderedRt` decides (the ray-queue kernel walks shadow and extension rays in one loop).
+template <int ORD>
+JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws, bool orderedRt = true) {
+    const bool ORDERED = ORD == 2 ? orderedRt : ORD == 1;
+    if ((ws.gbits & 0xffu) == 0u) {                          // group exhausted: pop
+        if (ws.sp == 0) { ws.done = true; return; }
+        --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
+    }
+    const int k = ORDERED ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);   // next position in visiting order (anyHit: leaves first)
+    ws.gbits &= ~(1u << k);
+    const unsigned slot = (ws.gbits >> (8 + 3 * k)) & 7u;
+    const unsigned ni = ws.gbase >> 28, base = ws.gbase & 0x0fffffffu;
+    if (slot >= ni) { ws.pendLeaf = (int) (base + WIDE_NODE_G * ni + 2u * (slot - ni)); return; }
+    const unsigned a = base + WIDE_NODE_G * slot;
+    if (ws.gbits & 0xffu) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
+    const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
+    const uint4 tl = wide[a + 4 + (ORD != 0 ? (r.negmask >> 2) : 0)];   // [children base | the 24-bit visiting orders of 4 octants]
+    const unsigned cbase = tl.x;
+    const unsigned hits = wideNodeHits(n0, n2, n3, n4, r.o, r.inv, r.tmin, r.tmax);
     // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first)
-    const unsigned perm = ORDERED ? (__funnelshift_r(plo, phi, pbit & 31) & 0x00ffffffu) : 0x00fac688u;   // identity: slot k at position k
+    const unsigned perm = ORDERED ? wideOrderOf(tl, r.negmask) : 0x00fac688u;   // identity: slot k at position k
     const unsigned nchild = n0.w >> 28;
     unsigned pend = 0u;
-    if (ORDERED) {
+    if (ORD != 0) {                                           // (the identity list leaves the hits where they are)
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) pend |= ((hits >> ((perm >> (3 * k2)) & 7u)) & 1u) << k2;
     } else pend = hits;
@@ -372,7 +388,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
                 WSTAT(if (ws.pendLeaf >= 0) cnt.w_np++; else if (ws.done) cnt.w_nd++;)
                 if (ws.walking()) {
                     WSTAT(cnt.w_node_steps++; const int leafBefore = ws.pendLeaf; const bool doneBefore = ws.done;)
-                    wideNodeStep<!ANY>(wide, stk, stride, r, ws);
+                    wideNodeStep<ANY ? 0 : 1>(wide, stk, stride, r, ws);
                     WSTAT(if (ws.pendLeaf < 0 && !ws.done) cnt.w_fetch++; (void) leafBefore; (void) doneBefore;)
                 }
             }

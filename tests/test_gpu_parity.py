@@ -784,14 +784,14 @@ def test_wide_bvh_nearly_axis_parallel_rays(gpu, lightdir):
 
 def test_wide_bvh_on_a_deep_degenerate_tree(gpu):
     """triangles of geometrically growing size nested in one corner: the SAH peels a few triangles per level, the
-    binary tree is a chain and the wide tree stays deep (14 levels: a long per-lane LDS stack, fewer workgroups per
+    binary tree is a chain and the wide tree stays deep (14 levels even with the area-optimal cut: a long per-lane LDS stack, fewer workgroups per
     CU); the film still equals the oracle's"""
     sc_ = gpu.scenes
     s = sc_.SceneData("deep")
     s.materials = [sc_.material(sc_.DIFFUSE, (0.7, 0.6, 0.5))]
     v = []
-    for k in range(160):
-        e = np.float32(1.12) ** k * np.float32(0.01)
+    for k in range(320):
+        e = np.float32(1.06) ** k * np.float32(0.01)
         v += [(0, 0, -k * 1e-3), (e, 0, -k * 1e-3), (0, e, -k * 1e-3)]
     v = np.array(v, np.float32)
     nrm = np.tile(np.array([[0, 0, 1]], np.float32), (len(v), 1))

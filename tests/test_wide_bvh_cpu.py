@@ -28,6 +28,9 @@ def slab_q(nd, s, o, inv, tmin, tmax):
     return t0 <= t1
 
 
+NODE_G = 6        # granules from one interior child to the next (WIDE_NODE_G in jtx_scene_dev.hpp: one 128-byte line per node)
+
+
 def decode(w, a):
     """wide node at granule a -> dict (layout: jtx_scene_dev.hpp)"""
     n0, n1, n2, n3, n4, n5 = (w[a + i] for i in range(6))
@@ -36,18 +39,19 @@ def decode(w, a):
     byts = lambda u0, u1: [(int(u0) >> (8 * i)) & 0xff for i in range(4)] + [(int(u1) >> (8 * i)) & 0xff for i in range(4)]
     lo = [byts(n1[0], n1[1]), byts(n1[2], n1[3]), byts(n2[0], n2[1])]
     hi = [byts(n2[2], n2[3]), byts(n3[0], n3[1]), byts(n3[2], n3[3])]
-    bits = 0
-    for i, word in enumerate([n4[1], n4[2], n4[3], n5[0], n5[1], n5[2]]):
-        bits |= int(word) << (32 * i)
     n = int(n0[3]) >> 28
-    order = [[(bits >> (24 * o + 3 * k)) & 7 for k in range(n)] for o in range(8)]
+    assert int(n5[0]) == int(n4[0])                       # the children base stands in both tail granules
+    order = []
+    for half in (n4, n5):                                 # octants 0-3 / 4-7: 4 x 24 bit behind the base
+        bits = int(half[1]) | int(half[2]) << 32 | int(half[3]) << 64
+        order += [[(bits >> (24 * o + 3 * k)) & 7 for k in range(n)] for o in range(4)]
     return dict(origin=origin, cell=cell, base=int(n4[0]), ni=(int(n0[3]) >> 24) & 0xf, n=n, lo=lo, hi=hi, order=order)
 
 
 def child_addr(nd, slot):
     if slot < nd["ni"]:
-        return nd["base"] + 6 * slot, False
-    return nd["base"] + 6 * nd["ni"] + 2 * (slot - nd["ni"]), True
+        return nd["base"] + NODE_G * slot, False
+    return nd["base"] + NODE_G * nd["ni"] + 2 * (slot - nd["ni"]), True
 
 
 def slab(pmin, pmax, o, inv, tmin, tmax):
