@@ -159,6 +159,13 @@ int jtx_mi_bvh_build(const jtx_mi_scene_desc *desc, jtx_mi_bvh_node *nodes_out, 
 int jtx_mi_decode_jpeg(const uint8_t *bytes, int64_t num_bytes, int32_t *width, int32_t *height, int32_t *components,
                        uint8_t *out, int64_t capacity);
 
+/* Host-only: OpenEXR -> RGBA float, rows top to bottom: what TextureImage::load gets from tinyexr's LoadEXR /
+ * LoadEXRFromMemory (image.cpp:63-66, 81-95, 108-121; channels R, G, B, optional A else 1.0; a single channel goes to all
+ * four outputs).  Single-part scan-line files, compression NONE / RLE / ZIPS / ZIP (the reference's maps are ZIP), HALF /
+ * FLOAT / UINT samples; tiled, deep, multi-part files and PIZ / lossy blocks are refused.  rgba_out == NULL: only width /
+ * height are filled in; capacity counts floats.  No GPU needed. */
+int jtx_mi_decode_exr(const uint8_t *bytes, int64_t num_bytes, int32_t *width, int32_t *height, float *rgba_out, int64_t capacity);
+
 /* Host-only: the 8-ary quantised node set the uncounted kernels walk for HBM-resident scenes, derived from the
  * flat nodes of jtx_mi_bvh_build (layout: DESIGN.md "Data layout", 16-byte granules = 4 uint32 each; 0 granules
  * when the tree is a single leaf or cannot be quantised).  granules_out may be NULL to query the size.  No GPU needed. */

@@ -1,0 +1,295 @@
+// jtx_exr.cpp -- host-side OpenEXR reader for textures: what TextureImage::load gets from tinyexr's LoadEXR /
+// LoadEXRFromMemory (image.cpp:63-66, 81-95, 108-121): one RGBA float image, rows top to bottom.
+//
+// Scope = what the reference's assets use and a little more: single-part SCANLINE files, compression NONE / RLE / ZIPS /
+// ZIP (all eleven maps under assets/scenes/shaderball/maps are ZIP, three HALF channels B, G, R), HALF / FLOAT / UINT
+// channels, any data window, either line order (decreasing-Y files upside down, as tinyexr returns them).  Tiled, deep, multi-part files and PIZ / PXR24 / B44 / DWA blocks are
+// refused with a message.  The channel mapping is tinyexr's (tinyexr.h:6638-6794): channels named R, G, B (A optional,
+// 1.0 when absent); a single channel of any name is copied to all FOUR outputs.  HALF -> float is tinyexr's
+// half_to_float (an exact conversion; NaN payloads shifted up by 13 bits), UINT -> float a plain conversion.
+// The zlib inflate below is a plain RFC 1950 / 1951 decoder written for this file.
+#include "../../include/jtx_mi.h"
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+int jtx_capi_fail(const std::string &msg);           // jtx_capi.hip: sets the thread's error text, returns 1
+
+namespace {
+
+struct Fail { std::string msg; };
+[[noreturn]] void fail(const std::string &m) { throw Fail{m}; }
+
+// ---- inflate (RFC 1951) inside a zlib stream (RFC 1950) ----
+struct BitReader {
+    const uint8_t *p, *end;
+    uint64_t acc = 0; int n = 0;
+    void need(int k) { while (n < k) { const uint64_t b = p < end ? *p++ : 0u; acc |= b << n; n += 8; } }
+    unsigned bits(int k) { if (k == 0) return 0u; need(k); const unsigned v = (unsigned) (acc & ((1ull << k) - 1)); acc >>= k; n -= k; return v; }
+    void alignByte() { const int r = n & 7; acc >>= r; n -= r; }
+};
+
+struct Huff {
+    uint16_t count[16] = {}, symbol[320] = {};
+    void build(const uint8_t *lens, int num) {
+        std::memset(count, 0, sizeof count);
+        for (int i = 0; i < num; ++i) count[lens[i]]++;
+        count[0] = 0;
+        uint16_t offs[16]; offs[1] = 0;
+        for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t) (offs[l] + count[l]);
+        for (int i = 0; i < num; ++i) if (lens[i]) symbol[offs[lens[i]]++] = (uint16_t) i;
+    }
+    int decode(BitReader &br) const {                     // canonical code, one bit at a time (blocks are small)
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l <= 15; ++l) {
+            code |= (int) br.bits(1);
+            const int c = count[l];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        fail("EXR: bad Huffman code in a zlib block");
+    }
+};
+
+void inflateZlib(const uint8_t *src, size_t srcLen, uint8_t *dst, size_t dstLen) {
+    if (srcLen < 6) fail("EXR: zlib block too short");
+    if ((src[0] & 0x0f) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) fail("EXR: not a zlib stream");
+    BitReader br{src + 2, src + srcLen};
+    size_t out = 0;
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    bool last = false;
+    while (!last) {
+        last = br.bits(1) != 0;
+        const unsigned type = br.bits(2);
+        if (type == 0) {
+            br.alignByte();
+            const unsigned len = br.bits(16), nlen = br.bits(16);
+            if ((len ^ nlen) != 0xffffu) fail("EXR: bad stored block");
+            if (out + len > dstLen) fail("EXR: zlib block longer than the scan lines it holds");
+            for (unsigned i = 0; i < len; ++i) dst[out++] = (uint8_t) br.bits(8);
+            continue;
+        }
+        if (type == 3) fail("EXR: bad zlib block type");
+        Huff lit, dist;
+        if (type == 1) {
+            uint8_t l[288];
+            for (int i = 0; i < 144; ++i) l[i] = 8;
+            for (int i = 144; i < 256; ++i) l[i] = 9;
+            for (int i = 256; i < 280; ++i) l[i] = 7;
+            for (int i = 280; i < 288; ++i) l[i] = 8;
+            lit.build(l, 288);
+            uint8_t d[30]; for (int i = 0; i < 30; ++i) d[i] = 5;
+            dist.build(d, 30);
+        } else {
+            const int hlit = (int) br.bits(5) + 257, hdist = (int) br.bits(5) + 1, hclen = (int) br.bits(4) + 4;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {};
+            for (int i = 0; i < hclen; ++i) cl[order[i]] = (uint8_t) br.bits(3);
+            Huff clh; clh.build(cl, 19);
+            uint8_t lens[320] = {};
+            int i = 0;
+            while (i < hlit + hdist) {
+                const int sym = clh.decode(br);
+                if (sym < 16) lens[i++] = (uint8_t) sym;
+                else {
+                    int rep; uint8_t v = 0;
+                    if (sym == 16) { if (i == 0) fail("EXR: bad code-length repeat"); v = lens[i - 1]; rep = 3 + (int) br.bits(2); }
+                    else if (sym == 17) rep = 3 + (int) br.bits(3);
+                    else rep = 11 + (int) br.bits(7);
+                    if (i + rep > hlit + hdist) fail("EXR: code lengths overrun");
+                    while (rep--) lens[i++] = v;
+                }
+            }
+            if (hlit > 286 || hdist > 30) fail("EXR: too many Huffman codes");
+            lit.build(lens, hlit); dist.build(lens + hlit, hdist);
+        }
+        while (true) {
+            const int sym = lit.decode(br);
+            if (sym < 256) { if (out >= dstLen) fail("EXR: zlib block longer than the scan lines it holds"); dst[out++] = (uint8_t) sym; continue; }
+            if (sym == 256) break;
+            if (sym > 285) fail("EXR: bad length symbol");
+            const unsigned len = lbase[sym - 257] + br.bits(lext[sym - 257]);
+            const int ds = dist.decode(br);
+            if (ds > 29) fail("EXR: bad distance symbol");
+            const size_t d = dbase[ds] + br.bits(dext[ds]);
+            if (d > out) fail("EXR: distance beyond the start of the block");
+            if (out + len > dstLen) fail("EXR: zlib block longer than the scan lines it holds");
+            for (unsigned k = 0; k < len; ++k, ++out) dst[out] = dst[out - d];
+        }
+    }
+    if (out != dstLen) fail("EXR: zlib block shorter than the scan lines it holds");
+}
+
+// OpenEXR's byte predictor + interleave, undone (tinyexr.h:1536-1570, from ImfZipCompressor.cpp)
+void unpredict(std::vector<uint8_t> &tmp, uint8_t *dst) {
+    const size_t n = tmp.size();
+    for (size_t i = 1; i < n; ++i) tmp[i] = (uint8_t) ((int) tmp[i - 1] + (int) tmp[i] - 128);
+    const uint8_t *t1 = tmp.data(), *t2 = tmp.data() + (n + 1) / 2;
+    size_t s = 0;
+    while (true) {
+        if (s < n) dst[s++] = *t1++; else break;
+        if (s < n) dst[s++] = *t2++; else break;
+    }
+}
+
+void unRle(const uint8_t *src, size_t srcLen, std::vector<uint8_t> &out) {      // ImfRle.cpp: count < 0 -> literal run
+    size_t o = 0, i = 0;
+    while (i < srcLen) {
+        const int c = (int8_t) src[i++];
+        if (c < 0) { const size_t n = (size_t) -c; if (i + n > srcLen || o + n > out.size()) fail("EXR: bad RLE run"); std::memcpy(&out[o], src + i, n); o += n; i += n; }
+        else { const size_t n = (size_t) c + 1; if (i >= srcLen || o + n > out.size()) fail("EXR: bad RLE run"); std::memset(&out[o], src[i++], n); o += n; }
+    }
+    if (o != out.size()) fail("EXR: RLE block shorter than the scan lines it holds");
+}
+
+float halfToFloat(uint16_t h) {                            // tinyexr.h half_to_float
+    uint32_t o = (uint32_t) (h & 0x7fffu) << 13;
+    const uint32_t shiftedExp = 0x7c00u << 13, e = shiftedExp & o;
+    o += (127u - 15u) << 23;
+    if (e == shiftedExp) o += (128u - 16u) << 23;          // Inf / NaN
+    else if (e == 0) {                                     // zero / denormal: renormalise
+        o += 1u << 23;
+        float f; std::memcpy(&f, &o, 4);
+        const uint32_t mu = 113u << 23; float magic; std::memcpy(&magic, &mu, 4);
+        f -= magic;
+        std::memcpy(&o, &f, 4);
+    }
+    o |= (uint32_t) (h & 0x8000u) << 16;
+    float r; std::memcpy(&r, &o, 4);
+    return r;
+}
+
+struct Channel { std::string name; int type; int xs, ys; };
+
+uint32_t rd32(const uint8_t *p) { return (uint32_t) p[0] | (uint32_t) p[1] << 8 | (uint32_t) p[2] << 16 | (uint32_t) p[3] << 24; }
+uint64_t rd64(const uint8_t *p) { return (uint64_t) rd32(p) | (uint64_t) rd32(p + 4) << 32; }
+
+void decodeExr(const uint8_t *b, size_t n, int32_t *width, int32_t *height, float *out, int64_t capacity) {
+    if (n < 8 || rd32(b) != 20000630u) fail("EXR: bad magic number");
+    const uint32_t ver = rd32(b + 4);
+    if ((ver & 0xffu) != 2) fail("EXR: unsupported file version");
+    if (ver & 0x200u) fail("EXR: tiled files are not supported");
+    if (ver & 0x800u) fail("EXR: deep data is not supported");
+    if (ver & 0x1000u) fail("EXR: multi-part files are not supported");
+    size_t p = 8;
+    std::vector<Channel> ch;
+    int comp = -1, lineOrder = 0;
+    int32_t dw[4] = {0, 0, -1, -1};
+    bool haveDw = false;
+    auto cstr = [&](size_t &q) { const size_t s = q; while (q < n && b[q]) ++q; if (q >= n) fail("EXR: header runs past the end"); std::string r((const char *) b + s, q - s); ++q; return r; };
+    while (true) {
+        if (p >= n) fail("EXR: header runs past the end");
+        if (b[p] == 0) { ++p; break; }
+        const std::string name = cstr(p), type = cstr(p);
+        if (p + 4 > n) fail("EXR: header runs past the end");
+        const uint32_t sz = rd32(b + p); p += 4;
+        if (sz > n - p) fail("EXR: attribute runs past the end");
+        const uint8_t *a = b + p;
+        if (name == "channels") {
+            size_t q = p;
+            while (q < p + sz && b[q]) {
+                Channel c; c.name = cstr(q);
+                if (q + 16 > p + sz) fail("EXR: bad channel list");
+                c.type = (int) rd32(b + q); c.xs = (int) rd32(b + q + 8); c.ys = (int) rd32(b + q + 12); q += 16;
+                ch.push_back(c);
+            }
+        } else if (name == "compression") { if (sz < 1) fail("EXR: bad compression attribute"); comp = a[0]; }
+        else if (name == "dataWindow") { if (sz < 16) fail("EXR: bad dataWindow"); for (int i = 0; i < 4; ++i) dw[i] = (int32_t) rd32(a + 4 * i); haveDw = true; }
+        else if (name == "lineOrder") { if (sz < 1) fail("EXR: bad lineOrder"); lineOrder = a[0]; }
+        p += sz;
+    }
+    // rows are placed by the y every block carries -- and, as tinyexr does it (tinyexr.h:3868-3892: row height - 1 - y for any
+    // lineOrder != 0), a DECREASING_Y file comes out upside down: a quirk of the reference's reader, reproduced
+    if (!haveDw || ch.empty() || comp < 0) fail("EXR: header lacks channels / compression / dataWindow");
+    if (dw[2] < dw[0] || dw[3] < dw[1]) fail("EXR: empty data window");
+    const int64_t W = (int64_t) dw[2] - dw[0] + 1, H = (int64_t) dw[3] - dw[1] + 1;
+    if (W > 65536 || H > 65536) fail("EXR: image too large");
+    int linesPerBlock;
+    if (comp == 0 || comp == 1 || comp == 2) linesPerBlock = 1;
+    else if (comp == 3) linesPerBlock = 16;
+    else fail(comp == 4 ? "EXR: PIZ compression is not supported" : "EXR: this compression is not supported (NONE, RLE, ZIPS, ZIP are)");
+    size_t rowBytes = 0;
+    std::vector<size_t> chOff(ch.size());
+    for (size_t c = 0; c < ch.size(); ++c) {
+        if (ch[c].xs != 1 || ch[c].ys != 1) fail("EXR: sub-sampled channels are not supported");
+        if (ch[c].type < 0 || ch[c].type > 2) fail("EXR: bad pixel type");
+        chOff[c] = rowBytes;
+        rowBytes += (size_t) W * (ch[c].type == 1 ? 2 : 4);
+    }
+    *width = (int32_t) W; *height = (int32_t) H;
+    if (!out) return;
+    if (capacity < 4 * W * H) fail("EXR: output buffer too small");
+    int iR = -1, iG = -1, iB = -1, iA = -1;                 // tinyexr.h:6638-6653
+    for (size_t c = 0; c < ch.size(); ++c) {
+        if (ch[c].name == "R") iR = (int) c; else if (ch[c].name == "G") iG = (int) c;
+        else if (ch[c].name == "B") iB = (int) c; else if (ch[c].name == "A") iA = (int) c;
+    }
+    const bool grey = ch.size() == 1;
+    if (!grey) { if (iR < 0) fail("R channel not found"); if (iG < 0) fail("G channel not found"); if (iB < 0) fail("B channel not found"); }
+    const int64_t nblocks = (H + linesPerBlock - 1) / linesPerBlock;
+    if (p + 8 * (size_t) nblocks > n) fail("EXR: offset table runs past the end");
+    const size_t table = p;
+    std::vector<uint8_t> raw, tmp;
+    std::vector<char> rowSeen((size_t) H, 0);
+    auto sample = [&](const uint8_t *row, int c, int64_t x) -> float {
+        const uint8_t *q = row + chOff[c];
+        if (ch[c].type == 1) return halfToFloat((uint16_t) (q[2 * x] | q[2 * x + 1] << 8));
+        const uint32_t u = rd32(q + 4 * x);
+        if (ch[c].type == 2) { float f; std::memcpy(&f, &u, 4); return f; }
+        return (float) u;
+    };
+    for (int64_t blk = 0; blk < nblocks; ++blk) {
+        const uint64_t off = rd64(b + table + 8 * (size_t) blk);
+        if (off + 8 > n) fail("EXR: block offset past the end");
+        const int32_t y0 = (int32_t) rd32(b + off);
+        const uint32_t dsz = rd32(b + off + 4);
+        if (dsz > n - off - 8) fail("EXR: block runs past the end");
+        const int64_t r0 = (int64_t) y0 - dw[1];
+        if (r0 < 0 || r0 >= H) fail("EXR: block outside the data window");
+        const int64_t lines = r0 + linesPerBlock <= H ? linesPerBlock : H - r0;
+        const size_t want = rowBytes * (size_t) lines;
+        const uint8_t *src = b + off + 8;
+        raw.resize(want);
+        if (comp == 0) { if (dsz != want) fail("EXR: uncompressed block of the wrong size"); std::memcpy(raw.data(), src, want); }
+        else if (dsz == want) std::memcpy(raw.data(), src, want);                 // stored as is (tinyexr.h:1494-1498)
+        else {
+            tmp.resize(want);
+            if (comp == 1) unRle(src, dsz, tmp); else inflateZlib(src, dsz, tmp.data(), want);
+            unpredict(tmp, raw.data());
+        }
+        for (int64_t l = 0; l < lines; ++l) {
+            const uint8_t *row = raw.data() + rowBytes * (size_t) l;
+            const int64_t rowOut = lineOrder == 0 ? r0 + l : H - 1 - (r0 + l);
+            float *o = out + 4 * W * rowOut;
+            rowSeen[(size_t) (r0 + l)] = 1;
+            for (int64_t x = 0; x < W; ++x) {
+                if (grey) { const float v = sample(row, 0, x); o[4 * x] = v; o[4 * x + 1] = v; o[4 * x + 2] = v; o[4 * x + 3] = v; }
+                else {
+                    o[4 * x] = sample(row, iR, x); o[4 * x + 1] = sample(row, iG, x); o[4 * x + 2] = sample(row, iB, x);
+                    o[4 * x + 3] = iA >= 0 ? sample(row, iA, x) : 1.0f;
+                }
+            }
+        }
+    }
+    for (int64_t y = 0; y < H; ++y) if (!rowSeen[(size_t) y]) fail("EXR: a scan line is missing");
+}
+
+} // namespace
+
+extern "C" int jtx_mi_decode_exr(const uint8_t *bytes, int64_t num_bytes, int32_t *width, int32_t *height, float *rgba_out, int64_t capacity) {
+    if (!bytes || num_bytes <= 0 || !width || !height) return jtx_capi_fail("jtx_mi_decode_exr: null argument");
+    try {
+        decodeExr(bytes, (size_t) num_bytes, width, height, rgba_out, capacity);
+        return 0;
+    } catch (const Fail &f) {
+        return jtx_capi_fail(f.msg);
+    } catch (const std::exception &e) {
+        return jtx_capi_fail(e.what());
+    }
+}

@@ -280,7 +280,7 @@ __device__ __attribute__((noinline)) QTraceOut queueTrace(const uint4 *wide_, co
                     const unsigned perm = ordered ? wideOrderOf(tl, w.negmask) : 0x00fac688u;
                     unsigned pend = 0u;
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; ++k2) pend |= ((hits >> ((perm >> (3 * k2)) & 7u)) & 1u) << k2;
+                    for (int k2 = 0; k2 < 8; ++k2) pend |= wideBit(hits, wideField3(perm, 3 * k2)) << k2;
                     pend &= (1u << (n0.w >> 28)) - 1u;
                     w.gbase = cbase | (((n0.w >> 24) & 0xfu) << 28);
                     w.gbits = pend | (perm << 8);

@@ -308,6 +308,13 @@ JD unsigned wideNodeHits(const uint4 n0, const uint4 n2, const uint4 n3, const u
     return hits;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+JD unsigned wideField3(unsigned v, int at) { return __builtin_amdgcn_ubfe(v, (unsigned) at, 3u); }
+JD unsigned wideBit(unsigned v, unsigned at) { return __builtin_amdgcn_ubfe(v, at, 1u); }
+#else
+JD unsigned wideField3(unsigned v, int at) { return (v >> at) & 7u; }
+JD unsigned wideBit(unsigned v, unsigned at) { return (v >> at) & 1u; }
+#endif
 // the visiting order of the ray's octant out of a node's tail granule (octant & 3 selects 24 of the 96 bits behind the base)
 JD unsigned wideOrderOf(const uint4 tl, int negmask) {
     const int q = negmask & 3;
@@ -343,7 +350,7 @@ JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, con
     unsigned pend = 0u;
     if (ORD != 0) {                                           // (the identity list leaves the hits where they are)
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) pend |= ((hits >> ((perm >> (3 * k2)) & 7u)) & 1u) << k2;
+        for (int k2 = 0; k2 < 8; ++k2) pend |= wideBit(hits, wideField3(perm, 3 * k2)) << k2;     // 2 v_bfe_u32 + v_lshl_or_b32 per position
     } else pend = hits;
     pend &= (1u << nchild) - 1u;
     ws.gbase = cbase | (((n0.w >> 24) & 0xfu) << 28);

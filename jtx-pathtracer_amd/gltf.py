@@ -133,6 +133,100 @@ def decode_jpeg(data):
     return out
 
 
+def decode_exr(data):
+    """OpenEXR bytes -> float32 (H, W, 4), rows top to bottom: what TextureImage::load gets from tinyexr (jtx_mi_decode_exr)."""
+    import ctypes as C
+    from . import _capi as capi
+    lib = capi.load()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    w, h = C.c_int32(), C.c_int32()
+    capi.check(lib.jtx_mi_decode_exr(buf, len(data), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 4), np.float32)
+    capi.check(lib.jtx_mi_decode_exr(buf, len(data), C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+    return out
+
+
+def load_texture_file(path):
+    """TextureImage::load(path) (image.cpp:59-74): .exr through tinyexr -> (H, W, 4) floats as stored; anything else through
+    stbi_loadf -> (H, W, C) floats, 8-bit samples raised to 2.2 (PNG and JPEG here).  None when the file cannot be read."""
+    try:
+        data = open(path, "rb").read()
+        ext = path.rsplit(".", 1)[-1]
+        if ext in ("exr", "EXR"):
+            return decode_exr(data)
+        if data[:8] == b"\x89PNG\r\n\x1a\n":
+            return ldr_to_float(decode_png(data))
+        if data[:2] == b"\xff\xd8":
+            return ldr_to_float(decode_jpeg(data))
+    except Exception:
+        return None
+    return None
+
+
+def encode_exr(img, compression="zip", half=True, names=None, line_order=0, origin=(0, 0)):
+    """float32 (H, W, C) -> scan-line OpenEXR bytes (test writer: NONE / RLE / ZIPS / ZIP, HALF or FLOAT channels stored
+    in alphabetical order as the format asks; names default to B G R [A] / Y)."""
+    import struct, zlib
+    img = np.ascontiguousarray(img, np.float32)
+    h, w, c = img.shape
+    names = names or {1: ["Y"], 3: ["R", "G", "B"], 4: ["R", "G", "B", "A"]}[c]
+    order = sorted(range(c), key=lambda i: names[i])
+    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3}[compression]
+    lines = 16 if comp == 3 else 1
+    x0, y0 = origin
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(payload)) + payload
+    chl = b"".join(names[i].encode() + b"\0" + struct.pack("<iB3xii", 1 if half else 2, 0, 1, 1) for i in order) + b"\0"
+    box = struct.pack("<4i", x0, y0, x0 + w - 1, y0 + h - 1)
+    hdr = (b"\x76\x2f\x31\x01" + struct.pack("<I", 2) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([comp])) +
+           attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", bytes([line_order])) +
+           attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) +
+           attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    blocks = []
+    for r0 in range(0, h, lines):
+        rows = img[r0:r0 + lines]
+        raw = b"".join((rows[l, :, i].astype(np.float16) if half else rows[l, :, i]).tobytes() for l in range(rows.shape[0]) for i in order)
+        if comp == 0:
+            data = raw
+        else:
+            a = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+            t[1:] = (t[1:] - t[:-1] + 128 + 256) & 255
+            t = t.astype(np.uint8).tobytes()
+            if comp == 1:
+                out = bytearray(); i = 0
+                while i < len(t):                       # ImfRle.cpp: runs of 3+ equal bytes, else literals
+                    j = i
+                    while j + 1 < len(t) and t[j + 1] == t[i] and j - i < 126:
+                        j += 1
+                    if j - i >= 2:
+                        out += bytes([j - i, t[i]]); i = j + 1
+                    else:
+                        k = i
+                        while k < len(t) and k - i < 127 and not (k + 2 < len(t) and t[k] == t[k + 1] == t[k + 2]):
+                            k += 1
+                        out += bytes([(256 - (k - i)) & 255]) + t[i:k]; i = k
+                data = bytes(out)
+            else:
+                data = zlib.compress(t, 6)
+            if len(data) >= len(raw):
+                data = raw
+        blocks.append((y0 + r0, data))
+    if line_order == 1:
+        blocks = blocks[::-1]
+    table_at = len(hdr)
+    pos = table_at + 8 * len(blocks)
+    offs = {}
+    body = b""
+    for y, data in blocks:
+        offs[y] = pos
+        body += struct.pack("<iI", y, len(data)) + data
+        pos += 8 + len(data)
+    table = b"".join(struct.pack("<Q", offs[y0 + r0]) for r0 in range(0, h, lines))
+    return hdr + table + body
+
+
 def encode_png(img):
     """uint8 (H, W, C) -> PNG bytes (filter 0, C in 1..4)."""
     img = np.ascontiguousarray(img, np.uint8)

@@ -482,9 +482,43 @@ def load_obj(path, default_material=None, materials_by_name=None):
     PreTransformVertices with identity.  One mesh per `o` / `g` group and material (Assimp splits meshes
     by material); one Triangle ref per face (loader.cpp:216-222).  `materials_by_name` maps usemtl /
     object names to material dicts; everything else gets `default_material` (white Lambert 0.73).
-    Textures referenced by an .mtl are not decoded here (no image codec in this package)."""
+    A `mtllib`'s `map_Kd` becomes the material's albedo texture, read as TextureImage::load reads it (loader.cpp:64-101, 114:
+    .exr through the EXR reader, PNG / JPEG through the stb restatements; a file that cannot be read leaves the id at -1);
+    such a material is otherwise a copy of `default_material` (the reference's is DIFFUSE white, loader.cpp:139-144)."""
+    import os
     default_material = default_material or material(DIFFUSE, (0.73, 0.73, 0.73))
-    materials_by_name = materials_by_name or {}
+    materials_by_name = dict(materials_by_name or {})
+    base = os.path.dirname(path)
+    mtl_maps = {}                     # material name -> map_Kd path
+    with open(path) as f:
+        libs = [ln.split(None, 1)[1].strip() for ln in f if ln.startswith("mtllib") and len(ln.split()) > 1]
+    for lib in libs:
+        try:
+            with open(os.path.join(base, lib)) as f:
+                name = None
+                for ln in f:
+                    t = ln.split()
+                    if len(t) >= 2 and t[0] == "newmtl":
+                        name = t[1]
+                    elif len(t) >= 2 and t[0] == "map_Kd" and name is not None:
+                        mtl_maps[name] = t[-1]
+        except OSError:
+            pass
+    tex_files, tex_store = {}, []
+    for name, rel in mtl_maps.items():
+        if name in materials_by_name:
+            continue
+        full = os.path.join(base, rel)
+        if full not in tex_files:
+            from . import gltf
+            px = gltf.load_texture_file(full)
+            tex_files[full] = -1
+            if px is not None and px.shape[-1] >= 3:
+                tex_store.append(px)
+                tex_files[full] = len(tex_store) - 1
+        m = dict(default_material)
+        m["albedo_tex"] = tex_files[full]
+        materials_by_name[name] = m
     V, VN, VT = [], [], []
     groups = []                       # (name, mtl, [face corners [(v, vt, vn), ...]])
     cur = None
@@ -525,6 +559,7 @@ def load_obj(path, default_material=None, materials_by_name=None):
                 for k in range(1, len(corners) - 1):            # triangle fan
                     cur[2].append((corners[0], corners[k], corners[k + 1]))
     scene = SceneData(path.rsplit("/", 1)[-1])
+    scene.textures = tex_store
     mat_index = {}
 
     def mat_id(name, mtl):
