@@ -361,8 +361,35 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
 void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     const jtxh::BvhResult &b = s.bvh;
     const size_t nn = b.nodes.size(), np = b.refs.size();
+    static const bool traceCreate = getenv("JTX_TRACE_CREATE") != nullptr;    // where scene creation spends its time (stderr)
+    auto lapT = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!traceCreate) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[jtx create] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - lapT).count());
+        lapT = n;
+    };
+    // the 8-ary node set depends on the binary nodes only: its thread starts first and runs beside everything below
+    std::vector<int32_t> wideMap;
+    std::vector<uint4> wide; int wideDepth = 0; bool wideOk = false;
+    std::exception_ptr err = nullptr; std::mutex errMu;
+    auto guarded = [&](auto fn) { return [&, fn] { try { fn(); } catch (...) { std::lock_guard<std::mutex> g(errMu); err = std::current_exception(); } }; };
+    const char *off = getenv("JTX_NO_WIDE");
+    const bool wantWide = nn && !(off && atoi(off));
+    std::thread wideThread;
+    if (wantWide) wideThread = std::thread(guarded([&] { wideOk = buildWide(b.nodes, wide, wideDepth, &wideMap) && wideDepth <= kMaxWideDepth; }));
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } wideJoin{wideThread};   // also on a throw below
+    // per-primitive loops: split over host threads (each index writes its own records)
+    auto forPrims = [&](auto body) {
+        int nt = (int) std::thread::hardware_concurrency(); if (nt > 16) nt = 16; if (nt < 1 || np < 8192) nt = 1;
+        std::vector<std::thread> ts;
+        for (int t = 1; t < nt; ++t) ts.emplace_back(guarded([&, t] { for (size_t i = np * t / nt; i < np * (t + 1) / nt; ++i) body(i); }));
+        for (size_t i = 0; i < np / nt; ++i) body(i);
+        for (auto &t : ts) t.join();
+        if (err) std::rethrow_exception(err);
+    };
     std::vector<float4> tris(3 * np), shade(4 * np);
-    for (size_t i = 0; i < np; ++i) {
+    forPrims([&](size_t i) {
         const jtx_mi_mesh &m = d.meshes[b.refs[i].mesh_index];
         const int tri = b.refs[i].index;
         float v0[3], v1[3], v2[3];
@@ -385,12 +412,14 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         shade[4 * i + 1] = make_float4(n1[1], n1[2], n2[0], n2[1]);
         shade[4 * i + 2] = make_float4(n2[2], uv[0], uv[1], uv[2]);
         shade[4 * i + 3] = make_float4(uv[3], uv[4], uv[5], fmat);
-    }
+    });
+    lap("triangle + shading records");
     s.tris.upload(tris); s.shade.upload(shade);
+    lap("  upload");
     // ---- refit sources: object-space vertices / normals per BVH-ordered primitive, the mesh transforms, node lists ----
     {
         std::vector<float4> src(5 * np);
-        for (size_t i = 0; i < np; ++i) {
+        forPrims([&](size_t i) {
             const jtx_mi_mesh &m = d.meshes[b.refs[i].mesh_index];
             const int32_t *ix = m.indices + 3 * (size_t) b.refs[i].index;
             const float *p0 = m.vertices + 3 * (size_t) ix[0], *p1 = m.vertices + 3 * (size_t) ix[1], *p2 = m.vertices + 3 * (size_t) ix[2];
@@ -401,7 +430,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
             src[5 * i + 2] = make_float4(p2[2], q0[0], q0[1], q0[2]);
             src[5 * i + 3] = make_float4(q1[0], q1[1], q1[2], q2[0]);
             src[5 * i + 4] = make_float4(q2[1], q2[2], fm, 0.f);
-        }
+        });
         s.prim_src.upload(src);
         s.pbox.alloc(2 * np);
         s.mesh_xf_host.assign((size_t) 16 * d.num_meshes, 0.f);
@@ -428,67 +457,52 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         s.nbox.upload(nb); s.leaf_nodes.upload(leaves); s.level_nodes.upload(lv);
         s.num_leaves = (int) leaves.size();
     }
+    lap("refit sources + upload");
 
     // ---- threaded node records: one near-first depth-first ordering per direction-sign octant ----
     // (layout and rationale: traverseThreaded in jtx_scene_dev.hpp).  The 8 orderings are independent of each other and of
     // the wide-node build: one host thread each.
-    std::vector<float4> tn(2 * 8 * nn);
-    std::vector<int> recNode(8 * nn);
-    std::vector<int32_t> wideMap;
-    std::vector<uint4> wide; int wideDepth = 0; bool wideOk = false;
+    std::vector<int> pos(8 * nn);                                   // pos[k * nn + g]: node g's place in octant k's order
     {
         std::vector<int> size(nn, 1);                               // subtree sizes (children follow their parent in b.nodes)
         for (size_t i = nn; i-- > 0;)
             if (b.nodes[i].num_prims == 0) size[i] = 1 + size[i + 1] + size[b.nodes[i].offset];
-        auto ordering = [&](int k) {
-            // near-first DFS: dirIsNeg[axis] ? (second, first) : (first, second)   (scene.cpp:40-46)
-            std::vector<int> order(nn);
-            std::vector<int> st{0}; size_t pos = 0;
-            while (!st.empty()) {
-                const int g = st.back(); st.pop_back();
-                order[pos++] = g;
+        // position of every node in octant k's near-first depth-first order, top-down in index order (a parent stands before
+        // its children in b.nodes): the near child follows its parent, the far child follows the near subtree
+        // (dirIsNeg[axis] ? (second, first) : (first, second), scene.cpp:40-46); the records themselves are written on the
+        // device (k_build_threaded) from s.nbox, these positions and the sizes
+        auto positions = [&](int k) {
+            int *p = pos.data() + (size_t) k * nn;
+            if (nn) p[0] = 0;
+            for (size_t g = 0; g < nn; ++g) {
                 const jtx_mi_bvh_node &n = b.nodes[g];
-                if (n.num_prims == 0) {
-                    const int first = g + 1, second = n.offset;
-                    const bool neg = (k >> n.axis) & 1;
-                    st.push_back(neg ? first : second);                // far child: visited after the near subtree
-                    st.push_back(neg ? second : first);
-                }
-            }
-            for (size_t i = 0; i < nn; ++i) {
-                const jtx_mi_bvh_node &n = b.nodes[order[i]];
-                int z, w;
-                if (n.num_prims == 0) {
-                    const size_t behind = i + (size_t) size[order[i]];
-                    z = behind < nn ? (int) ((size_t) k * nn + behind) : -1;
-                    w = 0;
-                } else {
-                    z = n.offset;
-                    w = (int) n.num_prims | (i + 1 == nn ? (int) 0x80000000u : 0);
-                }
-                float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
-                const size_t r = (size_t) k * nn + i;
-                recNode[r] = order[i];
-                tn[2 * r + 0] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
-                tn[2 * r + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+                if (n.num_prims != 0) continue;
+                const int first = (int) g + 1, second = n.offset;
+                const bool neg = (k >> n.axis) & 1;
+                const int near = neg ? second : first, far = neg ? first : second;
+                p[near] = p[g] + 1;
+                p[far] = p[g] + 1 + size[near];
             }
         };
-        const char *off = getenv("JTX_NO_WIDE");
-        const bool wantWide = !(off && atoi(off));
-        std::vector<std::thread> pool;
-        std::exception_ptr err = nullptr; std::mutex errMu;
-        auto guarded = [&](auto fn) { return [&, fn] { try { fn(); } catch (...) { std::lock_guard<std::mutex> g(errMu); err = std::current_exception(); } }; };
-        if (nn) {
-            if (wantWide) pool.emplace_back(guarded([&] { wideOk = buildWide(b.nodes, wide, wideDepth, &wideMap) && wideDepth <= kMaxWideDepth; }));
-            for (int k = 1; k < 8; ++k) pool.emplace_back(guarded([&, k] { ordering(k); }));
-            ordering(0);
+        {
+            std::vector<std::thread> pool;
+            for (int k = 1; k < 8; ++k) pool.emplace_back(guarded([&, k] { positions(k); }));
+            positions(0);
+            for (auto &t : pool) t.join();
         }
-        for (auto &t : pool) t.join();
+        if (err) std::rethrow_exception(err);
+        lap("positions in the 8 orderings");
+        DevBuf<int> dpos, dsize;
+        dpos.upload(pos); dsize.upload(size);
+        s.tnodes.alloc(2 * 8 * nn); s.rec_node.alloc(8 * nn);
+        HIPCHK(jtx_launch_build_threaded(s.nbox.p, dpos.p, dsize.p, (int) nn, s.tnodes.p, s.rec_node.p, nullptr));
+        HIPCHK(hipStreamSynchronize(nullptr));
+        lap("8 threaded orderings");
+        if (wideThread.joinable()) wideThread.join();
+        lap("wait for the wide nodes");
         if (err) std::rethrow_exception(err);
     }
-    s.tnodes.upload(tn);
     s.dev.tnodes = s.tnodes.p;
-    s.rec_node.upload(recNode);
     // ---- tiny scenes: the flat leaf list of traverseLeaves (leaves in b.nodes order; per octant: leaf at position p,
     //      position of leaf l -- read off the threaded orderings) ----
     s.lw_box.release(); s.lw_tab.release(); s.dev.lw_box = nullptr; s.dev.lw_tab = nullptr; s.dev.lw_leaves = 0;
@@ -506,9 +520,11 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
             }
             std::vector<unsigned> tab(128, 0u);
             for (int k = 0; k < 8; ++k) {
+                std::vector<int> at(nn, -1);                                    // node standing at position i of octant k's order
+                for (size_t g = 0; g < nn; ++g) at[(size_t) pos[(size_t) k * nn + g]] = (int) g;
                 int p2 = 0;
                 for (size_t i = 0; i < nn; ++i) {
-                    const int l = leafId[recNode[(size_t) k * nn + i]];
+                    const int l = leafId[at[i]];
                     if (l < 0) continue;
                     tab[16 * k + (p2 >> 2)] |= (unsigned) l << (8 * (p2 & 3));                    // leaf visited at position p2
                     tab[16 * k + 8 + (l >> 2)] |= (unsigned) p2 << (8 * (l & 3));                 // position of leaf l
@@ -580,6 +596,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     ds.material_mask = 0;
     for (int i = 0; i < d.num_materials; ++i) ds.material_mask |= 1 << d.materials[i].type;
     for (int k = 0; k < 3; ++k) ds.sky[k] = d.sky_color[k];
+    lap("upload the rest");
     s.device_bytes = ((size_t) 16 * nn + tris.size() + shade.size() + s.wide.n) * sizeof(float4) + mats.size() * sizeof(DMaterial) +
                      lights.size() * sizeof(DLight) + tex.size() * sizeof(DTexture) + texels.size() * sizeof(float);
 }
@@ -910,19 +927,31 @@ int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
     try {
         if (!desc || !out) throw std::runtime_error("null argument");
         *out = nullptr;
+        const bool trace = getenv("JTX_TRACE_CREATE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!trace) return;
+            const auto n = std::chrono::steady_clock::now();
+            fprintf(stderr, "[jtx create] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count());
+            t0 = n;
+        };
         validate(*desc);
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
             throw std::runtime_error("no HIP device: the jtx_mi core has no CPU fallback");
         s = new jtx_mi_scene();
         HIPCHK(hipGetDevice(&s->device));
+        lap("validate");
         jtxh::buildBVH(*desc, s->bvh);
+        lap("buildBVH");
         flatten(*desc, *s);
+        lap("flatten (all of the above)");
         HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIPCHK(hipHostMalloc((void **) &s->stop_host, sizeof(unsigned), hipHostMallocMapped));
         *s->stop_host = 0u;
         { void *d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, s->stop_host, 0)); s->stop_dev = (const unsigned *) d; }
-        { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, s->device)); s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+        { int cus = 0; HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device)); s->num_cus = cus > 0 ? cus : 256; }
+        lap("stream, stop flag, CU count");
         *out = s;
         return 0;
     } catch (const std::exception &e) { delete s; return fail(e.what()); }

@@ -82,6 +82,7 @@ struct RefitArgs {
 
 } // namespace jtx
 
+hipError_t jtx_launch_build_threaded(const float4 *nbox, const int *pos, const int *size, int nn, float4 *tnodes, int *rec_node, hipStream_t st);
 hipError_t jtx_launch_refit(const jtx::RefitArgs &a, const int *level_begin, int num_levels, hipStream_t st);
 hipError_t jtx_wf_generate(const jtx::WfParams &p, int s0, int nstrata, hipStream_t st);
 hipError_t jtx_wf_trace(const jtx::WfParams &p, int any, int grid, bool count, hipStream_t st);

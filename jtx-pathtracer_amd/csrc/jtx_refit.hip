@@ -94,6 +94,33 @@ __global__ void __launch_bounds__(256) k_refit_threaded(RefitArgs a) {
     a.tnodes[2 * r + 1] = make_float4(b1.x, b1.y, keep.z, keep.w);      // link / leaf words stay
 }
 
+// Scene creation: the 8 x num_nodes stackless records (layout: traverseThreaded in jtx_scene_dev.hpp) written on the device
+// from the binary nodes, every node's position in each octant's near-first order (host: one top-down pass per octant)
+// and the subtree sizes -- the host used to fill and upload the 134 MB array itself (atrium: 16 of 67 ms).
+__global__ void __launch_bounds__(256) k_build_threaded(const float4 *nbox, const int *pos, const int *size, int nn, float4 *tnodes, int *rec_node) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= nn) return;
+    const float4 b0 = nbox[2 * (size_t) g], b1 = nbox[2 * (size_t) g + 1];
+    const int offset = __float_as_int(b1.z), nprims = __float_as_int(b1.w);
+    const int sz = size[g];
+    for (int k = 0; k < 8; ++k) {
+        const int i = pos[(size_t) k * nn + g];
+        int z, w;
+        if (nprims == 0) {                                   // interior: where the walk goes on when the box is missed
+            const int behind = i + sz;
+            z = behind < nn ? k * nn + behind : -1;
+            w = 0;
+        } else {                                             // leaf: its primitives; bit 31 marks the last record of the order
+            z = offset;
+            w = nprims | (i + 1 == nn ? (int) 0x80000000u : 0);
+        }
+        const size_t r = (size_t) k * nn + i;
+        rec_node[r] = g;
+        tnodes[2 * r] = b0;
+        tnodes[2 * r + 1] = make_float4(b1.x, b1.y, __int_as_float(z), __int_as_float(w));
+    }
+}
+
 JD void nodeCorners(const RefitArgs &a, int node, float lo[3], float hi[3]) {
     const float4 b0 = a.nbox[2 * (size_t) node], b1 = a.nbox[2 * (size_t) node + 1];
     lo[0] = b0.x; hi[0] = b0.y; lo[1] = b0.z; hi[1] = b0.w; lo[2] = b1.x; hi[2] = b1.y;
@@ -146,5 +173,11 @@ hipError_t jtx_launch_refit(const RefitArgs &a, const int *level_begin, int num_
     }
     if (a.num_nodes) hipLaunchKernelGGL(k_refit_threaded, blocks((size_t) 8 * a.num_nodes, 256), dim3(256), 0, st, a);
     if (a.num_wide && a.wide) hipLaunchKernelGGL(k_refit_wide, blocks(a.num_wide, 128), dim3(128), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t jtx_launch_build_threaded(const float4 *nbox, const int *pos, const int *size, int nn, float4 *tnodes, int *rec_node, hipStream_t st) {
+    if (nn <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_threaded, dim3((unsigned) ((nn + 255) / 256)), dim3(256), 0, st, nbox, pos, size, nn, tnodes, rec_node);
     return hipGetLastError();
 }
