@@ -45,9 +45,10 @@ def source_hash():
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "jtx-pathtracer_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    # what the timed kernel (k_render_paths + k_resolve_samples) is compiled from; the wide-node BUILDER lives in
+    # jtx_capi.hip and shows in the counter file's wide_stats (node steps per ray) instead
+    for f in ("jtx_kernels.hip", "jtx_scene_dev.hpp", "jtx_bxdf.hpp", "jtx_device_math.hpp", "jtx_launch.hpp", "jtx_tiles.hpp"):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -220,7 +221,11 @@ def main():
     t0 = time.perf_counter()
     scene = jtx.Scene(data)
     scene.buildBVH()
-    t_upload = time.perf_counter() - t0
+    t_upload = time.perf_counter() - t0                     # first creation of the process: includes loading the code object
+    t0 = time.perf_counter()
+    again = jtx.Scene(data); again.buildBVH()                # what a BVH rebuild after an edit costs (display.cpp:902-905)
+    warm_create_ms = round((time.perf_counter() - t0) * 1e3, 2)
+    again.destroy()
     cam = data.camera_desc(W, H, xs, ys, depth)
     acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
@@ -363,7 +368,7 @@ def main():
                        "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
                        "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu",
-                       "scene_upload_ms": round(t_upload * 1e3, 2),
+                       "scene_upload_ms": round(t_upload * 1e3, 2), "scene_create_warm_ms": warm_create_ms,
                        "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": info["lds_resident"],
                        "wide_bvh_bytes": info["wide_bytes"],
                        "timed_region": "frames rendered into HBM-resident film buffers (jtx_mi_render_device), incl. the resolve pass"},

@@ -1167,3 +1167,36 @@ def _tri_world(data, ref):
     for r in range(3):                                               # applyToPoint row by row, fp32 left to right
         out[:, r] = ((T[r, 0] * v[:, 0] + T[r, 1] * v[:, 1]) + T[r, 2] * v[:, 2]) + T[r, 3]
     return out
+
+
+_QUEUE_SCRIPT = r"""
+import sys, zlib, numpy as np
+sys.path.insert(0, sys.argv[1])
+import jtx_pathtracer_amd as gpu
+out = []
+for which in ("atrium", "axis", "mixed"):
+    data = gpu.scenes.mixed() if which == "mixed" else gpu.scenes.atrium(target_tris=20000)
+    if which == "axis":                      # a DISTANT light straight overhead: every shadow ray is irregular (1/d = inf)
+        data.lights = [gpu.scenes.light(gpu.scenes.DISTANT, (0.0, -1.0, 0.0), (1, 1, 1), 3.0)]
+    sc = gpu.Scene(data); sc.buildBVH()
+    assert not sc.info()["lds_resident"] and sc.info()["wide_depth"] >= 3
+    cam = gpu.StaticCamera(200, 120, data.camera, 2, 3, 8)
+    cam.render(sc, count_rays=False, integrator=1)
+    out.append("%08x %08x" % (zlib.crc32(np.ascontiguousarray(cam.acc_).tobytes()), zlib.crc32(np.ascontiguousarray(cam.img_).tobytes())))
+print("|".join(out))
+"""
+
+
+def test_ray_queue_kernel_is_bit_identical(gpu):
+    """JTX_QUEUE=1 routes HBM-resident scenes through k_render_queue (csrc/jtx_queue.hip: several paths per lane, every lane
+    walks its own queue of shadow and extension rays, path state in wave-private records): the film must be the one the
+    default kernel -- itself checked against the oracle above -- produces, bit for bit; incl. irregular rays."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for q in ("0", "1"):
+        env = dict(os.environ, JTX_QUEUE=q)
+        r = subprocess.run([sys.executable, "-c", _QUEUE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[q] = r.stdout.strip().splitlines()[-1]
+    assert res["0"] == res["1"] and res["0"].count("|") == 2
