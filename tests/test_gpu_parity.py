@@ -1200,3 +1200,27 @@ def test_ray_queue_kernel_is_bit_identical(gpu):
         assert r.returncode == 0, r.stderr[-2000:]
         res[q] = r.stdout.strip().splitlines()[-1]
     assert res["0"] == res["1"] and res["0"].count("|") == 2
+
+
+def test_closed_form_films_on_the_gpu(gpu):
+    """the two closed-form scenes of tests/test_geometry_physics_cpu.py rendered by the HIP kernels (timed kernel and the
+    counting one): the film must equal rho * sky over the convex Lambertian body, and the float64 direct-lighting formula on
+    the floor under the point light -- a check against physics, not against the twin restatement"""
+    import physics_cases as pc
+    s = pc.furnace_scene()
+    sc = gpu.Scene(s); sc.buildBVH()
+    for count in (False, True):
+        cam = gpu.StaticCamera(96, 96, s.camera, 2, 2, 8)
+        cam.render(sc, count_rays=count, integrator=1)
+        pc.check_furnace_film(np.asarray(cam.acc_, np.float32), 96, 96, 4)
+    s = pc.plane_scene()
+    sc = gpu.Scene(s); sc.buildBVH()
+    W, H = 64, 48
+    camd = s.camera_desc(W, H, 2, 2, 1)
+    rows, cols, smp = np.meshgrid(np.arange(H), np.arange(W), np.arange(4), indexing="ij")
+    ro, rd = ol.camera_rays(camd, rows.ravel(), cols.ravel(), smp.ravel())
+    want = pc.plane_film(ro, rd, W, H, 4)
+    for count in (False, True):
+        cam = gpu.StaticCamera(W, H, s.camera, 2, 2, 1)
+        cam.render(sc, count_rays=count, integrator=1)
+        assert np.allclose(np.asarray(cam.acc_, np.float32).reshape(H, W, 3), want, rtol=3e-5, atol=1e-6)
