@@ -825,7 +825,10 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             const long perPass = (long) (maxRad / ((size_t) p.rad_stride * sizeof(float4)));
             const int chunk = perPass >= se - sb ? se - sb : (perPass > 1 ? (int) perPass : 1);
             const size_t need = (size_t) p.rad_stride * (size_t) chunk;
-            if (s.rad.n < need) s.rad.alloc(need);
+            if (s.rad.n < need || s.rad.n / 4 > need) {                     // grow, and give memory back when the frame shrank a lot
+                if (s.rad.p) HIPCHK(hipStreamSynchronize(stream));           // (a pass in flight may still write the old buffer)
+                s.rad.alloc(need);
+            }
             p.rad = s.rad.p;
             // JTX_QUEUE=1: ray queues per lane for HBM-resident scenes (jtx_queue.hip: bit-identical, lane use 0.36 -> 0.56, but
             // slower -- the memory system, not the issue slots, is what the 8-ary traversal waits for)

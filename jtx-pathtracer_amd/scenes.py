@@ -492,9 +492,15 @@ def load_obj(path, default_material=None, materials_by_name=None):
     mtl_maps = {}                     # material name -> map_Kd path
     with open(path) as f:
         libs = [ln.split(None, 1)[1].strip() for ln in f if ln.startswith("mtllib") and len(ln.split()) > 1]
+    def inside(rel):                   # an asset is untrusted input: its library / map names stay inside its own directory
+        root = os.path.realpath(base or ".")
+        full = os.path.realpath(os.path.join(root, rel))
+        return full if not os.path.isabs(rel) and os.path.commonpath([root, full]) == root else None
     for lib in libs:
         try:
-            with open(os.path.join(base, lib)) as f:
+            if inside(lib) is None:
+                continue
+            with open(inside(lib)) as f:
                 name = None
                 for ln in f:
                     t = ln.split()
@@ -508,10 +514,10 @@ def load_obj(path, default_material=None, materials_by_name=None):
     for name, rel in mtl_maps.items():
         if name in materials_by_name:
             continue
-        full = os.path.join(base, rel)
+        full = inside(rel)
         if full not in tex_files:
             from . import gltf
-            px = gltf.load_texture_file(full)
+            px = gltf.load_texture_file(full) if full is not None else None
             tex_files[full] = -1
             if px is not None and px.shape[-1] >= 3:
                 tex_store.append(px)
