@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -63,6 +64,7 @@ public:
     std::vector<Mesh> meshes;
     std::vector<TextureImage> textures;
     CameraProperties cameraProperties;
+    std::vector<std::shared_ptr<void>> storage;                       // arrays a loader allocated for `meshes` (the reference leaks its new[])
 
     ~Scene() { destroyBVH(); }
     int numPrimitives() const { return (int) triangles.size(); }

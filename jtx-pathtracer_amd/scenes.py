@@ -594,7 +594,7 @@ def load_obj(path, default_material=None, materials_by_name=None):
             pos += [tuple(x) for x in p]
             nrm += n
             if has_uv:
-                uvs += [(VT[c[1]][0], 1.0 - VT[c[1]][1]) for c in f_]   # FlipUVs
+                uvs += [(np.float32(VT[c[1]][0]), np.float32(1.0) - np.float32(VT[c[1]][1])) for c in f_]   # FlipUVs, in float as Assimp does it
         idx, v, nn, uv = _faces_to_mesh(pos, nrm, uvs if has_uv else None)
         scene.add_mesh(idx, v, nn, mat_id(name, mtl), uvs=uv, name=name)
     return scene
