@@ -1152,10 +1152,15 @@ int jtx_mi_debug_timeline(jtx_mi_scene *s, unsigned long long *out, int n) {   /
 }
 #endif
 #ifdef JTX_PROFILE_PHASES
+int jtx_mi_debug_phases_reset(jtx_mi_scene *s) {       // diagnostic builds only
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemset(s->counters.p + 16, 0, 7 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 int jtx_mi_debug_phases(jtx_mi_scene *s, unsigned long long *out6) {   // diagnostic builds only
     if (!s || !s->counters.p) return 1;
     (void) hipDeviceSynchronize();
-    return hipMemcpy(out6, s->counters.p + 16, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+    return hipMemcpy(out6, s->counters.p + 16, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;   // [6]: hand-out (timed kernel only)
 }
 #endif
 

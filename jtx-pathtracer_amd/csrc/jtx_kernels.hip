@@ -299,6 +299,10 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
 
     Counters9 cnt = {};
     PathState ps;
+#ifdef JTX_PROFILE_PHASES
+    for (int i = 0; i < 6; ++i) ps.ph[i] = 0;
+    const long long k0 = clock64();
+#endif
     // the wave's current chunk (all wave-uniform)
     int next = 0, nunits = 0;                      // paths handed out / in the chunk
     int row0 = 0, col0 = 0, slot0 = 0, sBegin = 0;
@@ -306,6 +310,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     int s = 0, slot = 0;                           // this lane's current path: stratum, pixel slot in the rank's frame
     bool alive = false, need = true;
     while (true) {
+#ifdef JTX_PROFILE_PHASES
+        const long long h0 = clock64();
+#endif
         // ---- hand out paths to the lanes that need one ----
         while (true) {
             const unsigned long long mask = __ballot(need);
@@ -352,6 +359,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             }
         }
         need = false;
+#ifdef JTX_PROFILE_PHASES
+        ps.ph[5] += clock64() - h0;                                      // the hand-out (chunk fetches, camera rays)
+#endif
         if (__ballot(alive) == 0ull) break;
 #ifdef JTX_PROFILE_TIMELINE
         tl_iters++; tl_active += alive ? 1 : 0;
@@ -381,6 +391,13 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     }
 #ifdef JTX_PROFILE_WIDE
     if (SRC == SRC_WIDE) exportWideStats(p, cnt);
+#endif
+#ifdef JTX_PROFILE_PHASES
+    if (p.counters && lane == 0) {         // diagnostic build: per-phase wave clocks as lane 0 sees them (tools/tools_phases.py --timed)
+        for (int i = 0; i < 5; ++i) atomicAdd(&p.counters[16 + i], (unsigned long long) ps.ph[i]);
+        atomicAdd(&p.counters[16 + 5], (unsigned long long) (clock64() - k0));
+        atomicAdd(&p.counters[16 + 6], (unsigned long long) ps.ph[5]);
+    }
 #endif
 #ifdef JTX_PROFILE_TIMELINE
     if (p.counters) {
