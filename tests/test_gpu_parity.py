@@ -1224,3 +1224,36 @@ def test_closed_form_films_on_the_gpu(gpu):
         cam = gpu.StaticCamera(W, H, s.camera, 2, 2, 1)
         cam.render(sc, count_rays=count, integrator=1)
         assert np.allclose(np.asarray(cam.acc_, np.float32).reshape(H, W, 3), want, rtol=3e-5, atol=1e-6)
+
+
+def test_obj_with_an_exr_diffuse_map_renders_like_the_oracle(gpu, tmp_path):
+    """ingestion end to end: an OBJ whose .mtl names an EXR map (loader.cpp:64-101 -> TextureImage::load -> tinyexr: RGBA
+    floats, channels_ = 4) and a JPEG map (stbi_loadf, 3 channels), loaded by scenes.load_obj, rendered by the HIP kernels
+    and by the oracle: bit-identical film"""
+    from jtx_pathtracer_amd import gltf
+    rs = np.random.RandomState(4)
+    (tmp_path / "maps").mkdir()
+    yy, xx = np.mgrid[0:32, 0:48]
+    img = np.stack([0.2 + 0.7 * ((xx // 6 + yy // 4) % 2), 0.5 + 0.4 * np.sin(xx / 5.0), 0.3 + 0.02 * yy], -1).astype(np.float32)
+    (tmp_path / "maps" / "floor.exr").write_bytes(gltf.encode_exr(img, compression="zip"))
+    from PIL import Image
+    Image.fromarray((rs.rand(24, 24, 3) * 255).astype(np.uint8)).resize((96, 96), 0).save(str(tmp_path / "maps" / "wall.jpg"), quality=92)
+    (tmp_path / "room.mtl").write_text("newmtl floor\nmap_Kd maps/floor.exr\nnewmtl wall\nmap_Kd maps/wall.jpg\n")
+    (tmp_path / "room.obj").write_text(
+        "mtllib room.mtl\nv -2 0 -2\nv 2 0 -2\nv 2 0 2\nv -2 0 2\nv -2 3 -2\nv 2 3 -2\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 1 0\nvn 0 0 1\n"
+        "o floor\nusemtl floor\nf 1/1/1 4/4/1 3/3/1 2/2/1\no wall\nusemtl wall\nf 1/1/2 2/2/2 6/3/2 5/4/2\n")
+    white = gpu.scenes.material(gpu.scenes.DIFFUSE, (1.0, 1.0, 1.0))
+    s = gpu.scenes.load_obj(str(tmp_path / "room.obj"), default_material=white)
+    assert len(s.textures) == 2 and s.textures[0].shape == (32, 48, 4) and s.textures[1].shape == (96, 96, 3)
+    s.lights = [gpu.scenes.light(gpu.scenes.POINT, (0.5, 2.5, 1.0), (1, 1, 1), 12.0)]
+    s.sky = (0.2, 0.3, 0.4)
+    s.camera = dict(center=(0.0, 2.0, 5.0), target=(0.0, 1.0, 0.0), up=(0, 1, 0), yfov=45.0, defocus_angle=0.0, focus_distance=1.0)
+    sc = gpu.Scene(s); sc.buildBVH()
+    osc = ol.OracleScene(s)
+    acc, img8, cnt = osc.render(s.camera_desc(160, 120, 2, 2, 4))
+    for count in (True, False):
+        cam = gpu.StaticCamera(160, 120, s.camera, 2, 2, 4)
+        cam.render(sc, count_rays=count, integrator=1)
+        assert_same_f32(cam.acc_, acc, "OBJ + EXR map")
+        assert (cam.img_ == img8).all()
+    assert len(np.unique(img8.reshape(-1, 3), axis=0)) > 500          # the maps show
