@@ -246,7 +246,7 @@ void decodeExr(const uint8_t *b, size_t n, int32_t *width, int32_t *height, floa
     };
     for (int64_t blk = 0; blk < nblocks; ++blk) {
         const uint64_t off = rd64(b + table + 8 * (size_t) blk);
-        if (off + 8 > n) fail("EXR: block offset past the end");
+        if (off > n || n - off < 8) fail("EXR: block offset past the end");      // (off + 8 could wrap)
         const int32_t y0 = (int32_t) rd32(b + off);
         const uint32_t dsz = rd32(b + off + 4);
         if (dsz > n - off - 8) fail("EXR: block runs past the end");

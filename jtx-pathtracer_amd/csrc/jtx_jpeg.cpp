@@ -204,6 +204,10 @@ struct Decoder {
     // ---- the fixed-point inverse DCT of the reference's decoder ----
     static int f2f(double x) { return (int) (x * 4096 + 0.5); }
     static uint8_t clamp8(int x) { return (unsigned) x > 255u ? (x < 0 ? 0 : 255) : (uint8_t) x; }
+    // (corrupted coefficients can overflow the 32-bit intermediates; stb_image wraps there, and so does this: unsigned arithmetic)
+    static int wadd(int a, int b) { return (int) ((unsigned) a + (unsigned) b); }
+    static int wsub(int a, int b) { return (int) ((unsigned) a - (unsigned) b); }
+    static int wmul(int a, int b) { return (int) ((unsigned) a * (unsigned) b); }
     static void idct1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int &x0, int &x1, int &x2, int &x3,
                        int &t0, int &t1, int &t2, int &t3) {
         static const int c0541 = f2f(0.5411961f), cm1847 = f2f(-1.847759065f), c0765 = f2f(0.765366865f), c1175 = f2f(1.175875602f),
@@ -211,19 +215,19 @@ struct Decoder {
                          cm0899 = f2f(-0.899976223f), cm2562 = f2f(-2.562915447f), cm1961 = f2f(-1.961570560f), cm0390 = f2f(-0.390180644f);
         int p1, p2, p3, p4, p5;
         p2 = s2; p3 = s6;
-        p1 = (p2 + p3) * c0541;
-        t2 = p1 + p3 * cm1847;
-        t3 = p1 + p2 * c0765;
+        p1 = wmul(wadd(p2, p3), c0541);
+        t2 = wadd(p1, wmul(p3, cm1847));
+        t3 = wadd(p1, wmul(p2, c0765));
         p2 = s0; p3 = s4;
-        t0 = (p2 + p3) * 4096;
-        t1 = (p2 - p3) * 4096;
-        x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;
+        t0 = wmul(wadd(p2, p3), 4096);
+        t1 = wmul(wsub(p2, p3), 4096);
+        x0 = wadd(t0, t3); x3 = wsub(t0, t3); x1 = wadd(t1, t2); x2 = wsub(t1, t2);
         t0 = s7; t1 = s5; t2 = s3; t3 = s1;
-        p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
-        p5 = (p3 + p4) * c1175;
-        t0 = t0 * c0298; t1 = t1 * c2053; t2 = t2 * c3072; t3 = t3 * c1501;
-        p1 = p5 + p1 * cm0899; p2 = p5 + p2 * cm2562; p3 = p3 * cm1961; p4 = p4 * cm0390;
-        t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+        p3 = wadd(t0, t2); p4 = wadd(t1, t3); p1 = wadd(t0, t3); p2 = wadd(t1, t2);
+        p5 = wmul(wadd(p3, p4), c1175);
+        t0 = wmul(t0, c0298); t1 = wmul(t1, c2053); t2 = wmul(t2, c3072); t3 = wmul(t3, c1501);
+        p1 = wadd(p5, wmul(p1, cm0899)); p2 = wadd(p5, wmul(p2, cm2562)); p3 = wmul(p3, cm1961); p4 = wmul(p4, cm0390);
+        t3 = wadd(t3, wadd(p1, p4)); t2 = wadd(t2, wadd(p2, p3)); t1 = wadd(t1, wadd(p2, p4)); t0 = wadd(t0, wadd(p1, p3));
     }
     static void idct(uint8_t *out, int stride, const short *d) {
         int val[64];
@@ -235,9 +239,9 @@ struct Decoder {
             } else {
                 int x0, x1, x2, x3, t0, t1, t2, t3;
                 idct1d(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56], x0, x1, x2, x3, t0, t1, t2, t3);
-                x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-                v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-                v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+                x0 = wadd(x0, 512); x1 = wadd(x1, 512); x2 = wadd(x2, 512); x3 = wadd(x3, 512);
+                v[0] = wadd(x0, t3) >> 10; v[56] = wsub(x0, t3) >> 10; v[8] = wadd(x1, t2) >> 10; v[48] = wsub(x1, t2) >> 10;
+                v[16] = wadd(x2, t1) >> 10; v[40] = wsub(x2, t1) >> 10; v[24] = wadd(x3, t0) >> 10; v[32] = wsub(x3, t0) >> 10;
             }
         }
         for (int i = 0; i < 8; ++i) {
@@ -245,9 +249,9 @@ struct Decoder {
             int x0, x1, x2, x3, t0, t1, t2, t3;
             idct1d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], x0, x1, x2, x3, t0, t1, t2, t3);
             const int bias = 65536 + (128 << 17);
-            x0 += bias; x1 += bias; x2 += bias; x3 += bias;
-            o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17); o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
-            o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17); o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
+            x0 = wadd(x0, bias); x1 = wadd(x1, bias); x2 = wadd(x2, bias); x3 = wadd(x3, bias);
+            o[0] = clamp8(wadd(x0, t3) >> 17); o[7] = clamp8(wsub(x0, t3) >> 17); o[1] = clamp8(wadd(x1, t2) >> 17); o[6] = clamp8(wsub(x1, t2) >> 17);
+            o[2] = clamp8(wadd(x2, t1) >> 17); o[5] = clamp8(wsub(x2, t1) >> 17); o[3] = clamp8(wadd(x3, t0) >> 17); o[4] = clamp8(wsub(x3, t0) >> 17);
         }
     }
 
