@@ -161,8 +161,8 @@ int jtx_mi_decode_jpeg(const uint8_t *bytes, int64_t num_bytes, int32_t *width, 
 
 /* Host-only: OpenEXR -> RGBA float, rows top to bottom: what TextureImage::load gets from tinyexr's LoadEXR /
  * LoadEXRFromMemory (image.cpp:63-66, 81-95, 108-121; channels R, G, B, optional A else 1.0; a single channel goes to all
- * four outputs).  Single-part scan-line files, compression NONE / RLE / ZIPS / ZIP (the reference's maps are ZIP), HALF /
- * FLOAT / UINT samples; tiled, deep, multi-part files and PIZ / lossy blocks are refused.  rgba_out == NULL: only width /
+ * four outputs).  Single-part scan-line files, compression NONE / RLE / ZIPS / ZIP / PIZ (the reference's maps are ZIP), HALF /
+ * FLOAT / UINT samples; tiled, deep, multi-part files and the lossy block types are refused.  rgba_out == NULL: only width /
  * height are filled in; capacity counts floats.  No GPU needed. */
 int jtx_mi_decode_exr(const uint8_t *bytes, int64_t num_bytes, int32_t *width, int32_t *height, float *rgba_out, int64_t capacity);
 

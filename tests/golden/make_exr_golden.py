@@ -29,6 +29,21 @@ def ref_exr():
     return lib
 
 
+def ref_encode(lib, img, fp16, compression):
+    """the reference's own writer (SaveEXRImageToMemory through oracle/ref_exr.cpp): compression 4 = PIZ"""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w, c = img.shape
+    lib.ref_exr_save.restype = C.c_size_t
+    lib.ref_exr_save.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_char_p)]
+    out = C.POINTER(C.c_ubyte)(); err = C.c_char_p()
+    n = lib.ref_exr_save(img.ctypes.data_as(C.POINTER(C.c_float)), w, h, c, fp16, compression, C.byref(out), C.byref(err))
+    if n == 0:
+        raise RuntimeError(f"tinyexr could not write the file: {err.value}")
+    data = bytes(out[:n])
+    lib.ref_exr_free_bytes.argtypes = [C.POINTER(C.c_ubyte)]; lib.ref_exr_free_bytes(out)
+    return data
+
+
 def ref_decode(lib, data):
     p = C.POINTER(C.c_float)(); w, h = C.c_int(), C.c_int(); err = C.c_char_p()
     rc = lib.ref_exr_from_memory(data, len(data), C.byref(p), C.byref(w), C.byref(h), C.byref(err))
@@ -76,10 +91,27 @@ def cases():
     return out
 
 
+def piz_cases(lib):
+    """PIZ files written by the reference's tinyexr: 32-line blocks, Huffman + wavelet + value table"""
+    out = []
+    rs = np.random.RandomState(11)
+    smooth = picture(70, 45, 3, 3)
+    out.append(("piz_half_rgb_70x45", ref_encode(lib, smooth, 1, 4)))                     # two blocks, odd sizes, 14-bit wavelet
+    out.append(("piz_half_rgba_33x64", ref_encode(lib, picture(33, 64, 4, 5), 1, 4)))
+    out.append(("piz_half_grey_19x7", ref_encode(lib, picture(19, 7, 1, 6), 1, 4)))
+    out.append(("piz_float_rgb_noise_200x40", ref_encode(lib, (rs.rand(40, 200, 3) * 1000).astype(np.float32), 0, 4)))   # > 2^14 distinct words: modulo wavelet
+    out.append(("piz_half_zero_40x33", ref_encode(lib, np.zeros((33, 40, 3), np.float32), 1, 4)))       # empty bitmap
+    flat = np.full((36, 48, 3), 0.25, np.float32); flat[10:20, 5:30] = 3.0
+    out.append(("piz_half_flat_48x36", ref_encode(lib, flat, 1, 4)))                      # long runs: the run-length symbol
+    out.append(("piz_half_rgb_1x1", ref_encode(lib, picture(1, 1, 3, 7), 1, 4)))
+    out.append(("piz_float_rgb_3x50", ref_encode(lib, picture(3, 50, 3, 8), 0, 4)))
+    return out
+
+
 def main():
     lib = ref_exr()
     store = {}
-    for name, data in cases():
+    for name, data in cases() + piz_cases(lib):
         store[name + ".exr"] = np.frombuffer(data, np.uint8)
         store[name + ".f32"] = ref_decode(lib, data)
         mine = gltf.decode_exr(data)
@@ -90,7 +122,7 @@ def main():
         maps[os.path.basename(f)] = [a.shape[0], a.shape[1], zlib.crc32(a.tobytes())]
     store["reference_maps.json"] = np.frombuffer(repr(maps).encode(), np.uint8)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "exr_cases.npz"), **store)
-    print(f"{len(cases())} files, {len(maps)} reference maps, {sum(v.nbytes for v in store.values())} bytes")
+    print(f"{sum(k.endswith('.exr') for k in store)} files, {len(maps)} reference maps, {sum(v.nbytes for v in store.values())} bytes")
 
 
 if __name__ == "__main__":
