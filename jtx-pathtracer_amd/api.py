@@ -351,10 +351,16 @@ class StaticCamera:
         return self.img_
 
     def save(self, path):
-        """RGB8Image::save flips rows (image.cpp:14-22); writes a binary PPM (no PNG encoder here)."""
+        """RGB8Image::save (image.cpp:11-25): rows flipped; a PNG when the path ends in .png (the same pixels as the
+        reference's stbi_write_png file, not the same bytes), else a binary PPM."""
+        rows = np.ascontiguousarray(self.img_[::-1])
         with open(path, "wb") as f:
-            f.write(b"P6\n%d %d\n255\n" % (self.width_, self.height_))
-            f.write(self.img_[::-1].tobytes())
+            if str(path).lower().endswith(".png"):
+                from . import gltf
+                f.write(gltf.encode_png(rows.reshape(self.height_, self.width_, 3)))
+            else:
+                f.write(b"P6\n%d %d\n255\n" % (self.width_, self.height_))
+                f.write(rows.tobytes())
 
 
 class DynamicCamera(StaticCamera):

@@ -157,10 +157,39 @@ public:
     void clear() { std::fill(buffer.begin(), buffer.end(), RGB{0, 0, 0}); }
     const RGB *data() const { return buffer.data(); }
     RGB *data() { return buffer.data(); }
-    void save(const char *path) const {                               // rows flipped as image.cpp:14-22; binary PPM
+    // RGB8Image::save (image.cpp:11-25: rows flipped, stbi_write_png): a PNG when the path ends in .png -- 8-bit RGB, filter 0,
+    // stored deflate blocks: the same pixels as the reference's file, not the same bytes -- else a binary PPM
+    void save(const char *path) const {
         FILE *f = std::fopen(path, "wb"); if (!f) return;
-        std::fprintf(f, "P6\n%d %d\n255\n", w_, h_);
-        for (int r = h_ - 1; r >= 0; --r) std::fwrite(&buffer[(size_t) r * w_], 3, w_, f);
+        const std::string p(path);
+        const bool png = p.size() > 4 && (p.substr(p.size() - 4) == ".png" || p.substr(p.size() - 4) == ".PNG");
+        if (!png) {
+            std::fprintf(f, "P6\n%d %d\n255\n", w_, h_);
+            for (int r = h_ - 1; r >= 0; --r) std::fwrite(&buffer[(size_t) r * w_], 3, w_, f);
+            std::fclose(f); return;
+        }
+        auto crc = [](const std::vector<unsigned char> &d, size_t from) { unsigned c = 0xffffffffu; for (size_t i = from; i < d.size(); ++i) { c ^= d[i]; for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u))); } return ~c; };
+        auto be32 = [](std::vector<unsigned char> &d, unsigned v) { d.push_back(v >> 24); d.push_back(v >> 16); d.push_back(v >> 8); d.push_back(v); };
+        auto chunk = [&](const char *tag, const std::vector<unsigned char> &body) {
+            std::vector<unsigned char> c; be32(c, (unsigned) body.size()); c.insert(c.end(), tag, tag + 4); c.insert(c.end(), body.begin(), body.end());
+            be32(c, crc(c, 4)); std::fwrite(c.data(), 1, c.size(), f);
+        };
+        std::fwrite("\x89PNG\r\n\x1a\n", 1, 8, f);
+        std::vector<unsigned char> ihdr; be32(ihdr, (unsigned) w_); be32(ihdr, (unsigned) h_); ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+        chunk("IHDR", ihdr);
+        std::vector<unsigned char> raw; raw.reserve((size_t) h_ * (3 * w_ + 1));
+        for (int r = h_ - 1; r >= 0; --r) { raw.push_back(0); const unsigned char *row = &buffer[(size_t) r * w_].R; raw.insert(raw.end(), row, row + 3 * (size_t) w_); }
+        std::vector<unsigned char> z; z.push_back(0x78); z.push_back(0x01);
+        unsigned a = 1, b = 0;
+        for (size_t at = 0; at < raw.size() || at == 0; at += 65535) {
+            const size_t n = raw.size() - at < 65535 ? raw.size() - at : 65535;
+            z.push_back(at + n >= raw.size() ? 1 : 0); z.push_back(n & 255); z.push_back(n >> 8); z.push_back(~n & 255); z.push_back((~n >> 8) & 255);
+            z.insert(z.end(), raw.begin() + at, raw.begin() + at + n);
+            for (size_t i = at; i < at + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+            if (raw.empty()) break;
+        }
+        be32(z, (b << 16) | a);
+        chunk("IDAT", z); chunk("IEND", {});
         std::fclose(f);
     }
 private:

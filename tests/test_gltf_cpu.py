@@ -224,3 +224,15 @@ def test_external_uris_must_stay_inside_the_asset_directory(tmp_path):
         else:
             with pytest.raises(ValueError):
                 gltf._external(str(tmp_path / "a"), uri)
+
+
+def test_camera_save_writes_png_and_ppm(tmp_path):
+    """RGB8Image::save (image.cpp:11-25) of the Python mirror: rows flipped; .png decodes back to the image"""
+    import jtx_pathtracer_amd as jtx
+    cam = jtx.StaticCamera.__new__(jtx.StaticCamera)
+    cam.width_, cam.height_ = 23, 11
+    cam.img_ = (np.arange(23 * 11 * 3) % 251).astype(np.uint8).reshape(11, 23, 3)
+    cam.save(str(tmp_path / "o.png")); cam.save(str(tmp_path / "o.ppm"))
+    assert np.array_equal(gltf.decode_png((tmp_path / "o.png").read_bytes()), cam.img_[::-1])
+    ppm = (tmp_path / "o.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n23 11\n255\n") and ppm[len(b"P6\n23 11\n255\n"):] == cam.img_[::-1].tobytes()

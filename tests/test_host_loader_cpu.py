@@ -73,3 +73,20 @@ def test_cpp_loader_reports_errors(exe, tmp_path):
     assert r.returncode == 1 and "out of range" in r.stdout
     r = subprocess.run([exe, str(tmp_path / "x.glb")], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (37, 21), (300, 250)])
+def test_cpp_mirror_saves_a_valid_png(tmp_path, w, h):
+    """RGB8Image::save (image.cpp:11-25): the PNG the C++ mirror writes decodes to the image, bottom row first in memory = last
+    row of the file flipped to the top"""
+    exe = str(tmp_path / "save_png_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "save_png_test.cpp"),
+                    "-L" + LIB_DIR, "-ljtx_mi", "-Wl,-rpath," + LIB_DIR, "-lpthread"], check=True)
+    out = str(tmp_path / "o.png")
+    subprocess.run([exe, out, str(w), str(h)], check=True)
+    px = gltf.decode_png(open(out, "rb").read())
+    r, c = np.mgrid[0:h, 0:w]
+    want = np.stack([(r * 7 + c) & 255, (c * 3) & 255, (r ^ c) & 255], -1).astype(np.uint8)[::-1]
+    assert px.shape == (h, w, 3) and np.array_equal(px, want)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(out)), want)          # an independent reader agrees
