@@ -23,7 +23,7 @@ glTF file, as far as the hot path can see it:
     progressive) and OpenEXR by the library's host decoders (csrc/jtx_jpeg.cpp, csrc/jtx_exr.cpp).
 
 The three decoders are pinned against the reference's own: ext/stb/stb_image.h and ext/tinyexr/tinyexr.h compiled where
-they lie into oracle/_ref (tests/golden/{png,jpeg,exr}_cases.npz and their generators).  What remains unpinned is the
+they lie by the test infrastructure (tests/golden/{png,jpeg,exr}_cases.npz and their generators).  What remains unpinned is the
 Assimp side (mesh splitting, traversal order): covered by round-trip tests against this module's own writer and by
 structural checks on the reference's helmet.glb where that file is present.
 """
