@@ -159,6 +159,12 @@ int jtx_mi_bvh_build(const jtx_mi_scene_desc *desc, jtx_mi_bvh_node *nodes_out, 
 int jtx_mi_decode_jpeg(const uint8_t *bytes, int64_t num_bytes, int32_t *width, int32_t *height, int32_t *components,
                        uint8_t *out, int64_t capacity);
 
+/* Host-only: PNG -> interleaved 8-bit samples as stbi_load_from_memory(.., req_comp = 0) of the reference's stb_image returns
+ * them (image.cpp:70,97): components 1 (grey), 2 (grey + alpha), 3 (RGB / palette), 4 (RGBA / palette + tRNS); a tRNS colour
+ * key adds the alpha channel; 1 - 16 bits, Adam7.  out == NULL: only width / height / components.  No GPU needed. */
+int jtx_mi_decode_png(const uint8_t *bytes, int64_t num_bytes, int32_t *width, int32_t *height, int32_t *components,
+                      uint8_t *out, int64_t capacity);
+
 /* Host-only: OpenEXR -> RGBA float, rows top to bottom: what TextureImage::load gets from tinyexr's LoadEXR /
  * LoadEXRFromMemory (image.cpp:63-66, 81-95, 108-121; channels R, G, B, optional A else 1.0; a single channel goes to all
  * four outputs).  Single-part scan-line files, compression NONE / RLE / ZIPS / ZIP / PIZ (the reference's maps are ZIP), HALF /

@@ -43,129 +43,20 @@ _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
 # ------------------------------------------------------------------------------------------------
 # PNG (decode for textures, encode for the test writer)
 # ------------------------------------------------------------------------------------------------
-def _png_unfilter(raw, p, h, stride, bpp):
-    """h filtered scan lines of `stride` bytes starting at raw[p] -> (uint8 (h, stride), next p)"""
-    out = np.zeros((h, stride), np.uint8)
-    prev = np.zeros(stride, np.int32)
-    for y in range(h):
-        if p + 1 + stride > len(raw):
-            raise ValueError("PNG data ends inside a scan line")
-        ft = raw[p]
-        line = np.frombuffer(raw, np.uint8, stride, p + 1).astype(np.int32)
-        p += 1 + stride
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        elif ft in (1, 3, 4):
-            cur = np.zeros(stride, np.int32)
-            for x in range(stride):                       # sub / average / paeth depend on the decoded left pixel
-                a = cur[x - bpp] if x >= bpp else 0
-                b = prev[x]
-                c = prev[x - bpp] if x >= bpp else 0
-                if ft == 1:
-                    pr = a
-                elif ft == 3:
-                    pr = (a + b) >> 1
-                else:
-                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[x] = (line[x] + pr) & 255
-        else:
-            raise ValueError("bad PNG filter type")
-        out[y] = cur
-        prev = cur
-    return out, p
-
-
 def decode_png(data):
     """PNG bytes -> uint8 array (H, W, C) as stbi_load_from_memory(.., req_comp = 0) of the reference's stb_image returns it
-    (pinned by tests/golden/png_cases.npz): C = 1 (grey), 2 (grey + alpha), 3 (RGB / palette), 4 (RGBA / palette + tRNS);
-    a tRNS colour key on a grey / RGB image adds the alpha channel (0 where the pixel equals the key); 1 / 2 / 4-bit grey is
-    scaled to 0..255; 16-bit samples keep their high byte (the key is compared on all 16 bits first); Adam7 files are
-    de-interlaced."""
-    if data[:8] != b"\x89PNG\r\n\x1a\n":
-        raise ValueError("not a PNG")
-    pos, idat, plte, trns, hdr = 8, [], None, None, None
-    while pos < len(data):
-        if pos + 8 > len(data):
-            raise ValueError("truncated PNG")
-        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
-        body = data[pos + 8:pos + 8 + n]
-        pos += 12 + n
-        if kind == b"IHDR":
-            hdr = struct.unpack(">IIBBBBB", body)
-        elif kind == b"IDAT":
-            idat.append(body)
-        elif kind == b"PLTE":
-            plte = np.frombuffer(body, np.uint8).reshape(-1, 3)
-        elif kind == b"tRNS":
-            trns = np.frombuffer(body, np.uint8)
-        elif kind == b"IEND":
-            break
-    if hdr is None:
-        raise ValueError("PNG without IHDR")
-    w, h, depth, ctype, _, _, interlace = hdr
-    if ctype not in (0, 2, 3, 4, 6) or w == 0 or h == 0:
-        raise ValueError("bad PNG header")
-    if depth not in (8, 16) and not (ctype == 3 and depth in (1, 2, 4, 8)) and not (ctype == 0 and depth in (1, 2, 4)):
-        raise ValueError("unsupported PNG bit depth")
-    if ctype == 3 and (depth == 16 or plte is None):
-        raise ValueError("bad palette PNG")
-    nch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
-    bpp = max(1, nch * depth // 8)
-    raw = zlib.decompress(b"".join(idat))
-
-    def samples(rows, ww):
-        """unfiltered rows of a (sub-)image ww pixels wide -> integer samples (hh, ww, nch), 16-bit values kept whole"""
-        hh = rows.shape[0]
-        if depth == 16:
-            r = rows.reshape(hh, ww, nch, 2).astype(np.int32)
-            return (r[..., 0] << 8) | r[..., 1]
-        if depth == 8:
-            return rows.reshape(hh, ww, nch).astype(np.int32)
-        bits = np.unpackbits(rows, axis=1)[:, : ww * depth].reshape(hh, ww, depth)
-        return (bits * (1 << np.arange(depth - 1, -1, -1))).sum(-1).astype(np.int32)[..., None]
-
-    if not interlace:
-        rows, _ = _png_unfilter(raw, 0, h, (w * nch * depth + 7) // 8, bpp)
-        val = samples(rows, w)
-    else:                                                 # Adam7: seven sub-images, each filtered on its own
-        val = np.zeros((h, w, nch), np.int32)
-        p = 0
-        for (x0, y0, dx, dy) in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
-            sw, sh = (w - x0 + dx - 1) // dx, (h - y0 + dy - 1) // dy
-            if sw <= 0 or sh <= 0:
-                continue
-            rows, p = _png_unfilter(raw, p, sh, (sw * nch * depth + 7) // 8, bpp)
-            val[y0::dy, x0::dx] = samples(rows, sw)
-    if ctype == 3:
-        idx = val[..., 0]
-        if idx.max() >= len(plte):
-            raise ValueError("PNG palette index out of range")
-        rgb = plte[idx]
-        if trns is not None:
-            alpha = np.full(256, 255, np.uint8)
-            alpha[: len(trns)] = trns[:256]
-            return np.concatenate([rgb, alpha[idx][..., None]], -1)
-        return np.ascontiguousarray(rgb)
-    key = None
-    if trns is not None and ctype in (0, 2) and len(trns) >= 2 * nch:      # colour key (stbi__compute_transparency[16])
-        k16 = np.frombuffer(bytes(trns[: 2 * nch]), ">u2").astype(np.int32)
-        key = k16 if depth == 16 else (k16 & 255)
-    if key is not None:
-        alpha = np.where((val == key).all(-1), 0, 255 if depth != 16 else 65535)[..., None]
-        val = np.concatenate([val, alpha], -1)
-    if depth == 16:
-        px = (val >> 8).astype(np.uint8)
-    elif depth == 8:
-        px = val.astype(np.uint8)
-    else:                                                 # packed grey: stbi__depth_scale_table (0xff, 0x55, 0x11)
-        scale = {1: 255, 2: 85, 4: 17}[depth]
-        px = val.copy()
-        px[..., 0] = val[..., 0] * scale
-        px = px.astype(np.uint8)
-    return np.ascontiguousarray(px)
+    (jtx_mi_decode_png, csrc/jtx_png.cpp; pinned by tests/golden/png_cases.npz): C = 1 (grey), 2 (grey + alpha), 3 (RGB /
+    palette), 4 (RGBA / palette + tRNS); a tRNS colour key on a grey / RGB image adds the alpha channel; 1 / 2 / 4-bit grey is
+    scaled to 0..255; 16-bit samples keep their high byte; Adam7 files are de-interlaced."""
+    import ctypes as C
+    from . import _capi as capi
+    lib = capi.load()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    w, h, c = C.c_int32(), C.c_int32(), C.c_int32()
+    capi.check(lib.jtx_mi_decode_png(buf, len(data), C.byref(w), C.byref(h), C.byref(c), None, 0))
+    out = np.zeros((h.value, w.value, c.value), np.uint8)
+    capi.check(lib.jtx_mi_decode_png(buf, len(data), C.byref(w), C.byref(h), C.byref(c), out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size))
+    return out
 
 
 def decode_jpeg(data):

@@ -7,7 +7,7 @@
 //   * a face without `vn` gets its flat normal (GenNormals), `vt` becomes (u, 1 - v) (FlipUVs); a mesh has uvs only if every
 //     corner of its faces has one;
 //   * `map_Kd` of a `mtllib` entry is read as TextureImage::load reads it (image.cpp:59-74): .exr through jtx_mi_decode_exr
-//     (RGBA floats as stored), JPEG through jtx_mi_decode_jpeg + stbi_loadf's pow(v / 255, 2.2); paths stay inside the
+//     (RGBA floats as stored), JPEG / PNG through jtx_mi_decode_jpeg / jtx_mi_decode_png + stbi_loadf's pow(v / 255, 2.2); paths stay inside the
 //     asset's directory; anything unreadable leaves albedoTexId at -1 ("Failed to load texture", loader.cpp:98).
 // glTF / GLB: the Python mirror (jtx_pathtracer_amd.gltf) -- a JSON + PNG reader is not worth a second copy in C++.
 #pragma once
@@ -55,7 +55,18 @@ inline bool loadTexture(const std::string &path, TextureImage &t) {
         for (size_t i = 0; i < px.size(); ++i) t.data_[i] = lut[px[i]];
         t.width_ = w; t.height_ = h; t.channels_ = c; return c >= 3;
     }
-    return false;                                                      // PNG and the rest: not decoded on the C++ side
+    if (bytes.size() > 8 && bytes[0] == 0x89 && bytes[1] == 'P' && bytes[2] == 'N' && bytes[3] == 'G') {
+        if (jtx_mi_decode_png(bytes.data(), (int64_t) bytes.size(), &w, &h, &c, nullptr, 0)) return false;
+        std::vector<uint8_t> px((size_t) w * h * c);
+        if (jtx_mi_decode_png(bytes.data(), (int64_t) bytes.size(), &w, &h, &c, px.data(), (int64_t) px.size())) return false;
+        float lut[256];
+        for (int v = 0; v < 256; ++v) lut[v] = (float) std::pow((double) ((float) v / 255.0f), (double) 2.2f);
+        const int ncol = (c & 1) ? c : c - 1;                          // stbi__ldr_to_hdr: an alpha channel stays linear (v / 255)
+        t.data_.resize(px.size());
+        for (size_t i = 0; i < px.size(); ++i) t.data_[i] = (int) (i % (size_t) c) < ncol ? lut[px[i]] : (float) px[i] / 255.0f;
+        t.width_ = w; t.height_ = h; t.channels_ = c; return c >= 3;
+    }
+    return false;
 }
 
 } // namespace loader_detail

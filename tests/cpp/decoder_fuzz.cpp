@@ -1,4 +1,4 @@
-// decoder_fuzz.cpp -- the two image readers of the library (csrc/jtx_jpeg.cpp, csrc/jtx_exr.cpp) compiled for the HOST with
+// decoder_fuzz.cpp -- the image readers of the library (csrc/jtx_jpeg.cpp, csrc/jtx_exr.cpp, csrc/jtx_png.cpp) compiled for the HOST with
 // AddressSanitizer + UBSan and fed corrupted copies of valid files: an asset is untrusted input, a bad one must end in an
 // error code or a picture, never in a memory error.  Built and run by tests/test_decoder_fuzz_cpu.py (CPU only).
 #include "../../include/jtx_mi.h"
@@ -30,7 +30,11 @@ int main(int argc, char **argv) {
             else if (kind == 2) { const size_t at = rnd() % b.size(), n = 1 + rnd() % 64; for (size_t i = at; i < at + n && i < b.size(); ++i) b[i] = 0xff; }   // a run of 0xff
             else { const size_t at = rnd() % b.size(); b.insert(b.begin() + at, (size_t) (rnd() % 16), (uint8_t) rnd()); }               // inserted bytes
             int32_t w = 0, h = 0, c = 0; int rc;
-            if (exr) {
+            const bool png = orig.size() > 4 && orig[0] == 0x89 && orig[1] == 'P';
+            if (png) {
+                rc = jtx_mi_decode_png(b.data(), (int64_t) b.size(), &w, &h, &c, nullptr, 0);
+                if (rc == 0 && (int64_t) w * h * c <= (1 << 24)) { std::vector<uint8_t> out((size_t) w * h * c); rc = jtx_mi_decode_png(b.data(), (int64_t) b.size(), &w, &h, &c, out.data(), (int64_t) out.size()); }
+            } else if (exr) {
                 rc = jtx_mi_decode_exr(b.data(), (int64_t) b.size(), &w, &h, nullptr, 0);
                 if (rc == 0 && (int64_t) w * h <= (1 << 22)) { std::vector<float> out((size_t) 4 * w * h); rc = jtx_mi_decode_exr(b.data(), (int64_t) b.size(), &w, &h, out.data(), (int64_t) out.size()); }
             } else {
