@@ -20,6 +20,17 @@ int main(int argc, char **argv) {
         std::printf("mesh %s %d %d uv %d mat %d tex %d crc %08x\n", m.name.c_str(), m.numVertices, m.numIndices, m.uvs ? 1 : 0,
                     (int) (m.material - s.materials.data()), m.material->albedoTexId, c);
     }
+    if (argc > 2) {                                            // raw dump for comparisons with a tolerance
+        FILE *f = std::fopen(argv[2], "wb");
+        for (const auto &m : s.meshes) {
+            const int hdr[4] = {m.numVertices, m.numIndices, m.uvs ? 1 : 0, (int) (m.material - s.materials.data())};
+            std::fwrite(hdr, 4, 4, f); std::fwrite(m.vertices, 12, m.numVertices, f); std::fwrite(m.normals, 12, m.numVertices, f);
+            if (m.uvs) std::fwrite(m.uvs, 8, m.numVertices, f);
+            std::fwrite(m.indices, 12, m.numIndices, f);
+        }
+        for (const auto &mt : s.materials) { const float v[8] = {(float) mt.type, mt.albedo.x, mt.albedo.y, mt.albedo.z, mt.alphaX, mt.alphaY, (float) mt.albedoTexId, (float) mt.metallicRoughnessTexId}; std::fwrite(v, 4, 8, f); }
+        std::fclose(f);
+    }
     for (const auto &t : s.textures) std::printf("texture %d %d %d crc %08x\n", t.width_, t.height_, t.channels_, crc(0, t.data_.data(), sizeof(float) * t.data_.size()));
     return 0;
 }

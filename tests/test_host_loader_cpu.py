@@ -90,3 +90,68 @@ def test_cpp_mirror_saves_a_valid_png(tmp_path, w, h):
     assert px.shape == (h, w, 3) and np.array_equal(px, want)
     from PIL import Image
     assert np.array_equal(np.asarray(Image.open(out)), want)          # an independent reader agrees
+
+
+def _read_dump(path, nmesh, nmat):
+    b = open(path, "rb").read(); p = 0; meshes = []
+    for _ in range(nmesh):
+        nv, nt, hasuv, mat = np.frombuffer(b, np.int32, 4, p); p += 16
+        v = np.frombuffer(b, np.float32, 3 * nv, p).reshape(nv, 3); p += 12 * nv
+        n = np.frombuffer(b, np.float32, 3 * nv, p).reshape(nv, 3); p += 12 * nv
+        uv = None
+        if hasuv:
+            uv = np.frombuffer(b, np.float32, 2 * nv, p).reshape(nv, 2); p += 8 * nv
+        idx = np.frombuffer(b, np.int32, 3 * nt, p).reshape(nt, 3); p += 12 * nt
+        meshes.append((v, n, uv, idx, int(mat)))
+    mats = np.frombuffer(b, np.float32, 8 * nmat, p).reshape(nmat, 8)
+    return meshes, mats
+
+
+def _compare_with_python_gltf(exe, tmp_path, glb):
+    want = gltf.load_gltf(glb)
+    dump = str(tmp_path / "dump.bin")
+    r = subprocess.run([exe, glb, dump], capture_output=True, text=True, check=True)
+    head = r.stdout.splitlines()[0].split()
+    assert int(head[1]) == len(want.meshes) and int(head[3]) == want.num_triangles and int(head[5]) == len(want.materials) and int(head[7]) == len(want.textures), r.stdout[:300]
+    meshes, mats = _read_dump(dump, len(want.meshes), len(want.materials))
+    for (v, n, uv, idx, mat), m in zip(meshes, want.meshes):
+        assert np.array_equal(idx, m["indices"]) and mat == m["material"]
+        scale = max(1.0, float(np.abs(m["vertices"]).max()))
+        assert np.allclose(v, m["vertices"], rtol=0, atol=2e-7 * scale)          # float64 products rounded once: the last bit may differ
+        assert np.allclose(n, m["normals"], rtol=0, atol=3e-7)
+        assert (uv is None) == (m["uvs"] is None) and (uv is None or np.array_equal(uv, m["uvs"]))
+    for row, m in zip(mats, want.materials):
+        assert int(row[0]) == m["type"] and np.allclose(row[1:4], m["albedo"]) and row[4] == np.float32(m["alpha_x"]) and row[5] == np.float32(m["alpha_y"])
+        assert int(row[6]) == m["albedo_tex"] and int(row[7]) == m["mr_tex"]
+    tex_lines = [l for l in r.stdout.splitlines() if l.startswith("texture")]
+    assert len(tex_lines) == len(want.textures)
+    for l, t in zip(tex_lines, want.textures):
+        t = np.ascontiguousarray(t, np.float32)
+        assert l == f"texture {t.shape[1]} {t.shape[0]} {t.shape[2]} crc {zlib.crc32(t.tobytes()):08x}"
+    return want
+
+
+def test_cpp_gltf_loader_builds_what_the_python_loader_builds(exe, tmp_path):
+    """loadScene on a GLB written by gltf.write_glb from the mixed-material scene (PNG textures, node matrices with rotation,
+    non-uniform scale and translation): meshes, materials and textures equal the Python loader's"""
+    data = jtx.scenes.mixed(sphere_res=(10, 5), textured=True)
+    rs = np.random.RandomState(3)
+    mats = []
+    for _ in data.meshes:
+        a = rs.rand() * 6.28
+        m = np.eye(4); m[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ np.diag(0.5 + rs.rand(3)); m[:3, 3] = rs.randn(3)
+        mats.append(m)
+    tex8 = [(np.clip(np.asarray(t)[..., :3], 0, 1) ** (1 / 2.2) * 255).astype(np.uint8) for t in data.textures]
+    glb = str(tmp_path / "s.glb")
+    gltf.write_glb(glb, data, textures_u8=tex8, node_matrices=mats)
+    want = _compare_with_python_gltf(exe, tmp_path, glb)
+    assert len(want.meshes) >= 15 and len(want.textures) == 2
+
+
+HELMET = "/root/reference/src/assets/scenes/helmet.glb"
+
+
+@pytest.mark.skipif(not os.path.exists(HELMET), reason="reference tree not present")
+def test_cpp_gltf_loader_on_the_reference_helmet(exe, tmp_path):
+    want = _compare_with_python_gltf(exe, tmp_path, HELMET)
+    assert want.num_triangles > 10000 and len(want.textures) == 2
