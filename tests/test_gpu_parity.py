@@ -1257,3 +1257,33 @@ def test_obj_with_an_exr_diffuse_map_renders_like_the_oracle(gpu, tmp_path):
         assert_same_f32(cam.acc_, acc, "OBJ + EXR map")
         assert (cam.img_ == img8).all()
     assert len(np.unique(img8.reshape(-1, 3), axis=0)) > 500          # the maps show
+
+
+def test_cpp_host_loads_an_asset_and_renders_it(gpu, tmp_path):
+    """a C++ host end to end (tests/cpp/host_asset_demo.cpp): loadScene of a GLB with PNG maps (host/jtx_host_loader.hpp) ->
+    buildBVH -> StaticCamera::renderFinal -> Camera::save; the image equals the Python mirror's render of the same file"""
+    import os, subprocess, zlib
+    from jtx_pathtracer_amd import gltf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "jtx-pathtracer_amd")
+    exe = str(tmp_path / "host_asset_demo")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "cpp", "host_asset_demo.cpp"),
+                    "-L", libdir, "-ljtx_mi", "-lpthread", "-Wl,-rpath," + libdir], check=True)
+    data = gpu.scenes.mixed(sphere_res=(12, 6), textured=True)
+    tex8 = [(np.clip(np.asarray(t)[..., :3], 0, 1) ** (1 / 2.2) * 255).astype(np.uint8) for t in data.textures]
+    glb = str(tmp_path / "room.glb")
+    gltf.write_glb(glb, data, textures_u8=tex8)
+    png = str(tmp_path / "out.png")
+    out = subprocess.run([exe, glb, png], check=True, capture_output=True, text=True).stdout.split()
+    kv = dict(zip(out[0::2], out[1::2]))
+    s = gltf.load_gltf(glb)
+    s.sky = (0.5, 0.7, 1.0)
+    s.lights = [gpu.scenes.light(gpu.scenes.POINT, (278.0, 500.0, 279.5), (1, 1, 1), 60000.0)]
+    s.camera = dict(center=(278.0, 273.0, -800.0), target=(278.0, 273.0, 0.0), up=(0, 1, 0), yfov=39.3077, defocus_angle=0.0, focus_distance=1.0)
+    assert int(kv["meshes"]) == len(s.meshes) and int(kv["triangles"]) == s.num_triangles and int(kv["textures"]) == 2
+    sc = gpu.Scene(s); sc.buildBVH()
+    cam = gpu.StaticCamera(96, 72, s.camera, 2, 2, 5)
+    cam.render(sc, count_rays=False)
+    assert kv["crc"] == "%08x" % zlib.crc32(np.ascontiguousarray(cam.img_).tobytes())
+    assert np.array_equal(gltf.decode_png(open(png, "rb").read()), np.asarray(cam.img_).reshape(72, 96, 3)[::-1])
+    assert len(np.unique(np.asarray(cam.img_).reshape(-1, 3), axis=0)) > 8          # (every glTF material is metal-rough white: mostly mirrored sky)
