@@ -155,3 +155,19 @@ HELMET = "/root/reference/src/assets/scenes/helmet.glb"
 def test_cpp_gltf_loader_on_the_reference_helmet(exe, tmp_path):
     want = _compare_with_python_gltf(exe, tmp_path, HELMET)
     assert want.num_triangles > 10000 and len(want.textures) == 2
+
+
+REF_SCENES = "/root/reference/src/assets/scenes"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="reference tree not present")
+@pytest.mark.parametrize("rel", ["cornell_box.obj", "knob.obj", "f22_box.obj", "shaderball/shaderball.obj", "bunny.obj"])
+def test_cpp_obj_loader_on_the_reference_assets(exe, rel):
+    """the reference's own OBJ assets (shaderball.mtl names EXR maps, two of which exist): C++ loadScene = Python load_obj"""
+    path = os.path.join(REF_SCENES, rel)
+    white = jtx.scenes.material(jtx.scenes.DIFFUSE, (1.0, 1.0, 1.0))
+    want = describe(jtx.scenes.load_obj(path, default_material=white))
+    got = subprocess.run([exe, path], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    strip = lambda ls: [" ".join(w for i, w in enumerate(l.split()) if not (l.startswith("mesh") and i in (7, 8))) for l in ls if not l.startswith("meshes")]
+    assert strip(got) == strip(want)
+    assert got[0].split()[:4] == want[0].split()[:4] and got[0].split()[6:] == want[0].split()[6:]      # meshes, triangles, textures
