@@ -40,6 +40,39 @@ def algorithmic_bytes(c):
     return b_closest + b_any + b_shade + b_cam
 
 
+# Useful work of the REFERENCE's algorithm, per counted event, in fp32 lane-operations (one add / sub / mul / div / min / max /
+# compare / abs / sqrt = 1; integer RNG / hashing and address arithmetic = 0; derivation from the reference's source in
+# DESIGN.md section 6).  Minimal forms: 1/d once per ray, baked triangle edges, one shading-normal interpolation per path
+# vertex -- what any implementation of the same mathematics must do, NOT what this kernel issues: phase A's box tests of
+# leaves the reference never visits, scheduling ballots, spill code and idle lanes all LOWER the fraction built on it.
+USEFUL_OPS = {
+    "ray": 6,          # 3 divisions 1/d + 3 sign tests (scene.cpp:11-12), per closestHit / anyHit call
+    "node": 25,        # AABB::hit aabb.hpp:66-81: per axis 2 sub, 2 mul, min, max (18); t0 = max of 4, t1 = min of 4 (6); t0 <= t1 (1)
+    "tri": 55,         # Moeller-Trumbore run to the end, mesh.hpp:106-127 / 168-192: cross 9, dot 5, |det| test 2, 1/det 1, tvec 3,
+                       #   b1 6 + 2 tests, cross 9, b2 6 + add + 2 tests, t 6 + 2 interval tests (most tests leave earlier: upper bound per test)
+    "shade": 242,      # one Lambert vertex of integrateMIS (integrator.cpp:171-216) whose light sample is occluded: hit point + normal / uv
+                       #   interpolation + face-forward 42 (mesh.hpp:129-145), Light::sample 26 + shadow-ray set-up 16 + rng floats 10,
+                       #   Frame::fromZ + toLocal 31, cosine-hemisphere sample incl. sin / cos 60, pdf / f / checks 12, toWorld 15,
+                       #   beta update 15, radiance add 6, next ray 6, wo 3.  The unoccluded branch (evalBxdf + pdfBxdf + MIS weight,
+                       #   another 129) and the dearer BxDFs are NOT counted -- the counters do not separate them: a lower bound
+    "camera": 40,      # Camera::getRay camera.hpp:127-139 (stratum offsets 8, viewport point 14, direction 3, rng floats 6) + clamp
+                       #   and accumulate camera.cpp:110-112 / image.hpp:82-86 (9)
+}
+
+
+def useful_lane_ops(c):
+    return (USEFUL_OPS["ray"] * (c["n_closest"] + c["n_any"]) + USEFUL_OPS["node"] * (c["n_nodes_closest"] + c["n_nodes_any"])
+            + USEFUL_OPS["tri"] * (c["n_tri_closest"] + c["n_tri_any"]) + USEFUL_OPS["shade"] * c["n_shade"]
+            + USEFUL_OPS["camera"] * c["n_camera"])
+
+
+def pmc_file():
+    """the newest profiles/rNN_pmc.json (rocprofv3 --pmc passes over the timed launches, tools/pmc_collect.sh + pmc_merge.py)"""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
+    return cands[-1] if cands else None
+
+
 def source_hash():
     """sha1 over the kernel sources: ties a profiles/ counter file to the build it was collected from."""
     import hashlib
@@ -123,19 +156,33 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
     SIMDS = num_cus * 4
     CLK = 2.4e9                                            # MI355X max shader clock (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE / 8 / kernel time reads 2.39 GHz
     valu_peak = SIMDS * CLK / 2.0 / 1e9                    # wave64 VALU instructions per second: one per 2 cycles per SIMD-32
+    lane_peak = num_cus * 128 * CLK / 1e12                 # fp32 lane-operations per second: 4 SIMD-32 per CU (x2 for FMA = the 157 TFLOP/s vector peak)
     t = kernel_ms * 1e-3
     out = {"bound": "valu", "achieved": None, "peak": round(valu_peak, 1), "unit": "G wave-instructions/s", "frac": None,
-           "traffic": None, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches_per_frame}
+           "traffic": None, "kernel": kernel_name, "kernel_ms": round(kernel_ms, 4), "launches_per_frame": launches_per_frame,
+           "num_cus": num_cus}
+    # ---- useful-work fraction: needs no profile, only this frame's device counters and the live kernel time ----
+    uops = useful_lane_ops(mine)
+    out["useful_frac"] = round(uops / t / 1e12 / lane_peak, 4)
+    out["useful"] = {"lane_ops_per_launch": int(uops), "achieved": round(uops / t / 1e12, 3), "peak": round(lane_peak, 2),
+                     "unit": "T fp32 lane-ops/s", "per_event": USEFUL_OPS,
+                     "note": "reference-algorithm lane-operations (fixed cost per counted event of the untimed counting pass: rays, node visits, "
+                             "triangle tests, shading events, camera samples; DESIGN.md section 6) / kernel time / (CUs x 128 lanes x 2.4 GHz)"}
     pmc = None
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    if os.path.exists(path):
+    path = pmc_file()
+    if path:
         try:
             j = json.load(open(path))
             pmc = j.get("workloads", {}).get(workload)
-            out["pmc_source"] = "profiles/r02_pmc.json"
+            out["pmc_source"] = os.path.relpath(path, ROOT)
             out["pmc_stale"] = j.get("source_hash") != source_hash()
         except Exception:
             pmc = None
+    if pmc and out.get("pmc_stale"):
+        # counters of another build say nothing about this one: the instruction-issue figures stay null until
+        # tools/pmc_collect.sh has been re-run on the current sources (the useful-work fraction above does not depend on them)
+        out["pmc_note"] = "kernel sources changed since the counters were collected: frac / traffic / lane_util withheld"
+        pmc = None
     # ---- own-layout algorithmic HBM bytes of this launch ----
     paths = mine["n_camera"]; rays = mine["n_closest"] + mine["n_any"]
     own = 16 * paths                                       # one 16-B radiance record per path (k_resolve_samples reads them back)
@@ -173,7 +220,8 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
                                              "device counters: what the REFERENCE's layout would have to move; not this kernel's traffic"}
     out["note"] = ("bound = VALU instruction issue: achieved = SQ_INSTS_VALU of this launch (rocprofv3 --pmc, profiles/) / live HIP-event "
                    "kernel time; peak = 4 SIMD x CUs x 2.4 GHz / 2 cycles per wave64 instruction.  lane_util = SQ_THREAD_CYCLES_VALU / "
-                   "(64 SQ_ACTIVE_INST_VALU).  hbm.* = own-layout algorithmic bytes and PMC-measured bytes against 8 TB/s." + grid_note)
+                   "(64 SQ_ACTIVE_INST_VALU).  useful_frac = reference-algorithm lane-operations / time / fp32 lane peak (issue-independent).  "
+                   "hbm.* = own-layout algorithmic bytes and PMC-measured bytes against 8 TB/s." + grid_note)
     return out
 
 
@@ -320,6 +368,20 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
+    # self-diagnosis of the first real multi-GPU run: how many ranks took part (an all-reduce of ones), which device each rank
+    # rendered on and what its shard kernel took
+    ranks_diag = None
+    if world > 1:
+        ddev = dev if backend == "nccl" else torch.device("cpu")          # (gloo rehearsals: host tensors)
+        ones = torch.ones(1, dtype=torch.int32, device=ddev)
+        dist.all_reduce(ones)
+        rowt = torch.tensor([float(rank), float(torch.cuda.current_device()), kernel_ms, float(mine["n_closest"] + mine["n_any"])],
+                            dtype=torch.float64, device=ddev)
+        rows = [torch.zeros_like(rowt) for _ in range(world)]
+        dist.all_gather(rows, rowt)
+        ranks_diag = {"nranks_seen": int(ones.item()),
+                      "ranks": [{"rank": int(r[0]), "device": int(r[1]), "shard_kernel_ms": round(float(r[2]), 4), "shard_rays": int(r[3])}
+                                for r in (x.tolist() for x in rows)]}
 
     # N = 1: the same frames DELIVERED TO HOST buffers (jtx_mi_render: SURVEY 8d's wall time, first launch to last byte of
     # acc / img on the host), reported beside the HBM-resident figure (never as `value`)
@@ -349,7 +411,7 @@ def main():
         launches_per_frame = 1
         info = scene.info()
         sinfo = {"lds_resident": bool(info["lds_resident"]), "lds_bytes": 8 * 32 * info["num_nodes"] + 48 * info["num_prims"],
-                 "workgroups": 256 * 7}
+                 "workgroups": info["resident_workgroups"]}
         roof_counters = mine
         if integrator == 2:
             names = ["k_wf_generate", "k_wf_trace<closest>", "k_wf_shade", "k_wf_trace<any>", "k_wf_resolve"]
@@ -358,7 +420,7 @@ def main():
             launches_per_frame = max(1, kind_ms[dom][1])
             kernel_ms = kind_ms[dom][0] / launches_per_frame          # average launch duration of that kernel
         roof = roofline_block(args.workload if world == 1 else args.workload + f"@{world}", sinfo, roof_counters, kernel_name,
-                              kernel_ms, launches_per_frame, 256)
+                              kernel_ms, launches_per_frame, info["num_cus"])
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -374,6 +436,8 @@ def main():
                        "timed_region": "frames rendered into HBM-resident film buffers (jtx_mi_render_device), incl. the resolve pass"},
             "roofline": roof,
         }
+        if ranks_diag is not None:
+            out["ranks"] = ranks_diag
         if host_ms is not None:
             out["ms_per_step_host"] = round(host_ms, 3)
             out["value_host"] = round(rays_frame / host_ms / 1e3, 2)        # Mrays/s with the film delivered to host memory (PCIe-inclusive)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JTX_MI_VERSION 2
+#define JTX_MI_VERSION 3
 #define JTX_MI_CANCELLED 2   /* jtx_mi_render: stopped by the callback / jtx_mi_cancel; the film holds the completed passes */
 
 /* LinearBVHNode, src/bvh.hpp:7-15 (32 B) */
@@ -135,6 +135,10 @@ typedef struct {
     int32_t wide_depth;       /* levels of the 8-ary quantised BVH the uncounted kernels walk (0 = not built) */
     int32_t wide_bytes;       /* its size in bytes */
     int32_t refitted;         /* != 0: boxes / triangles come from jtx_mi_scene_refit (topology of the last build), not from a build */
+    int32_t num_cus;          /* compute units of the scene's device (hipDeviceAttributeMultiprocessorCount) */
+    int32_t resident_workgroups;   /* workgroups of the persistent k_render_paths grid for this scene on this device (upper limit: a launch
+                                    * never has more workgroups than chunks) */
+    int32_t workgroup_size;   /* lanes per workgroup of that kernel: 256 when the scene is staged in LDS, 64 otherwise */
 } jtx_mi_scene_info;
 
 typedef struct jtx_mi_scene jtx_mi_scene;

@@ -76,7 +76,8 @@ class Counters(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("num_prims", C.c_int32), ("max_depth", C.c_int32),
                 ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("auto_integrator", C.c_int32),
-                ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32), ("refitted", C.c_int32)]
+                ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32), ("refitted", C.c_int32),
+                ("num_cus", C.c_int32), ("resident_workgroups", C.c_int32), ("workgroup_size", C.c_int32)]
 
 
 CANCELLED = 2          # JTX_MI_CANCELLED

@@ -6,12 +6,19 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libjtx_mi.so")
-SOURCES = ["jtx_kernels.hip", "jtx_alt.hip", "jtx_queue.hip", "jtx_wavefront.hip", "jtx_capi.hip", "jtx_multi.hip", "jtx_refit.hip", "jtx_bvh_build.cpp", "jtx_jpeg.cpp", "jtx_exr.cpp", "jtx_png.cpp"]
+SOURCES = ["jtx_kernels.hip", "jtx_alt.hip", "jtx_wavefront.hip", "jtx_capi.hip", "jtx_multi.hip", "jtx_refit.hip", "jtx_bvh_build.cpp", "jtx_jpeg.cpp", "jtx_exr.cpp", "jtx_png.cpp"]
 HEADERS = ["jtx_device_math.hpp", "jtx_bxdf.hpp", "jtx_scene_dev.hpp", "jtx_launch.hpp", "jtx_host.hpp", "jtx_tiles.hpp", "jtx_wide_quant.hpp", "jtx_inflate.hpp",
            os.path.join("..", "..", "include", "jtx_mi.h")]
 # -ffp-contract=off: device results must equal the strict-fp32 CPU oracle bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
+
+
+# experiment kernels that lost stay in the tree but out of the product library:
+# JTX_WITH_QUEUE=1 adds csrc/jtx_queue.hip (ray queues per lane, run with JTX_QUEUE=1)
+if os.environ.get("JTX_WITH_QUEUE") == "1":
+    SOURCES = SOURCES + ["jtx_queue.hip"]
+    FLAGS = FLAGS + ["-DJTX_WITH_QUEUE"]
 
 
 def _hipcc():

@@ -757,6 +757,7 @@ void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_m
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
                   float *d_acc, unsigned char *d_img, hipStream_t stream) {
     RenderParams p{};
+    s.last_work = nullptr;            // only a launch that owns a chunk counter arms passAbandoned() (a stale one would void later passes)
     p.scene = s.dev;
     p.cam = deriveCamera(cam);
     p.width = cam.width; p.height = cam.height; p.max_depth = cam.max_depth;
@@ -795,6 +796,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                       ~EvReturn() { if (armed) s.free_events.push_back(ev); } } evGuard{s, ev};   // a throw below must not leak the pair
     bool evClosed = false;
     HIPCHK(hipEventRecord(ev.first, stream));
+    if (owned == 0) {                 // a shard without tiles (more ranks than 32x32 tiles): nothing to launch, an empty timing pair
+        HIPCHK(hipEventRecord(ev.second, stream));
+        evGuard.armed = false;
+        s.pending.push_back(ev);
+        return;
+    }
     if (alt) {
         HIPCHK(jtx_launch_render_alt(p, owned, count, o.path_integrator, stream));
     } else if (integ == 1) {
@@ -832,14 +839,18 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             p.rad = s.rad.p;
             // JTX_QUEUE=1: ray queues per lane for HBM-resident scenes (jtx_queue.hip: bit-identical, lane use 0.36 -> 0.56, but
             // slower -- the memory system, not the issue slots, is what the 8-ary traversal waits for)
+            p.qstate = nullptr;
+#ifdef JTX_WITH_QUEUE             /* experiment builds only (JTX_WITH_QUEUE=1 python -m ... build): the product library does not carry the kernel */
             static const int queueKernel = [] { const char *e = getenv("JTX_QUEUE"); return e ? atoi(e) : 0; }();
             const bool queued = queueKernel && !s.dev.lds_threaded && s.dev.wide != nullptr;
-            p.qstate = nullptr;
             if (queued) {
                 const size_t qn = jtx_queue_state_float4(s.num_cus);
                 if (s.qstate.n < qn) s.qstate.alloc(qn);
                 p.qstate = s.qstate.p;
             }
+#else
+            constexpr bool queued = false;
+#endif
             for (int b0 = sb; b0 < se; b0 += chunk) {
                 RenderParams q = p;
                 q.sample_begin = b0; q.sample_end = b0 + chunk < se ? b0 + chunk : se;
@@ -851,8 +862,11 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.work = s.work.p + (s.work_slot++ & 63);                 // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
                 s.last_work = q.work;
-                if (queued) HIPCHK(jtx_launch_render_queue(q, owned, s.num_cus, stream));
-                else HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
+#ifdef JTX_WITH_QUEUE
+                if (queued) HIPCHK(jtx_launch_render_queue(q, owned, s.num_cus, stream)); else
+#endif
+                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
+                (void) queued;
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }
@@ -1041,6 +1055,8 @@ int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     out->auto_integrator = autoIntegrator(*s);
     out->wide_depth = s->dev.wide_depth; out->wide_bytes = (int32_t) (s->wide.n * sizeof(uint4));
     out->refitted = s->refitted;
+    out->num_cus = s->num_cus;
+    { int bs = 0; out->resident_workgroups = jtx_render_paths_grid(s->dev, s->num_cus, &bs); out->workgroup_size = bs; }
     return 0;
 }
 int jtx_mi_scene_get_bvh(const jtx_mi_scene *s, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out) {
@@ -1296,6 +1312,9 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                     if (more && !count) {                                       // abandon the pass in flight
                         __atomic_store_n(s->stop_host, 1u, __ATOMIC_RELEASE);
                         HIPCHK(hipStreamSynchronize(s->stream));
+                        // the waves poll the flag at every 64th chunk fetch: a short pass (or a slow callback) completes and is
+                        // resolved before they look -- then its strata ARE in the film and count as completed
+                        if (!passAbandoned(*s)) done = inFlightEnd;
                     }
                     cancelled = true; break;
                 }

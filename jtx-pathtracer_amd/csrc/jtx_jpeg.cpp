@@ -33,8 +33,8 @@ const uint8_t kDezigzag[64 + 15] = {
     63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};   // runs past the end land on 63
 
 struct Huff {
-    uint8_t size[257]; uint16_t code[256]; uint8_t values[256];
-    unsigned maxcode[18]; int delta[17];
+    uint8_t size[257] = {}; uint16_t code[256] = {}; uint8_t values[256] = {};
+    unsigned maxcode[18] = {}; int delta[17] = {};
     bool present = false;
     void build(const int *count) {
         int k = 0;
@@ -135,7 +135,7 @@ struct Decoder {
         std::memset(data, 0, 64 * sizeof(short));
         const int diff = t ? extendReceive(t) : 0;
         c.dc_pred += diff;
-        data[0] = (short) (c.dc_pred * dq[0]);
+        data[0] = (short) ((unsigned) c.dc_pred * (unsigned) dq[0]);              // unsigned: a hostile stream must not overflow a signed int
         int k = 1;
         do {
             const int rs = huffDecode(ac);
@@ -153,7 +153,7 @@ struct Decoder {
             if (t < 0 || t > 15) throw std::runtime_error("bad huffman code");
             const int diff = t ? extendReceive(t) : 0;
             c.dc_pred += diff;
-            data[0] = (short) (c.dc_pred * (1 << succ_low));
+            data[0] = (short) ((unsigned) c.dc_pred << succ_low);
         } else if (getBit()) data[0] += (short) (1 << succ_low);
     }
     void blockProgAC(short *data, const Huff &ac) {
@@ -338,6 +338,11 @@ struct Decoder {
         return true;
     }
     void entropy() {
+        for (int i = 0; i < scan_n; ++i) {                                        // an SOS naming a table no DHT defined
+            const Comp &c = comp[order[i]];
+            const bool needDC = !progressive || (spec_start == 0 && succ_high == 0), needAC = !progressive || spec_start != 0;
+            if ((needDC && !hdc[c.hd].present) || (needAC && !hac[c.ha].present)) throw std::runtime_error("missing Huffman table");
+        }
         resetScan();
         short block[64];
         if (scan_n == 1) {

@@ -581,6 +581,13 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
 }
 } // namespace jtx
 
+int jtx_render_paths_grid(const DevScene &sc, int num_cus, int *block_size) {
+    const bool lds = sc.lds_threaded != 0, wide = !lds && sc.wide != nullptr;
+    const int bs = lds ? BLOCK : 64;
+    if (block_size) *block_size = bs;
+    return (int) (((long) num_cus * 4 * (wide ? JTX_WIDE_OCC : JTX_RP_OCC) * 64 + bs - 1) / bs);
+}
+
 hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const bool lds = p.scene.lds_threaded != 0;

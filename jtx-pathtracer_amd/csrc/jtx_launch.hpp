@@ -91,6 +91,7 @@ hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
+int jtx_render_paths_grid(const jtx::DevScene &sc, int num_cus, int *block_size);   // workgroups the persistent grid holds (host only)
 hipError_t jtx_launch_render_queue(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
 size_t jtx_queue_state_float4(int num_cus);
 hipError_t jtx_launch_render_alt(const jtx::RenderParams &p, int num_owned_tiles, bool count, int li, hipStream_t stream);

@@ -235,8 +235,8 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
                 SetDev sd(s.device);
                 jtx_mi_render_opts q = o;
                 q.sample_begin = b; q.sample_end = e; q.tile_rank = r; q.tile_world = n;
+                if (!s.slab_slots) continue;                                            // more shards than 32x32 tiles: this one owns nothing
                 MCHK(jtx_mi_render_device(s.scene, cam, &q, s.acc, s.img, s.stream));
-                if (!s.slab_slots) continue;
                 const int nslots = (int) s.slab_slots;
                 hipLaunchKernelGGL(k_pack_shard, dim3((nslots + 255) / 256), dim3(256), 0, s.stream, s.acc, img_rgb ? s.img : nullptr, s.slab_acc,
                                    s.slab_img, nslots, r, n, W, H);

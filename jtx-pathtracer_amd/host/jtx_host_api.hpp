@@ -28,6 +28,11 @@ struct Vec2f { float x = 0, y = 0; };
 struct Vec3i { int x = 0, y = 0, z = 0; Vec3i() = default; Vec3i(int a, int b, int c) : x(a), y(b), z(c) {} };
 struct Ray { Vec3 origin, dir; float time = 0; Ray() = default; Ray(Vec3 o, Vec3 d, float t = 0) : origin(o), dir(d), time(t) {} };
 struct Interval { float min, max; Interval(float a, float b) : min(a), max(b) {} };
+struct AABB {                                                         // util/aabb.hpp:7-16: the default box is the empty one
+    Vec3 pmin{std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    Vec3 pmax{std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest()};
+    Vec3 diagonal() const { return Vec3(pmax.x - pmin.x, pmax.y - pmin.y, pmax.z - pmin.z); }
+};
 struct Transform { float m[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}; };
 constexpr float INF = std::numeric_limits<float>::infinity();
 
@@ -124,6 +129,17 @@ public:
         for (auto &l : lights) if (l.type == Light::DISTANT) l.sceneRadius = info.scene_radius;
     }
     void destroy() { destroyBVH(); }                                  // mesh arrays stay with the caller
+    AABB bounds() const {                                             // scene.hpp:71-74: the root node's box (after a refit: the refitted one)
+        AABB b;
+        if (!handle_) return b;
+        jtx_mi_scene_info i; check(jtx_mi_scene_get_info(handle_, &i));
+        if (i.num_nodes <= 0) return b;
+        std::vector<jtx_mi_bvh_node> nodes((size_t) i.num_nodes);
+        check(jtx_mi_scene_get_bvh(handle_, nodes.data(), nullptr));
+        b.pmin = Vec3(nodes[0].pmin[0], nodes[0].pmin[1], nodes[0].pmin[2]);
+        b.pmax = Vec3(nodes[0].pmax[0], nodes[0].pmax[1], nodes[0].pmax[2]);
+        return b;
+    }
     float getSceneRadius() const { if (!handle_) return 0; jtx_mi_scene_info i; check(jtx_mi_scene_get_info(handle_, &i)); return i.scene_radius; }
 
     // Scene::closestHit / anyHit (scene.cpp:10-94): single-ray forms for API compatibility (one GPU batch of 1)

@@ -30,8 +30,9 @@ int main() {
         SurfaceIntersection rec;
         const bool hit = scene.closestHit(Ray(Vec3(0.1f, 0.2f, 8), Vec3(0, 0, -1)), Interval(0.001f, INF), rec);
         const bool shadow = scene.anyHit(Ray(Vec3(0.1f, 0.2f, 8), Vec3(0, 0, -1)), Interval(0.0f, 5.0f));
-        std::printf("hash %08x samples %d hit %d t %.3f shadow %d radius %.4f\n", h, camera.currentSample_.load(), (int) hit, rec.t, (int) shadow,
-                    scene.getSceneRadius());
+        const AABB box = scene.bounds();            // scene.hpp:71-74
+        std::printf("hash %08x samples %d hit %d t %.3f shadow %d radius %.4f boundsmin %g,%g,%g boundsmax %g,%g,%g\n", h, camera.currentSample_.load(),
+                    (int) hit, rec.t, (int) shadow, scene.getSceneRadius(), box.pmin.x, box.pmin.y, box.pmin.z, box.pmax.x, box.pmax.y, box.pmax.z);
         // DynamicCamera (the UI's progressive camera): non-blocking render, restart on a camera change
         DynamicCamera dyn(64, 64, scene.cameraProperties, 2, 2, 4, 1);
         dyn.render(scene); dyn.wait();
