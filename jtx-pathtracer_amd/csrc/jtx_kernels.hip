@@ -25,6 +25,9 @@ namespace jtx {
 #ifndef JTX_RP_OCC
 #define JTX_RP_OCC 7
 #endif
+#ifndef JTX_NT_RAD
+#define JTX_NT_RAD 0
+#endif
 #ifndef JTX_WIDE_OCC
 #define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
 #endif
@@ -36,7 +39,11 @@ constexpr int BLOCKS_PER_TILE = 16 / WAVES_PER_BLOCK;   // a 32x32 tile = 16 wav
 JD void stageScene(const DevScene &sc, float4 *lds_tnodes, float4 *lds_tris) {
     const int nn = 2 * 8 * sc.num_nodes, nt = 3 * sc.num_prims;
     for (int i = threadIdx.x; i < nn; i += BLOCK) lds_tnodes[(i & 1) * (nn >> 1) + (i >> 1)] = sc.tnodes[i];   // LdsSrc: halves apart
+#if JTX_LDS_PLANES
+    for (int i = threadIdx.x; i < nt; i += BLOCK) lds_tris[(i % 3) * sc.num_prims + i / 3] = sc.tris[i];   // LdsSrc / LeafSrc: three planes
+#else
     for (int i = threadIdx.x; i < nt; i += BLOCK) lds_tris[i] = sc.tris[i];
+#endif
     __syncthreads();
 }
 
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
             bool done;
-            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
+            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes; src.np = sc.num_prims;
                                   done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
             else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BLOCK;
@@ -285,7 +292,11 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     const int lwPad = (sc.lw_leaves + 3) & ~3;
     unsigned *lds_tab = (unsigned *) (lds_lbox + 2 * lwPad);
     if (SRC == SRC_LEAF) {
+#if JTX_LDS_PLANES
+        for (int i = threadIdx.x; i < 2 * lwPad; i += BS) lds_lbox[(i & 1) * lwPad + (i >> 1)] = sc.lw_box[i];   // halves apart
+#else
         for (int i = threadIdx.x; i < 2 * lwPad; i += BS) lds_lbox[i] = sc.lw_box[i];
+#endif
         for (int i = threadIdx.x; i < 128; i += BS) lds_tab[i] = sc.lw_tab[i];
     }
     if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);
@@ -369,10 +380,10 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
         // ---- one bounce of every live path ----
         if (alive) {
             bool done;
-            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
+            if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes; src.np = sc.num_prims;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
             else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
-                                  src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves;
+                                  src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
             else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS;
@@ -384,7 +395,15 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                 if (c.x > 1.0f) c.x = 1.0f;
                 if (c.y > 1.0f) c.y = 1.0f;
                 if (c.z > 1.0f) c.z = 1.0f;
+#if JTX_NT_RAD
+                {   // written once, read once by the resolve pass: streamed, so that 2 GB of records do not wash the BVH out of L2
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    nt4 v; v.x = c.x; v.y = c.y; v.z = c.z; v.w = 0.0f;
+                    __builtin_nontemporal_store(v, (nt4 *) (p.rad + (size_t) (s - p.sample_begin) * p.rad_stride + slot));
+                }
+#else
                 p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot] = make_float4(c.x, c.y, c.z, 0.0f);
+#endif
                 alive = false; need = true;
             }
         }

@@ -75,11 +75,21 @@ struct GlobalSrc {
 // halves]): a ds_read_b128 serves 16 lanes at a time over 64 banks, and with interleaved 32-B records every first half
 // starts on an even bank quad -- 8 positions for 16 lanes, a 2-way conflict at best; split, a half of record i sits on
 // quad i mod 16 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the C2 kernel: 28 % interleaved).
+// The same for the triangles (JTX_LDS_PLANES): three float4 planes [all first granules][all second][all third] -- record i of a plane on
+// bank quad i mod 16 -- instead of 48-byte records (granule h of triangle i on quad (3 i + h) mod 16).
+#ifndef JTX_LDS_PLANES
+#define JTX_LDS_PLANES 1
+#endif
 struct LdsSrc {
     const float4 *tnodes, *tris;
     int half;             // records per half array = 8 * num_nodes
+    int np;               // triangles (plane stride)
     JD float4 tnode(int i, int h) const { return tnodes[h * half + i]; }
+#if JTX_LDS_PLANES
+    JD float4 tri(int i, int h) const { return tris[h * np + i]; }
+#else
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
+#endif
 };
 
 struct HitRec { float t; int prim; float b1, b2; };
@@ -139,6 +149,16 @@ JD bool slabRegular(const float4 na, const float4 nb, f3 o, f3 inv, float tmin, 
     const float az = (nb.x - o.z) * inv.z, bz = (nb.y - o.z) * inv.z;
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return t0 <= t1;
+}
+
+// ... with t.max = +inf (closestHit's open interval): min(x, +inf) == x for every non-NaN x, one instruction less per box
+JD bool slabRegularOpen(const float4 na, const float4 nb, f3 o, f3 inv, float tmin) {
+    const float ax = (na.x - o.x) * inv.x, bx = (na.y - o.x) * inv.x;
+    const float ay = (na.z - o.y) * inv.y, by = (na.w - o.y) * inv.y;
+    const float az = (nb.x - o.z) * inv.z, bz = (nb.y - o.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     return t0 <= t1;
 }
 
@@ -483,8 +503,15 @@ struct LeafSrc {
     const float4 *gbox;                             // the same in HBM: read with wave-uniform indices -> scalar loads
     const unsigned *tab;                            // LDS copy of the order / position tables
     int nleaf;
+    int np, lpad;                                   // triangles (plane stride); padded leaf count (stride between the halves of lbox)
     JD float4 tnode(int i, int h) const { return tnodes[h * half + i]; }
+#if JTX_LDS_PLANES
+    JD float4 tri(int i, int h) const { return tris[h * np + i]; }
+    JD float4 leafbox(int leaf, int h) const { return lbox[h * lpad + leaf]; }
+#else
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
+    JD float4 leafbox(int leaf, int h) const { return lbox[2 * leaf + h]; }
+#endif
 };
 
 template <bool ANY>
@@ -505,6 +532,9 @@ JD bool traverseLeaves(const LeafSrc &src, f3 o, f3 d, f3 inv, int negmask, floa
     typedef const float *CBox;
 #endif
     const CBox cb = (CBox) (const void *) src.gbox;
+    // closestHit's interval is open-ended (integrator.cpp:181: Interval(0.001, INF)): min(x, +inf) == x for the non-NaN x of a
+    // regular ray, so the t.max operand is dropped -- the compiler cannot (fminf(NaN, inf) is inf)
+    const bool openEnd = !ANY && tmax == __builtin_inff();
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         if (4 * g < n) {                                                         // wave-uniform
@@ -513,7 +543,7 @@ JD bool traverseLeaves(const LeafSrc &src, f3 o, f3 d, f3 inv, int negmask, floa
                 const int i = 4 * g + j;
                 const float4 na = make_float4(cb[8 * i], cb[8 * i + 1], cb[8 * i + 2], cb[8 * i + 3]);
                 const float4 nb = make_float4(cb[8 * i + 4], cb[8 * i + 5], 0.0f, 0.0f);
-                const bool pass = slabRegular(na, nb, o, inv, tmin, tmax);
+                const bool pass = openEnd ? slabRegularOpen(na, nb, o, inv, tmin) : slabRegular(na, nb, o, inv, tmin, tmax);
                 const unsigned at = ANY ? (unsigned) i : (pos[i >> 2] >> (8 * (i & 3))) & 0xffu;
                 pm |= (pass ? 1u : 0u) << at;
             }
@@ -528,7 +558,7 @@ JD bool traverseLeaves(const LeafSrc &src, f3 o, f3 d, f3 inv, int negmask, floa
                 const int k = __builtin_ctz(pm);
                 pm &= pm - 1u;
                 const int leaf = ANY ? k : (int) ((row[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                const float4 la = src.lbox[2 * leaf], lb = src.lbox[2 * leaf + 1];
+                const float4 la = src.leafbox(leaf, 0), lb = src.leafbox(leaf, 1);
                 bool pass = true;
                 if (!ANY && shrunk) pass = slabRegular(la, lb, o, inv, tmin, tmax);
                 if (pass) { leafOff = __float_as_int(lb.z); leafN = __float_as_int(lb.w); }
