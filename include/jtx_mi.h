@@ -139,6 +139,7 @@ typedef struct {
     int32_t resident_workgroups;   /* workgroups of the persistent k_render_paths grid for this scene on this device (upper limit: a launch
                                     * never has more workgroups than chunks) */
     int32_t workgroup_size;   /* lanes per workgroup of that kernel: 256 when the scene is staged in LDS, 64 otherwise */
+    int32_t device_built;     /* != 0: the tree comes from jtx_mi_scene_rebuild (the reference's tree, node for node and primitive for primitive) */
 } jtx_mi_scene_info;
 
 typedef struct jtx_mi_scene jtx_mi_scene;
@@ -195,6 +196,15 @@ void jtx_mi_scene_destroy(jtx_mi_scene *scene);                      /* Scene::d
  * jtx_mi_scene_create on the edited description gives the reference-identical tree). */
 int  jtx_mi_scene_set_transform(jtx_mi_scene *scene, int32_t mesh, const float *m16);
 int  jtx_mi_scene_refit(jtx_mi_scene *scene);
+/* Scene::rebuildBVH(maxPrimsInNode) (scene.hpp:66-69) after transform edits, ON THE DEVICE: a NEW topology for the edited geometry.
+ * The binned-SAH build of bvh.cpp:9-133 runs breadth first over the resident primitives (12 centroid buckets, 11 split costs, the
+ * reference's fp32 arithmetic for every decision; jtx_build_dev.hip) and gives the reference's tree node for node: boxes, split
+ * axes, child order, leaves, flattenBVH's depth-first numbering (bvh.cpp:135-149) -- and primitive for primitive: std::partition's
+ * swaps are a function of the predicate flags alone and are replayed in parallel, so Scene::triangles_ comes out in the order the
+ * host build (libstdc++) gives.  Everything derived from the tree follows on the device (the 8 stackless
+ * orderings, the 8-ary quantised nodes with their surface-area cut, triangle / shading records, refit sources).
+ * max_prims_in_node <= 0: 1. */
+int  jtx_mi_scene_rebuild(jtx_mi_scene *scene, int32_t max_prims_in_node);
 int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
 int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
 

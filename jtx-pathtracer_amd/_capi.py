@@ -77,7 +77,7 @@ class SceneInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("num_prims", C.c_int32), ("max_depth", C.c_int32),
                 ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("auto_integrator", C.c_int32),
                 ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32), ("refitted", C.c_int32),
-                ("num_cus", C.c_int32), ("resident_workgroups", C.c_int32), ("workgroup_size", C.c_int32)]
+                ("num_cus", C.c_int32), ("resident_workgroups", C.c_int32), ("workgroup_size", C.c_int32), ("device_built", C.c_int32)]
 
 
 CANCELLED = 2          # JTX_MI_CANCELLED
@@ -105,6 +105,7 @@ SYMBOLS = {
     "jtx_mi_decode_exr": (C.c_int, [_u8, C.c_int64, P(C.c_int32), P(C.c_int32), P(C.c_float), C.c_int64]),
     "jtx_mi_scene_set_transform": (C.c_int, [_scene, C.c_int32, _f]),
     "jtx_mi_scene_refit": (C.c_int, [_scene]),
+    "jtx_mi_scene_rebuild": (C.c_int, [_scene, C.c_int32]),
     "jtx_mi_cancel": (C.c_int, [_scene]),
     "jtx_mi_pin_host": (C.c_int, [C.c_void_p, C.c_uint64]),
     "jtx_mi_unpin_host": (C.c_int, [C.c_void_p]),

@@ -72,7 +72,7 @@ class Scene:
         return dict(num_nodes=i.num_nodes, num_prims=i.num_prims, max_depth=i.max_depth,
                     lds_resident=bool(i.lds_resident), scene_radius=float(i.scene_radius),
                     auto_integrator=int(i.auto_integrator), wide_depth=int(i.wide_depth), wide_bytes=int(i.wide_bytes),
-                    device_bytes=int(i.device_bytes), refitted=bool(i.refitted),
+                    device_bytes=int(i.device_bytes), refitted=bool(i.refitted), device_built=bool(i.device_built),
                     num_cus=int(i.num_cus), resident_workgroups=int(i.resident_workgroups), workgroup_size=int(i.workgroup_size))
 
     # -- transform edits (display.cpp:545-588): new Mesh::transform per mesh, then a device refit (topology kept)
@@ -83,6 +83,11 @@ class Scene:
 
     def refit(self):
         check(self._lib.jtx_mi_scene_refit(self.handle))
+
+    def rebuildBVHOnDevice(self, maxPrimsInNode=1):
+        """Scene::rebuildBVH after setTransform edits without leaving the device (jtx_mi_scene_rebuild): the reference's
+        binned-SAH tree for the edited geometry, node for node and primitive for primitive (`device_built` records where it was built)."""
+        check(self._lib.jtx_mi_scene_rebuild(self.handle, int(maxPrimsInNode)))
 
     def bvh(self):
         i = self.info()

@@ -45,7 +45,7 @@ struct Bounds {
 };
 
 struct Prim {
-    int index, mesh;
+    int index, mesh, orig;
     Bounds b;
     float centroid(int a) const { return 0.5f * b.lo[a] + 0.5f * b.hi[a]; }   // mesh.hpp:207-209
 };
@@ -179,7 +179,7 @@ void buildBVH(const jtx_mi_scene_desc &d, BvhResult &out) {
         }
         float v0[3], v1[3], v2[3];
         meshVertices(m, r.index, v0, v1, v2);
-        work[i].index = r.index; work[i].mesh = r.mesh_index;
+        work[i].index = r.index; work[i].mesh = r.mesh_index; work[i].orig = (int) i;
         work[i].b = Bounds(); work[i].b.grow(v0); work[i].b.grow(v1); work[i].b.grow(v2);   // tBounds mesh.hpp:79-84
     }
     Subtree tree;
@@ -190,8 +190,8 @@ void buildBVH(const jtx_mi_scene_desc &d, BvhResult &out) {
     if (n) b.build(tree, work.data(), n, 0);
     out.nodes = std::move(tree.nodes);
     out.max_depth = tree.maxDepth;
-    out.refs.resize(n);
-    for (size_t i = 0; i < n; ++i) out.refs[i] = jtx_mi_tri_ref{tree.ordered[i].index, tree.ordered[i].mesh};
+    out.refs.resize(n); out.orig.resize(n);
+    for (size_t i = 0; i < n; ++i) { out.refs[i] = jtx_mi_tri_ref{tree.ordered[i].index, tree.ordered[i].mesh}; out.orig[i] = tree.ordered[i].orig; }
     out.scene_radius = 0;
     if (!out.nodes.empty()) {                                        // getSceneRadius scene.hpp:81-84
         const jtx_mi_bvh_node &r = out.nodes[0];

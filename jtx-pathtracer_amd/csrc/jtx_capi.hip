@@ -35,6 +35,7 @@ template <class T> struct DevBuf {
     void alloc(size_t count) { release(); n = count; if (count) HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); }
     void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
     void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     ~DevBuf() { release(); }
 };
 
@@ -88,7 +89,8 @@ struct jtx_mi_scene {
     DevBuf<int> leaf_nodes, level_nodes, rec_node, wide_map, wide_fail;
     std::vector<float> mesh_xf_host;
     std::vector<int> level_begin;    // per interior depth: offsets into level_nodes
-    int num_leaves = 0, num_wide = 0, refitted = 0;
+    DevBuf<int> orig_id;             // per BVH-ordered primitive: its index in the scene's own Scene::triangles (input order of a device rebuild)
+    int num_leaves = 0, num_wide = 0, refitted = 0, device_built = 0;
     bool xf_dirty = false;
     DevBuf<float4> lw_box; DevBuf<unsigned> lw_tab;   // flat leaf list of tiny scenes (traverseLeaves)
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
@@ -357,6 +359,45 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
     return wb.ok;
 }
 
+// Tiny scenes: the flat leaf list of traverseLeaves (leaves in b.nodes order; per octant: leaf at position p, position of
+// leaf l -- read off the threaded orderings).  pos[k * nn + g]: node g's place in octant k's order.
+void buildLeafTables(jtx_mi_scene &s, const std::vector<int> &pos) {
+    const jtxh::BvhResult &b = s.bvh;
+    const size_t nn = b.nodes.size();
+    s.lw_box.release(); s.lw_tab.release(); s.dev.lw_box = nullptr; s.dev.lw_tab = nullptr; s.dev.lw_leaves = 0;
+    {
+        std::vector<int> leafId(nn, -1); int nl = 0;
+        for (size_t i = 0; i < nn; ++i) if (b.nodes[i].num_prims) leafId[i] = nl++;
+        if (nl > 0 && nl <= 32 && nn > 1) {
+            const int npad = (nl + 3) & ~3;                                     // phase A of traverseLeaves runs in groups of four
+            std::vector<float4> lb(2 * (size_t) npad, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (size_t i = 0; i < nn; ++i) if (leafId[i] >= 0) {
+                const jtx_mi_bvh_node &n = b.nodes[i];
+                const int z = n.offset, w = n.num_prims; float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
+                lb[2 * (size_t) leafId[i]] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
+                lb[2 * (size_t) leafId[i] + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
+            }
+            std::vector<unsigned> tab(128, 0u);
+            for (int k = 0; k < 8; ++k) {
+                std::vector<int> at(nn, -1);                                    // node standing at position i of octant k's order
+                for (size_t g = 0; g < nn; ++g) at[(size_t) pos[(size_t) k * nn + g]] = (int) g;
+                int p2 = 0;
+                for (size_t i = 0; i < nn; ++i) {
+                    const int l = leafId[at[i]];
+                    if (l < 0) continue;
+                    tab[16 * k + (p2 >> 2)] |= (unsigned) l << (8 * (p2 & 3));                    // leaf visited at position p2
+                    tab[16 * k + 8 + (l >> 2)] |= (unsigned) p2 << (8 * (l & 3));                 // position of leaf l
+                    ++p2;
+                }
+                for (int l = nl; l < npad; ++l) tab[16 * k + 8 + (l >> 2)] |= (unsigned) l << (8 * (l & 3));   // padding: positions >= nl
+            }
+            s.lw_box.upload(lb); s.lw_tab.upload(tab);
+            s.dev.lw_box = s.lw_box.p; s.dev.lw_tab = s.lw_tab.p; s.dev.lw_leaves = nl;
+        }
+    }
+
+}
+
 // Flatten the scene into the kernel layout documented in jtx_scene_dev.hpp.
 void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     const jtxh::BvhResult &b = s.bvh;
@@ -432,6 +473,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
             src[5 * i + 4] = make_float4(q2[1], q2[2], fm, 0.f);
         });
         s.prim_src.upload(src);
+        s.orig_id.upload(b.orig);
         s.pbox.alloc(2 * np);
         s.mesh_xf_host.assign((size_t) 16 * d.num_meshes, 0.f);
         for (int i = 0; i < d.num_meshes; ++i) std::memcpy(&s.mesh_xf_host[16 * (size_t) i], d.meshes[i].transform, 16 * sizeof(float));
@@ -503,39 +545,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         if (err) std::rethrow_exception(err);
     }
     s.dev.tnodes = s.tnodes.p;
-    // ---- tiny scenes: the flat leaf list of traverseLeaves (leaves in b.nodes order; per octant: leaf at position p,
-    //      position of leaf l -- read off the threaded orderings) ----
-    s.lw_box.release(); s.lw_tab.release(); s.dev.lw_box = nullptr; s.dev.lw_tab = nullptr; s.dev.lw_leaves = 0;
-    {
-        std::vector<int> leafId(nn, -1); int nl = 0;
-        for (size_t i = 0; i < nn; ++i) if (b.nodes[i].num_prims) leafId[i] = nl++;
-        if (nl > 0 && nl <= 32 && nn > 1) {
-            const int npad = (nl + 3) & ~3;                                     // phase A of traverseLeaves runs in groups of four
-            std::vector<float4> lb(2 * (size_t) npad, make_float4(0.f, 0.f, 0.f, 0.f));
-            for (size_t i = 0; i < nn; ++i) if (leafId[i] >= 0) {
-                const jtx_mi_bvh_node &n = b.nodes[i];
-                const int z = n.offset, w = n.num_prims; float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
-                lb[2 * (size_t) leafId[i]] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
-                lb[2 * (size_t) leafId[i] + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
-            }
-            std::vector<unsigned> tab(128, 0u);
-            for (int k = 0; k < 8; ++k) {
-                std::vector<int> at(nn, -1);                                    // node standing at position i of octant k's order
-                for (size_t g = 0; g < nn; ++g) at[(size_t) pos[(size_t) k * nn + g]] = (int) g;
-                int p2 = 0;
-                for (size_t i = 0; i < nn; ++i) {
-                    const int l = leafId[at[i]];
-                    if (l < 0) continue;
-                    tab[16 * k + (p2 >> 2)] |= (unsigned) l << (8 * (p2 & 3));                    // leaf visited at position p2
-                    tab[16 * k + 8 + (l >> 2)] |= (unsigned) p2 << (8 * (l & 3));                 // position of leaf l
-                    ++p2;
-                }
-                for (int l = nl; l < npad; ++l) tab[16 * k + 8 + (l >> 2)] |= (unsigned) l << (8 * (l & 3));   // padding: positions >= nl
-            }
-            s.lw_box.upload(lb); s.lw_tab.upload(tab);
-            s.dev.lw_box = s.lw_box.p; s.dev.lw_tab = s.lw_tab.p; s.dev.lw_leaves = nl;
-        }
-    }
+    buildLeafTables(s, pos);
 
     // ---- wide (8-ary, quantised) nodes for the uncounted kernels of HBM-resident scenes (traverseWide) ----
     s.wide.release(); s.dev.wide = nullptr; s.dev.wide_depth = 0;
@@ -1048,6 +1058,108 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 
+// Scene::rebuildBVH (scene.hpp:66-69) in the edit loop (display.cpp:545-588, 902-905), ON THE DEVICE: a new TOPOLOGY for the
+// edited geometry -- the reference's binned-SAH tree, node for node (jtx_build_dev.hip) -- and every structure derived from it.
+int jtx_mi_scene_rebuild(jtx_mi_scene *s, int32_t max_prims_in_node) {
+    try {
+        if (!s) throw std::runtime_error("null scene");
+        DeviceGuard dg(s->device);
+        std::lock_guard<std::mutex> lk(s->mu);
+        const int np = s->dev.num_prims;
+        if (np == 0) return 0;
+        const bool trace = getenv("JTX_TRACE_CREATE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!trace) return;
+            HIPCHK(hipStreamSynchronize(s->stream));
+            const auto n = std::chrono::steady_clock::now();
+            fprintf(stderr, "[jtx rebuild] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count());
+            t0 = n;
+        };
+        HIPCHK(hipStreamSynchronize(s->stream));                  // frames in flight read the buffers that are replaced below
+        HIPCHK(hipMemcpyAsync(s->mesh_xf.p, s->mesh_xf_host.data(), s->mesh_xf_host.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        const size_t maxN = 2 * (size_t) np;
+        DevBuf<float4> src2, tris2, shade2, nbox2; DevBuf<int> orig2, order, leaves2, levels2, pos, size, map2; DevBuf<uint4> wide2;
+        DevBuf<jtx_mi_bvh_node> hn;
+        src2.alloc(5 * (size_t) np); tris2.alloc(3 * (size_t) np); shade2.alloc(4 * (size_t) np); orig2.alloc(np); order.alloc(np);
+        nbox2.alloc(2 * maxN); hn.alloc(maxN); leaves2.alloc(maxN); levels2.alloc(maxN); pos.alloc(8 * maxN); size.alloc(maxN);
+        const char *off = getenv("JTX_NO_WIDE");
+        const bool wantWide = !(off && atoi(off));
+        const size_t wideCap = 6 * (size_t) np + 2 * (size_t) np + 8;     // every interior node its own wide node at worst
+        if (wantWide) { wide2.alloc(wideCap); map2.alloc(16 * (size_t) np); }
+        lap("allocate");
+        DevBuildBuffers B{};
+        B.prim_src = s->prim_src.p; B.tris = s->tris.p; B.shade = s->shade.p; B.orig = s->orig_id.p; B.mesh_xf = s->mesh_xf.p; B.np = np;
+        B.max_prims = max_prims_in_node > 0 ? max_prims_in_node : 1;
+        B.prim_src_out = src2.p; B.tris_out = tris2.p; B.shade_out = shade2.p; B.orig_out = orig2.p;
+        B.nbox = nbox2.p; B.hnodes = hn.p; B.order = order.p; B.leaf_nodes = leaves2.p; B.level_nodes = levels2.p; B.pos = pos.p; B.size = size.p;
+        B.wide = wantWide ? wide2.p : nullptr; B.wide_map = map2.p; B.wide_cap = wideCap;
+        DevBuildResult R;
+        HIPCHK(jtx_device_build(B, R, s->stream));
+        lap("device build");
+        const int nn = R.nn;
+        // ---- the host's copy: nodes, Scene::triangles_ in leaf order ----
+        std::vector<int> ord(np);
+        s->bvh.nodes.resize(nn);
+        HIPCHK(hipMemcpyAsync(s->bvh.nodes.data(), hn.p, (size_t) nn * sizeof(jtx_mi_bvh_node), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(ord.data(), order.p, (size_t) np * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        // ---- swap the new structures in; triangle / shading records recomputed from the re-ordered sources ----
+        s->prim_src.swap(src2); s->tris.swap(tris2); s->shade.swap(shade2); s->orig_id.swap(orig2);
+        s->nbox.swap(nbox2); s->leaf_nodes.swap(leaves2); s->level_nodes.swap(levels2);
+        if ((size_t) s->pbox.n < 2 * (size_t) np) s->pbox.alloc(2 * (size_t) np);
+        s->tnodes.alloc(2 * 8 * (size_t) nn); s->rec_node.alloc(8 * (size_t) nn);
+        RefitArgs a{};
+        a.prim_src = s->prim_src.p; a.mesh_xf = s->mesh_xf.p; a.tris = s->tris.p; a.shade = s->shade.p; a.pbox = s->pbox.p; a.num_prims = np;
+        HIPCHK(jtx_launch_refit_prims(a, s->stream));
+        HIPCHK(jtx_launch_build_threaded(s->nbox.p, pos.p, size.p, nn, s->tnodes.p, s->rec_node.p, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        lap("records, 8 threaded orderings");
+        {
+            std::vector<jtx_mi_tri_ref> refs(np); std::vector<int32_t> orig(np);
+            for (int i = 0; i < np; ++i) { refs[i] = s->bvh.refs[ord[i]]; orig[i] = s->bvh.orig[ord[i]]; }
+            s->bvh.refs.swap(refs); s->bvh.orig.swap(orig);
+        }
+        s->bvh.max_depth = R.max_depth;
+        s->level_begin = R.level_begin;
+        s->num_leaves = R.nleaves;
+        s->dev.tnodes = s->tnodes.p; s->dev.tris = s->tris.p; s->dev.shade = s->shade.p;
+        s->dev.num_nodes = nn;
+        s->dev.lds_threaded = (nn > 0 && 8 * (size_t) nn * 32 + (size_t) np * 48 <= kLdsThreadedBudget) ? 1 : 0;
+        // ---- 8-ary nodes ----
+        s->dev.wide = nullptr; s->dev.wide_depth = 0; s->num_wide = 0;
+        if (wantWide && R.wide_ok && R.wide_depth <= kMaxWideDepth) {
+            s->wide.swap(wide2); s->wide_map.swap(map2);
+            s->wide.n = R.wide_granules;                                    // (the allocation is larger; n = granules in use, as after a host build)
+            s->dev.wide = s->wide.p; s->dev.wide_depth = R.wide_depth; s->num_wide = R.num_wide;
+        }
+        if (!s->wide_fail.p) s->wide_fail.alloc(1);
+        // ---- tiny scenes: the flat leaf list needs the positions on the host ----
+        {
+            int nl = 0; for (const jtx_mi_bvh_node &n : s->bvh.nodes) if (n.num_prims) ++nl;
+            std::vector<int> hpos;
+            if (nl > 0 && nl <= 32 && nn > 1) { hpos.resize(8 * (size_t) nn); HIPCHK(hipMemcpy(hpos.data(), pos.p, hpos.size() * sizeof(int), hipMemcpyDeviceToHost)); }
+            else hpos.assign(8 * (size_t) nn, 0);
+            buildLeafTables(*s, hpos);
+        }
+        // ---- scene radius (scene.hpp:81-84) and with it the DISTANT lights (scene.cpp:128-134) ----
+        {
+            const jtx_mi_bvh_node &r = s->bvh.nodes[0];
+            const float dx = r.pmax[0] - r.pmin[0], dy = r.pmax[1] - r.pmin[1], dz = r.pmax[2] - r.pmin[2];
+            s->bvh.scene_radius = std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
+            if (s->lights.n) {
+                std::vector<DLight> ls(s->lights.n);
+                HIPCHK(hipMemcpy(ls.data(), s->lights.p, ls.size() * sizeof(DLight), hipMemcpyDeviceToHost));
+                bool any = false;
+                for (auto &l : ls) if (l.type == 1) { l.scene_radius = s->bvh.scene_radius; any = true; }
+                if (any) HIPCHK(hipMemcpy(s->lights.p, ls.data(), ls.size() * sizeof(DLight), hipMemcpyHostToDevice));
+            }
+        }
+        s->refitted = 0; s->device_built = 1; s->xf_dirty = false;
+        lap("host copies, lights");
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
+
 int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     if (!s || !out) return fail("null argument");
     out->num_nodes = s->dev.num_nodes; out->num_prims = s->dev.num_prims; out->max_depth = s->bvh.max_depth;
@@ -1055,6 +1167,7 @@ int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     out->auto_integrator = autoIntegrator(*s);
     out->wide_depth = s->dev.wide_depth; out->wide_bytes = (int32_t) (s->wide.n * sizeof(uint4));
     out->refitted = s->refitted;
+    out->device_built = s->device_built;
     out->num_cus = s->num_cus;
     { int bs = 0; out->resident_workgroups = jtx_render_paths_grid(s->dev, s->num_cus, &bs); out->workgroup_size = bs; }
     return 0;

@@ -2,6 +2,7 @@
 // the C-ABI implementation (jtx_capi.hip).
 #pragma once
 #include "jtx_scene_dev.hpp"
+#include <vector>
 
 #ifndef JTX_RP_BLOCK
 #define JTX_RP_BLOCK 256      // threads per workgroup of the render kernels (4 waves = 4 of the 16 8x8 pixel blocks of a tile)
@@ -82,6 +83,23 @@ struct RefitArgs {
 
 } // namespace jtx
 
+// ---- device BVH build (jtx_build_dev.hip): Scene::rebuildBVH on the device ----
+namespace jtx {
+struct DevBuildBuffers {               // caller-allocated device buffers, sized for np primitives / 2 np nodes
+    // in: the primitives in their current order
+    const float4 *prim_src, *tris, *shade; const int *orig; const float *mesh_xf; int np, max_prims;
+    // out: the primitives in the new leaf order, the nodes in depth-first order, lists for the refit / threading stages
+    float4 *prim_src_out, *tris_out, *shade_out; int *orig_out;
+    float4 *nbox; void *hnodes; int *order; int *leaf_nodes, *level_nodes; int *pos, *size;
+    uint4 *wide; int *wide_map; size_t wide_cap;     // wide == nullptr: no 8-ary nodes wanted
+};
+struct DevBuildResult {
+    int nn = 0, nleaves = 0, max_depth = 0, num_wide = 0, wide_depth = 0; size_t wide_granules = 0; bool wide_ok = false;
+    std::vector<int> level_begin;      // interior nodes by depth: offsets into level_nodes
+};
+} // namespace jtx
+hipError_t jtx_device_build(const jtx::DevBuildBuffers &b, jtx::DevBuildResult &r, hipStream_t st);
+hipError_t jtx_launch_refit_prims(const jtx::RefitArgs &a, hipStream_t st);
 hipError_t jtx_launch_build_threaded(const float4 *nbox, const int *pos, const int *size, int nn, float4 *tnodes, int *rec_node, hipStream_t st);
 hipError_t jtx_launch_refit(const jtx::RefitArgs &a, const int *level_begin, int num_levels, hipStream_t st);
 hipError_t jtx_wf_generate(const jtx::WfParams &p, int s0, int nstrata, hipStream_t st);

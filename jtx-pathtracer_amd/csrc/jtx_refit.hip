@@ -176,6 +176,11 @@ hipError_t jtx_launch_refit(const RefitArgs &a, const int *level_begin, int num_
     return hipGetLastError();
 }
 
+hipError_t jtx_launch_refit_prims(const RefitArgs &a, hipStream_t st) {
+    if (a.num_prims) hipLaunchKernelGGL(k_refit_prims, dim3((unsigned) ((a.num_prims + 255) / 256)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t jtx_launch_build_threaded(const float4 *nbox, const int *pos, const int *size, int nn, float4 *tnodes, int *rec_node, hipStream_t st) {
     if (nn <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_build_threaded, dim3((unsigned) ((nn + 255) / 256)), dim3(256), 0, st, nbox, pos, size, nn, tnodes, rec_node);

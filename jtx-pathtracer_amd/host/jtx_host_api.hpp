@@ -128,6 +128,16 @@ public:
         jtx_mi_scene_info info; check(jtx_mi_scene_get_info(handle_, &info));
         for (auto &l : lights) if (l.type == Light::DISTANT) l.sceneRadius = info.scene_radius;
     }
+    // Scene::rebuildBVH for the edit loop without the host: the edited transforms go to the device, where the reference's
+    // binned-SAH tree (bvh.cpp:9-133) is built anew, node for node and primitive for primitive, with everything derived from it
+    // (jtx_mi_scene_rebuild).  Single-device scenes only.
+    void rebuildBVHOnDevice(int maxPrimsInNode = 1) {
+        if (!handle_) { buildBVH(maxPrimsInNode); return; }
+        for (size_t i = 0; i < meshes.size(); ++i) check(jtx_mi_scene_set_transform(handle_, (int) i, &meshes[i].transform.m[0][0]));
+        check(jtx_mi_scene_rebuild(handle_, maxPrimsInNode));
+        jtx_mi_scene_info info; check(jtx_mi_scene_get_info(handle_, &info));
+        for (auto &l : lights) if (l.type == Light::DISTANT) l.sceneRadius = info.scene_radius;
+    }
     void destroy() { destroyBVH(); }                                  // mesh arrays stay with the caller
     AABB bounds() const {                                             // scene.hpp:71-74: the root node's box (after a refit: the refitted one)
         AABB b;

@@ -33,6 +33,14 @@ int main() {
         const AABB box = scene.bounds();            // scene.hpp:71-74
         std::printf("hash %08x samples %d hit %d t %.3f shadow %d radius %.4f boundsmin %g,%g,%g boundsmax %g,%g,%g\n", h, camera.currentSample_.load(),
                     (int) hit, rec.t, (int) shadow, scene.getSceneRadius(), box.pmin.x, box.pmin.y, box.pmin.z, box.pmax.x, box.pmax.y, box.pmax.z);
+        // the edit loop without the host (display.cpp:902-905): Scene::rebuildBVH on the device, same frame
+        scene.rebuildBVHOnDevice();
+        StaticCamera again(64, 64, scene.cameraProperties, 2, 2, 4);
+        again.renderFinal(scene);
+        unsigned hr = 2166136261u;
+        const unsigned char *br = &again.img_.data()[0].R;
+        for (int i = 0; i < 64 * 64 * 3; ++i) { hr ^= br[i]; hr *= 16777619u; }
+        std::printf("rebuildhash %08x\n", hr);
         // DynamicCamera (the UI's progressive camera): non-blocking render, restart on a camera change
         DynamicCamera dyn(64, 64, scene.cameraProperties, 2, 2, 4, 1);
         dyn.render(scene); dyn.wait();

@@ -318,6 +318,7 @@ def test_cpp_host_mirror_reproduces_reference_probe(gpu, tmp_path):
     assert kv["samples"] == "4" and kv["hit"] == "1" and kv["shadow"] == "0"
     assert abs(float(kv["t"]) - 9.0) < 1e-5 and abs(float(kv["radius"]) - 2 ** 0.5) < 1e-4
     assert kv["boundsmin"] == "-1,-1,-1" and kv["boundsmax"] == "1,1,-1"    # Scene::bounds() (scene.hpp:71-74): the quad's box
+    assert kv["rebuildhash"] == "1af9ba89"                                  # Scene::rebuildBVHOnDevice (jtx_mi_scene_rebuild)
     # DynamicCamera: same image as the static render; a restarted render equals a static one from the new camera
     assert kv["dynhash"] == "1af9ba89" and kv["dynsamples"] == "4" and kv["restart_same"] == "1"
     assert kv["multihash"] == "1af9ba89" and kv["multisamples"] == "4"      # 3 shards through jtx_mi_multi_render
@@ -1171,6 +1172,72 @@ def _edit(gpu, data, seed):
         tr = np.eye(4, dtype=np.float32); tr[:3, 3] = rs.uniform(-25, 25, 3)
         out[int(mi)] = (tr @ rot @ sc).astype(np.float32)
     return out
+
+
+def _same_tree(n0, r0, n1, r1, what):
+    """node for node: boxes, child links / leaf ranges, split axes; and Scene::triangles_ in the same order"""
+    assert len(n0) == len(n1), f"{what}: {len(n0)} vs {len(n1)} nodes"
+    assert (n0["pmin"] == n1["pmin"]).all() and (n0["pmax"] == n1["pmax"]).all(), f"{what}: boxes differ"
+    assert (n0["offset"] == n1["offset"]).all() and (n0["num_prims"] == n1["num_prims"]).all(), f"{what}: links / leaf ranges differ"
+    inner = n0["num_prims"] == 0
+    assert (n0["axis"][inner] == n1["axis"][inner]).all(), f"{what}: split axes differ"
+    assert (r0["index"] == r1["index"]).all() and (r0["mesh_index"] == r1["mesh_index"]).all(), f"{what}: primitive order differs"
+
+
+@pytest.mark.parametrize("which,max_prims", [("cornell", 1), ("mixed", 1), ("atrium", 1), ("atrium", 4), ("quads", 2)])
+def test_device_rebuild_gives_the_reference_tree(gpu, which, max_prims):
+    """jtx_mi_scene_rebuild (SURVEY 8f-2, Scene::rebuildBVH on the device, csrc/jtx_build_dev.hip): (a) rebuilding an unedited
+    scene gives the host builder's tree -- the reference's (bvh.cpp:9-149) -- node for node AND primitive for primitive
+    (std::partition's order included: the atrium keeps its quads in two-primitive leaves), so the frame (film, RGB8, all nine
+    ray counters: same node visits, same triangle tests) equals the oracle's bit for bit; (b) after transform edits the rebuilt
+    tree equals a FRESH host build of the edited scene and the frame the oracle's frame of the edited scene; (c) a refit
+    after a rebuild works on the new topology."""
+    make = {"cornell": gpu.scenes.cornell, "mixed": lambda: gpu.scenes.mixed(sphere_res=(16, 8)),
+            "atrium": lambda: gpu.scenes.atrium(target_tris=30000),
+            "quads": lambda: gpu.scenes.atrium(target_tris=6000)}[which]
+    data = make(); data.max_prims_in_node = max_prims
+    sc = gpu.Scene(data); sc.buildBVH(max_prims)
+    n0, r0 = sc.bvh()
+    assert which == "mixed" or (n0["num_prims"] > 1).any()             # leaves of several primitives: their inner order matters
+    W, H = 200, 120
+    osc = ol.OracleScene(data)
+    cam = data.camera_desc(W, H, 2, 2, 5)
+    acc, img, cnt = osc.render(cam)
+    sc.rebuildBVHOnDevice(max_prims)
+    info = sc.info()
+    assert info["device_built"] and not info["refitted"]
+    n1, r1 = sc.bvh()
+    _same_tree(n0, r0, n1, r1, f"{which} rebuilt")
+    for count in (True, False):
+        g = gpu.StaticCamera(W, H, data.camera, 2, 2, 5); g.render(sc, count_rays=count)
+        assert_same_f32(g.acc_, acc, f"{which}: frame on the rebuilt tree (count={count})"); assert (g.img_ == img).all()
+        if count:
+            assert g.counters == cnt, "same tree => same node visits and triangle tests"
+    # (b) edits
+    edits = _edit(gpu, data, 7)
+    fresh_data = make(); fresh_data.max_prims_in_node = max_prims
+    for mi, m in edits.items():
+        sc.setTransform(mi, m)
+        fresh_data.meshes[mi]["transform"] = m.copy()
+    sc.rebuildBVHOnDevice(max_prims)
+    fresh = gpu.Scene(fresh_data); fresh.buildBVH(max_prims)
+    nf, rf = fresh.bvh()
+    n2, r2 = sc.bvh()
+    _same_tree(nf, rf, n2, r2, f"{which} edited + rebuilt")
+    assert abs(sc.getSceneRadius() - fresh.getSceneRadius()) == 0
+    acc2, img2, cnt2 = ol.OracleScene(fresh_data).render(cam)
+    for count in (True, False):
+        g = gpu.StaticCamera(W, H, data.camera, 2, 2, 5); g.render(sc, count_rays=count)
+        assert_same_f32(g.acc_, acc2, f"{which}: edited frame on the rebuilt tree (count={count})"); assert (g.img_ == img2).all()
+        if count:
+            assert g.counters == cnt2
+    # (c) the refit sources follow the rebuild: identity refit on the new topology reproduces the frame
+    for mi, m in edits.items():
+        sc.setTransform(mi, m)
+    sc.refit()
+    g = gpu.StaticCamera(W, H, data.camera, 2, 2, 5); g.render(sc, count_rays=False)
+    assert_same_f32(g.acc_, acc2, f"{which}: refit after rebuild")
+    fresh.destroy(); sc.destroy()
 
 
 @pytest.mark.parametrize("which", ["cornell", "mixed", "atrium"])
