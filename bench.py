@@ -208,6 +208,30 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
         hbm["measured_bytes_per_launch"] = int(measured)
         hbm["measured_frac"] = round(measured / t / 1e9 / 8000.0, 4)
         hbm["raw_kib"] = {"FETCH_SIZE": c["FETCH_SIZE"], "WRITE_SIZE": c["WRITE_SIZE"]}
+        # Issue-cycle model (round 3): a wave64 VALU instruction does NOT issue every 2 cycles on gfx950 -- measured with every SIMD
+        # holding 8 waves of independent instructions (tools/micro/rate4.hip, profiles/r03_valu_rates.txt): v_add / v_mul / v_fma /
+        # v_mov on VGPR or inline-constant operands 2.4 cycles; everything else (min / max / max3, compares, v_cndmask, conversions,
+        # bit operations, ANY instruction with an SGPR or literal operand) 4.4; transcendentals 8.4.  With the dynamic mix of the
+        # launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32) that gives the cycles the instruction stream needs; >= 1.0 of the SIMDs'
+        # cycles means the kernel is VALU-issue saturated (the per-class costs are upper bounds: part of the add / mul / fma
+        # instructions counted as fast carry an SGPR operand, and a forwarded operand can make an instruction cheaper).
+        if c.get("SQ_INSTS_VALU_FMA_F32") is not None:
+            fast = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_FMA_F32"]
+            trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+            slow = insts - fast - trans
+            clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (pmc.get("kernel_ms", kernel_ms) * 1e-3) if c.get("GRBM_GUI_ACTIVE") else CLK
+            need = fast * 2.4 + slow * 4.4 + trans * 8.4
+            out["issue_model"] = {"fast_class_insts": int(fast), "slow_class_insts": int(slow), "transcendental_insts": int(trans),
+                                  "cycles_per_inst": {"fast": 2.4, "slow": 4.4, "transcendental": 8.4},
+                                  "cycles_needed": int(need), "simd_cycles_available": int(SIMDS * t * CLK),
+                                  "busy": round(need / (SIMDS * t * CLK), 3),
+                                  "note": "VALU cycles the launch's instruction mix needs at the issue rates measured on this chip "
+                                          "(profiles/r03_valu_rates.txt) / cycles the SIMDs have in the kernel's duration; >= 1: issue-saturated"}
+            del clk
+        if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            out["l1_hit_rate"] = round(1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
+        if c.get("TCC_HIT_sum"):
+            out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
         if c.get("SQ_LDS_IDX_ACTIVE"):
             out["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
         out["wait_share"] = {"s_waitcnt": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3),
