@@ -1240,6 +1240,50 @@ def test_device_rebuild_gives_the_reference_tree(gpu, which, max_prims):
     fresh.destroy(); sc.destroy()
 
 
+def test_device_rebuild_edge_cases(gpu):
+    """the corners of buildTree (bvh.cpp:18-57) through jtx_mi_scene_rebuild: one primitive (a leaf root), a quad whose halves
+    share their centroid (degenerate centroid bounds: one leaf of two), two separate triangles in either input order
+    (nth_element swaps or keeps), three and five primitives (buckets with a single primitive, empty buckets in between), a
+    flat cloud (zero surface area: a leaf whatever its size)"""
+    sc_ = gpu.scenes
+    def tri(x, y, z, s=1.0):
+        return np.array([[x, y, z], [x + s, y, z], [x, y + s, z]], np.float32)
+    def scene(tris, flat=False):
+        d = sc_.SceneData("edge")
+        d.materials = [sc_.material(sc_.DIFFUSE, (0.7, 0.7, 0.7))]
+        v = np.concatenate(tris).astype(np.float32)
+        d.add_mesh(np.arange(len(v), dtype=np.int32).reshape(-1, 3), v, np.tile(np.array([[0, 0, 1]], np.float32), (len(v), 1)), 0)
+        d.lights = [sc_.light(sc_.POINT, (0.0, 0.0, 5.0), (1, 1, 1), 10.0)]
+        d.camera = dict(center=(0.0, 0.0, 9.0), target=(0.0, 0.0, 0.0), up=(0, 1, 0), yfov=40.0, defocus_angle=0.0, focus_distance=1.0)
+        return d
+    quad = [np.array([[-1, -1, 0], [-1, 1, 0], [1, 1, 0]], np.float32), np.array([[-1, -1, 0], [1, 1, 0], [1, -1, 0]], np.float32)]
+    cases = {
+        "one": [tri(0, 0, 0)],
+        "quad": quad,
+        "two, in order": [tri(-2, 0, 0), tri(1, 0, 0)],
+        "two, swapped": [tri(1, 0, 0), tri(-2, 0, 0)],
+        "three": [tri(1, 0, 0), tri(-2, 0, 0), tri(0, 1.5, -1)],
+        "five on a line": [tri(float(x), 0, 0, 0.5) for x in (3, -4, 0, 1, -1)],
+        "degenerate points": [np.zeros((3, 3), np.float32) + np.float32(k) for k in (0, 0, 1)],
+    }
+    for name, tris in cases.items():
+        data = scene(tris)
+        sc = gpu.Scene(data); sc.buildBVH()
+        n0, r0 = sc.bvh()
+        sc.rebuildBVHOnDevice()
+        n1, r1 = sc.bvh()
+        _same_tree(n0, r0, n1, r1, name)
+        assert sc.info()["max_depth"] == gpu.api.bvh_build_host(data)[2]
+        ref = gpu.Scene(data); ref.buildBVH()
+        for count in (True, False):
+            a = gpu.StaticCamera(48, 48, data.camera, 2, 2, 3); a.render(sc, count_rays=count)
+            b = gpu.StaticCamera(48, 48, data.camera, 2, 2, 3); b.render(ref, count_rays=count)
+            assert_same_f32(a.acc_, b.acc_, f"{name}: frame after a device rebuild (count={count})")
+            if count:
+                assert a.counters == b.counters
+        sc.destroy(); ref.destroy()
+
+
 @pytest.mark.parametrize("which", ["cornell", "mixed", "atrium"])
 def test_refit_equals_a_fresh_build_of_the_edited_scene(gpu, which):
     """jtx_mi_scene_refit: (a) setting the SAME transforms again reproduces the built scene bit for bit (film and ray
