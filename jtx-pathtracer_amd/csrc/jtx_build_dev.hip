@@ -655,9 +655,13 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStre
     R.level_begin.assign((maxInterior > 0 ? maxInterior : 0) + 2, 0);                      // as jtx_mi_scene_create lays it out
     for (int d = 0; d <= maxInterior; ++d) R.level_begin[d + 1] = R.level_begin[d] + hs[3 + d];
     {
+        // (a SYNCHRONOUS copy: the runtime may read a pageable source of hipMemcpyAsync when the copy EXECUTES, not when it is
+        //  enqueued -- a block-scoped array was gone by then, and k_level_nodes scattered through garbage offsets: an intermittent
+        //  illegal access, caught by the round-3 test runs)
         int lb[129] = {0};
-        for (size_t d = 0; d < R.level_begin.size(); ++d) lb[d] = R.level_begin[d];
-        BCHK(hipMemcpyAsync(levelBeginDev, lb, 129 * sizeof(int), hipMemcpyHostToDevice, st));
+        for (size_t d = 0; d < R.level_begin.size() && d < 129; ++d) lb[d] = R.level_begin[d];
+        BCHK(hipStreamSynchronize(st));
+        BCHK(hipMemcpy(levelBeginDev, lb, 129 * sizeof(int), hipMemcpyHostToDevice));
     }
     hipLaunchKernelGGL(k_level_nodes, dim3(blocks(nn, 256)), dim3(256), 0, st, nodes, vals2, nn, levelBeginDev, cursor, B.level_nodes);
     hipLaunchKernelGGL(k_positions, dim3(blocks(nn, 256)), dim3(256), 0, st, B.nbox, parentDfs, axisOf, B.size, nn, B.pos);
@@ -674,9 +678,10 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStre
             if (count > 0) hipLaunchKernelGGL(k_wide_cuts, dim3(blocks(count, 256)), dim3(256), 0, st, B.level_nodes, R.level_begin[d], count, B.nbox, F);
         }
         int wc[4] = {6, 0, 0, 0};
-        BCHK(hipMemcpyAsync(wideCnt, wc, sizeof wc, hipMemcpyHostToDevice, st));
         WItem rootItem{0, 0};
-        BCHK(hipMemcpyAsync(items[0], &rootItem, sizeof rootItem, hipMemcpyHostToDevice, st));
+        BCHK(hipStreamSynchronize(st));
+        BCHK(hipMemcpy(wideCnt, wc, sizeof wc, hipMemcpyHostToDevice));
+        BCHK(hipMemcpy(items[0], &rootItem, sizeof rootItem, hipMemcpyHostToDevice));
         WideOut wo{B.wide, B.wide_map, wideCnt, (long long) B.wide_cap};
         int nin = 1, wcur = 0, levels = 0;
         bool ok = true;
@@ -687,8 +692,7 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStre
             BCHK(hipStreamSynchronize(st));
             if (wc[2]) { ok = false; break; }
             nin = wc[3]; wcur ^= 1;
-            const int zero = 0;
-            BCHK(hipMemcpyAsync(wideCnt + 3, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+            BCHK(hipMemsetAsync(wideCnt + 3, 0, sizeof(int), st));
         }
         R.wide_ok = ok; R.wide_depth = levels; R.num_wide = wc[1]; R.wide_granules = (size_t) wc[0];
     }

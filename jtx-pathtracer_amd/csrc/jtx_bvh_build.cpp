@@ -138,10 +138,12 @@ struct Builder {
             --threadsLeft;
             Builder other{maxPrims, threadsLeft / 2};
             threadsLeft -= other.threadsLeft;
-            auto fut = std::async(std::launch::async, [&other, p, mid, n, depth] {
-                Subtree r; other.build(r, p + mid, n - mid, depth + 1); return r; });
+            auto rightJob = [&other, p, mid, n, depth] { Subtree r; other.build(r, p + mid, n - mid, depth + 1); return r; };
+            std::future<Subtree> fut;
+            try { fut = std::async(std::launch::async, rightJob); }
+            catch (const std::system_error &) {}                     // no thread to be had (a process / thread limit): this one builds it itself
             build(t, p, mid, depth + 1);                             // first child lands at slot + 1
-            Subtree right = fut.get();
+            Subtree right = fut.valid() ? fut.get() : rightJob();
             t.nodes[slot].offset = (int) t.nodes.size();            // secondChildOffset (bvh.cpp:146)
             append(t, std::move(right));
         } else {

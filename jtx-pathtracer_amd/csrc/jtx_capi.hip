@@ -98,6 +98,11 @@ struct jtx_mi_scene {
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (64, used round-robin)
     unsigned work_slot = 0;
     unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
+    // a pass whose radiance records exceed the buffer cap goes in several launches of consecutive strata, each resolved on its
+    // own: (chunk counter, first stratum, one past the last) of every launch of the last pass, in order
+    struct PassPart { unsigned *work; int begin, end; };
+    std::vector<PassPart> pass_parts;
+    int pass_resolved_end = 0;       // strata of the last pass that are in the film (set by passAbandoned)
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;
     DevScene dev{};
@@ -417,15 +422,27 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
     auto guarded = [&](auto fn) { return [&, fn] { try { fn(); } catch (...) { std::lock_guard<std::mutex> g(errMu); err = std::current_exception(); } }; };
     const char *off = getenv("JTX_NO_WIDE");
     const bool wantWide = nn && !(off && atoi(off));
+    // (std::thread's constructor throws when the process may not have another thread -- a container's process / thread limit --:
+    //  every helper thread of this function is optional, the creating thread then does the work itself; and a vector of
+    //  joinable threads must never be unwound, that is std::terminate)
+    auto wideJob = guarded([&] { wideOk = buildWide(b.nodes, wide, wideDepth, &wideMap) && wideDepth <= kMaxWideDepth; });
     std::thread wideThread;
-    if (wantWide) wideThread = std::thread(guarded([&] { wideOk = buildWide(b.nodes, wide, wideDepth, &wideMap) && wideDepth <= kMaxWideDepth; }));
+    bool wideInline = false;
+    if (wantWide) { try { wideThread = std::thread(wideJob); } catch (const std::system_error &) { wideInline = true; } }
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } wideJoin{wideThread};   // also on a throw below
     // per-primitive loops: split over host threads (each index writes its own records)
     auto forPrims = [&](auto body) {
         int nt = (int) std::thread::hardware_concurrency(); if (nt > 16) nt = 16; if (nt < 1 || np < 8192) nt = 1;
         std::vector<std::thread> ts;
-        for (int t = 1; t < nt; ++t) ts.emplace_back(guarded([&, t] { for (size_t i = np * t / nt; i < np * (t + 1) / nt; ++i) body(i); }));
+        struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } joinAll{ts};
+        ts.reserve(nt);
+        int started = 1;
+        for (int t = 1; t < nt; ++t) {
+            try { ts.emplace_back(guarded([&, t] { for (size_t i = np * t / nt; i < np * (t + 1) / nt; ++i) body(i); })); started = t + 1; }
+            catch (const std::system_error &) { break; }
+        }
         for (size_t i = 0; i < np / nt; ++i) body(i);
+        for (size_t i = np * started / nt; i < np; ++i) body(i);                   // the ranges no thread could be created for
         for (auto &t : ts) t.join();
         if (err) std::rethrow_exception(err);
     };
@@ -528,8 +545,15 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         };
         {
             std::vector<std::thread> pool;
-            for (int k = 1; k < 8; ++k) pool.emplace_back(guarded([&, k] { positions(k); }));
+            struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } joinAll{pool};
+            pool.reserve(8);
+            int started = 1;
+            for (int k = 1; k < 8; ++k) {
+                try { pool.emplace_back(guarded([&, k] { positions(k); })); started = k + 1; }
+                catch (const std::system_error &) { break; }
+            }
             positions(0);
+            for (int k = started; k < 8; ++k) positions(k);
             for (auto &t : pool) t.join();
         }
         if (err) std::rethrow_exception(err);
@@ -541,6 +565,7 @@ void flatten(const jtx_mi_scene_desc &d, jtx_mi_scene &s) {
         HIPCHK(hipStreamSynchronize(nullptr));
         lap("8 threaded orderings");
         if (wideThread.joinable()) wideThread.join();
+        if (wideInline) wideJob();
         lap("wait for the wide nodes");
         if (err) std::rethrow_exception(err);
     }
@@ -768,6 +793,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                   float *d_acc, unsigned char *d_img, hipStream_t stream) {
     RenderParams p{};
     s.last_work = nullptr;            // only a launch that owns a chunk counter arms passAbandoned() (a stale one would void later passes)
+    s.pass_parts.clear(); s.pass_resolved_end = se;
     p.scene = s.dev;
     p.cam = deriveCamera(cam);
     p.width = cam.width; p.height = cam.height; p.max_depth = cam.max_depth;
@@ -872,6 +898,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.work = s.work.p + (s.work_slot++ & 63);                 // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
                 s.last_work = q.work;
+                s.pass_parts.push_back({q.work, q.sample_begin, q.sample_end});
 #ifdef JTX_WITH_QUEUE
                 if (queued) HIPCHK(jtx_launch_render_queue(q, owned, s.num_cus, stream)); else
 #endif
@@ -1318,9 +1345,14 @@ int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
 namespace {
 bool passAbandoned(jtx_mi_scene &s) {
     if (!s.last_work) return false;
-    unsigned v = 0;
-    HIPCHK(hipMemcpy(&v, s.last_work, sizeof v, hipMemcpyDeviceToHost));
-    return v >= 0x40000000u;
+    // the launches of the pass in order: every one before the first abandoned one completed and was resolved into the film
+    for (const auto &part : s.pass_parts) {
+        unsigned v = 0;
+        HIPCHK(hipMemcpy(&v, part.work, sizeof v, hipMemcpyDeviceToHost));
+        if (v >= 0x40000000u) { s.pass_resolved_end = part.begin; return true; }
+    }
+    if (!s.pass_parts.empty()) s.pass_resolved_end = s.pass_parts.back().end;
+    return false;
 }
 }
 
@@ -1404,7 +1436,10 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
             lap("enqueue");
             fetchImg();                                                         // the pass in flight: preview to (pinned) host memory
             lap("pass + img D2H");
-            if (passAbandoned(*s)) { cancelled = true; break; }               // the kernels saw the cancellation: that pass left no trace
+            if (passAbandoned(*s)) {                                            // the kernels saw the cancellation: the abandoned launch left no trace;
+                if (s->pass_resolved_end > done) done = s->pass_resolved_end;   // earlier launches of a split pass are in the film and count
+                cancelled = true; break;
+            }
             done = inFlightEnd;
             if (count) {
                 unsigned long long h[9];
@@ -1428,6 +1463,7 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                         // the waves poll the flag at every 64th chunk fetch: a short pass (or a slow callback) completes and is
                         // resolved before they look -- then its strata ARE in the film and count as completed
                         if (!passAbandoned(*s)) done = inFlightEnd;
+                        else if (s->pass_resolved_end > done) done = s->pass_resolved_end;
                     }
                     cancelled = true; break;
                 }

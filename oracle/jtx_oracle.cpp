@@ -1432,6 +1432,18 @@ void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int
                 cv.notify_all();
             } else cv.wait(lk, [&] { return generation != gen; });
         };
+        // (a thread that cannot be created -- a container's thread limit -- must not take the process down: probe how many there
+        //  are to be had first, the barrier needs the exact number)
+        {
+            std::vector<std::thread> probe; std::atomic<bool> go{false};
+            struct JoinAll { std::vector<std::thread> &v; std::atomic<bool> &g; ~JoinAll() { g.store(true); for (auto &t : v) if (t.joinable()) t.join(); } } ja{probe, go};
+            probe.reserve(threads);
+            int got = 0;
+            for (int t = 0; t < threads; ++t) {
+                try { probe.emplace_back([&go] { while (!go.load()) std::this_thread::yield(); }); ++got; } catch (const std::system_error &) { break; }
+            }
+            if (got < threads) threads = got > 1 ? got / 2 : 1;
+        }
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
             pool.emplace_back([&, t] {
@@ -1450,14 +1462,19 @@ void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int
     } else {
         std::atomic<size_t> next{0};
         std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t)
-            pool.emplace_back([&, t] {
-                while (true) {
-                    size_t j = next.fetch_add(1, std::memory_order_relaxed);
-                    if (j >= jobs.size()) break;
-                    tileSamples(jobs[j], sample_begin, sample_end, count ? &tc[t] : nullptr);
-                }
-            });
+        struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } ja{pool};
+        pool.reserve(threads);
+        auto worker = [&](int t) {
+            while (true) {
+                size_t j = next.fetch_add(1, std::memory_order_relaxed);
+                if (j >= jobs.size()) break;
+                tileSamples(jobs[j], sample_begin, sample_end, count ? &tc[t] : nullptr);
+            }
+        };
+        for (int t = 1; t < threads; ++t) {
+            try { pool.emplace_back(worker, t); } catch (const std::system_error &) { break; }    // fewer threads: the queue is shared
+        }
+        worker(0);
         for (auto &th : pool) th.join();
     }
     if (counters) {

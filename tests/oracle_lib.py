@@ -165,6 +165,10 @@ class OracleScene:
         spp = cam.x_pixel_samples * cam.y_pixel_samples
         if sample_end <= 0:
             sample_end = spp
+        if threads <= 0:
+            # the checker does not need every core of a 256-core host: a test process that also holds torch's and OpenMP's pools
+            # comes close to a container's thread limit with 256 more (bench.py's cpu_baseline passes its thread count itself)
+            threads = max(1, min(os.cpu_count() or 1, 64))
         if acc is None:
             acc = np.zeros((H, W, 3), np.float32)
         img = np.zeros((H, W, 3), np.uint8)

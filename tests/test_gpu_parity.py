@@ -831,6 +831,27 @@ def test_radiance_buffer_cap_renders_in_passes(gpu, cornell_pair, monkeypatch):
     assert_same_f32(cam_g.acc_, acc, "multi-pass frame, resumed")
 
 
+def test_cancel_inside_a_split_pass_reports_what_is_in_the_film(gpu, atrium_full, monkeypatch):
+    """a pass whose records exceed the radiance buffer goes in several launches, each resolved on its own; a
+    cancellation that arrives in a later launch leaves the earlier ones in the film -- and `currentSample_` must say so: the
+    film equals a render of exactly the strata reported"""
+    import threading
+    data, sc, osc = atrium_full
+    monkeypatch.setenv("JTX_MAX_RAD_MB", "280")                       # 1920x1080: 8 strata per launch, 8 launches per 64-spp pass
+    cam = gpu.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+    timer = threading.Timer(0.17, cam.terminateRender)
+    timer.start(); cam.render(sc); timer.join()
+    n = cam.currentSample_
+    if n == 64:
+        pytest.skip("the frame finished before the cancellation arrived")
+    assert n % 8 == 0, n
+    got = cam.acc_.copy()
+    part = gpu.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+    if n:
+        part.render(sc, sample_begin=0, sample_end=n)
+    assert_same_f32(got, part.acc_, f"film after a cancellation inside a split pass ({n} strata reported)")
+
+
 @pytest.mark.parametrize("seed,max_prims", [(11, 1), (12, 1), (13, 4)])
 def test_uncounted_random_triangle_soups(gpu, seed, max_prims):
     """no structure to lean on: thousands of overlapping random triangles of very different sizes, the four material
