@@ -7,7 +7,7 @@ i=0
 for P in "$@"; do
   i=$((i+1))
   rm -rf gpurun_out/pmcs_${tag}_p$i
-  timeout -k 10 400 rocprofv3 --pmc $P --output-format csv -d gpurun_out/pmcs_${tag}_p$i -- python3 tools/run_frames.py --workload $wl --frames 1 > gpurun_out/pmcs_${tag}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/pmcs_${tag}_p$i.log; }
+  timeout -k 10 ${PMC_TIMEOUT:-400} rocprofv3 --pmc $P --output-format csv -d gpurun_out/pmcs_${tag}_p$i -- python3 tools/run_frames.py --workload $wl --frames 1 > gpurun_out/pmcs_${tag}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/pmcs_${tag}_p$i.log; }
 done
 python3 - <<PY
 import csv, glob, json, re, collections
