@@ -228,6 +228,12 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
                                   "note": "VALU cycles the launch's instruction mix needs at the issue rates measured on this chip "
                                           "(profiles/r03_valu_rates.txt) / cycles the SIMDs have in the kernel's duration; >= 1: issue-saturated"}
             del clk
+        if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
+            # the second ceiling of the HBM-resident kernels: the vector-memory pipeline (one address unit and one data-return unit per CU)
+            unit_cycles = num_cus * c["GRBM_GUI_ACTIVE"] / 8.0
+            out["vector_memory"] = {"ta_busy": round(c["TA_TA_BUSY_sum"] / unit_cycles, 3), "td_busy": round(c["TD_TD_BUSY_sum"] / unit_cycles, 3),
+                                    "load_instructions": int(c["TA_FLAT_READ_WAVEFRONTS_sum"]),
+                                    "ta_cycles_per_load": round(c["TA_TA_BUSY_sum"] / max(1.0, c["TA_FLAT_READ_WAVEFRONTS_sum"]), 1)}
         if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
             out["l1_hit_rate"] = round(1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
         if c.get("TCC_HIT_sum"):

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-out = {"source_hash": bench.source_hash(), "collected_with": "tools/pmc_collect.sh (rocprofv3 --pmc, six separate passes, one uncounted frame) "
+out = {"source_hash": bench.source_hash(), "collected_with": "tools/pmc_collect.sh (rocprofv3 --pmc, seven separate passes, one uncounted frame) "
        "and tools/tools_wide_stats.py (-DJTX_PROFILE_WIDE build)", "workloads": {}}
 ws = {"atrium_1920x1080_64spp_d8": "atrium", "mixed_1920x1080_128spp_d8": "mixed"}
 for wl in bench.WORKLOADS:
