@@ -1037,6 +1037,15 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
         DeviceGuard dg(s->device);
         std::lock_guard<std::mutex> lk(s->mu);
         if (s->dev.num_nodes == 0) return 0;
+        const bool trace = getenv("JTX_TRACE_CREATE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!trace) return;
+            HIPCHK(hipStreamSynchronize(s->stream));
+            const auto n = std::chrono::steady_clock::now();
+            fprintf(stderr, "[jtx refit] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count());
+            t0 = n;
+        };
         HIPCHK(hipMemcpyAsync(s->mesh_xf.p, s->mesh_xf_host.data(), s->mesh_xf_host.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemsetAsync(s->wide_fail.p, 0, sizeof(int), s->stream));
         RefitArgs a{};
@@ -1046,12 +1055,14 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
         a.wide = s->wide.p; a.wide_map = s->wide_map.p; a.wide_fail = s->wide_fail.p;
         a.num_prims = s->dev.num_prims; a.num_nodes = s->dev.num_nodes; a.num_leaves = s->num_leaves; a.num_wide = s->wide.p ? s->num_wide : 0;
         HIPCHK(jtx_launch_refit(a, s->level_begin.data(), (int) s->level_begin.size() - 1, s->stream));
+        lap("kernels");
         // the host's copy of the nodes, the scene radius (scene.hpp:81-84) and with it the DISTANT lights (scene.cpp:128-134)
         std::vector<float4> nb(2 * (size_t) s->dev.num_nodes);
         HIPCHK(hipMemcpyAsync(nb.data(), s->nbox.p, nb.size() * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
         int wfail = 0;
         HIPCHK(hipMemcpyAsync(&wfail, s->wide_fail.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        lap("node boxes to the host");
         for (size_t i = 0; i < s->bvh.nodes.size(); ++i) {
             jtx_mi_bvh_node &n = s->bvh.nodes[i];
             n.pmin[0] = nb[2 * i].x; n.pmax[0] = nb[2 * i].y; n.pmin[1] = nb[2 * i].z; n.pmax[1] = nb[2 * i].w;
@@ -1081,6 +1092,7 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
         }
         if (wfail) { s->dev.wide = nullptr; s->dev.wide_depth = 0; }          // a node lost its grid (coordinates out of range): binary records only
         s->refitted = 1; s->xf_dirty = false;
+        lap("host nodes, lights, leaf list");
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
 }
