@@ -11,6 +11,11 @@ sums the disjoint shards onto rank 0 (strong scaling: the frame is fixed).
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  ray = one Scene::closestHit or Scene::anyHit call (SURVEY 8d).
+
+N = 1: after the headline's timed region the other BASELINE.json workloads (C3 atrium, C5 mixed, C1) are timed for a few frames
+each and ride in the same line under "workloads" (outside `value` / `steps` / `ms_per_step`, which stay the headline's);
+`--headline-only` skips them.  `--scene <file.glb|.gltf|.obj>` times an asset through the loaders (createScene, scene.cpp:176-209)
+instead of a procedural scene; a `sponza.gltf` / `sponza.glb` dropped into `assets/` replaces the procedural atrium.
 """
 import argparse
 import ctypes as C
@@ -29,6 +34,109 @@ WORKLOADS = {
     "atrium_1920x1080_64spp_d8": ("atrium", 1920, 1080, 8, 8, 8),
     "mixed_1920x1080_128spp_d8": ("mixed", 1920, 1080, 16, 8, 8),
 }
+
+
+EXTRA_STEPS = {"atrium_1920x1080_64spp_d8": 3, "mixed_1920x1080_128spp_d8": 3, "cornell_512x512_16spp_d4": 20}
+
+
+def sponza_asset():
+    """"if a real sponza.gltf is dropped in assets/ the bench uses it instead" (of the procedural atrium)."""
+    for n in ("sponza.gltf", "sponza.glb", "Sponza.gltf", "Sponza.glb"):
+        p = os.path.join(ROOT, "assets", n)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def frame_camera_inside(data):
+    """A file scene comes with createScene's camera (0,0,8) -> origin, yfov 20 (scene.cpp:196-201), which looks AT an object.  For an
+    interior (Sponza) the bench puts the camera inside instead, deterministically from the bounds: a quarter along the longest
+    horizontal axis, 30 % up, looking down that axis, yfov 60."""
+    import numpy as np
+    lo = np.min([np.min(m["vertices"] if m.get("transform") is None else m["vertices"] @ np.asarray(m["transform"], np.float32)[:3, :3].T
+                        + np.asarray(m["transform"], np.float32)[:3, 3], axis=0) for m in data.meshes], axis=0)
+    hi = np.max([np.max(m["vertices"] if m.get("transform") is None else m["vertices"] @ np.asarray(m["transform"], np.float32)[:3, :3].T
+                        + np.asarray(m["transform"], np.float32)[:3, 3], axis=0) for m in data.meshes], axis=0)
+    ax = 0 if (hi[0] - lo[0]) >= (hi[2] - lo[2]) else 2
+    c = 0.5 * (lo + hi)
+    c[1] = lo[1] + 0.3 * (hi[1] - lo[1])
+    t = c.copy()
+    c[ax] = lo[ax] + 0.25 * (hi[ax] - lo[ax]); t[ax] = hi[ax]
+    data.camera = dict(center=tuple(float(x) for x in c), target=tuple(float(x) for x in t), up=(0, 1, 0), yfov=60.0,
+                       defocus_angle=0.0, focus_distance=1.0)
+
+
+def load_workload(jtx, name, atrium_tris=262144, scene_file=None, camera=None):
+    """-> (workload name, SceneData, (W, H, xs, ys, depth)).  `scene_file`: an asset through the reference's createScene rules
+    (scenes.create_scene: OBJ / glTF / GLB loaders, loader.cpp:13-225, scene.cpp:176-209), named after the file."""
+    factory, W, H, xs, ys, depth = WORKLOADS[name]
+    if scene_file is None and factory == "atrium":
+        sp = sponza_asset()
+        if sp is not None:
+            scene_file, camera = sp, camera or "inside"
+    if scene_file is not None:
+        data = jtx.scenes.create_scene(scene_file)
+        if camera == "inside":
+            frame_camera_inside(data)
+        elif camera:
+            v = [float(x) for x in camera.split(",")]
+            if len(v) != 7:
+                raise SystemExit("--camera cx,cy,cz,tx,ty,tz,yfov")
+            data.camera.update(center=tuple(v[0:3]), target=tuple(v[3:6]), yfov=v[6])
+        base = os.path.splitext(os.path.basename(scene_file))[0]
+        return f"file:{base}_{W}x{H}_{xs * ys}spp_d{depth}", data, (W, H, xs, ys, depth)
+    data = getattr(jtx.scenes, factory)(atrium_tris) if factory == "atrium" else getattr(jtx.scenes, factory)()
+    return name, data, (W, H, xs, ys, depth)
+
+
+def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup):
+    """One rank, one workload: counted pass (device counters), warm-up, `steps` timed frames through jtx_mi_render_device
+    (film resident in HBM, resolve pass included), live HIP-event kernel time -> the dict that rides under "workloads"."""
+    lib = jtx._capi.load()
+    W, H, xs, ys, depth = dims
+    scene = jtx.Scene(data)
+    scene.buildBVH()
+    try:
+        cam = data.camera_desc(W, H, xs, ys, depth)
+        acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+        img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+        integrator = scene.info()["auto_integrator"]
+
+        def frame(count=False):
+            jtx.distributed.render_shard(scene, cam, 0, 1, acc, img, stream=tstream.cuda_stream, count_rays=count, integrator=integrator)
+        frame(count=True)
+        torch.cuda.synchronize()
+        cnt = jtx._capi.Counters()
+        jtx._capi.check(lib.jtx_mi_get_counters(scene.handle, C.byref(cnt)))
+        mine = cnt.as_dict()
+        rays = mine["n_closest"] + mine["n_any"]
+        for _ in range(warmup):
+            frame()
+        torch.cuda.synchronize()
+        ms = C.c_float(); nl = C.c_int32()
+        jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
+        t = time.perf_counter()
+        for _ in range(steps):
+            frame()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t
+        jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
+        kernel_ms = ms.value / max(1, nl.value)
+        info = scene.info()
+        out = {"ms_per_step": round(elapsed / steps * 1e3, 3), "kernel_ms": round(kernel_ms, 4), "steps": steps, "warmup": warmup,
+               "value": round(rays * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": rays,
+               "scene_triangles": data.num_triangles, "integrator": integrator}
+        if integrator == 1:
+            sinfo = {"lds_resident": bool(info["lds_resident"]), "lds_bytes": 8 * 32 * info["num_nodes"] + 48 * info["num_prims"],
+                     "workgroups": info["resident_workgroups"]}
+            roof = roofline_block(name, sinfo, mine, "k_render_paths", kernel_ms, 1, info["num_cus"])
+            for k in ("useful_frac", "frac", "traffic", "vector_memory", "lane_util", "issue_model", "pmc_stale"):
+                if k in roof:
+                    out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"]}
+            out["hbm_measured_frac"] = roof["hbm"].get("measured_frac")
+        return out
+    finally:
+        scene.destroy()
 
 
 def algorithmic_bytes(c):
@@ -219,7 +327,6 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
             fast = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_FMA_F32"]
             trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
             slow = insts - fast - trans
-            clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (pmc.get("kernel_ms", kernel_ms) * 1e-3) if c.get("GRBM_GUI_ACTIVE") else CLK
             need = fast * 2.4 + slow * 4.4 + trans * 8.4
             out["issue_model"] = {"fast_class_insts": int(fast), "slow_class_insts": int(slow), "transcendental_insts": int(trans),
                                   "cycles_per_inst": {"fast": 2.4, "slow": 4.4, "transcendental": 8.4},
@@ -227,7 +334,6 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
                                   "busy": round(need / (SIMDS * t * CLK), 3),
                                   "note": "VALU cycles the launch's instruction mix needs at the issue rates measured on this chip "
                                           "(profiles/r03_valu_rates.txt) / cycles the SIMDs have in the kernel's duration; >= 1: issue-saturated"}
-            del clk
         if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
             # the second ceiling of the HBM-resident kernels: the vector-memory pipeline (one address unit and one data-return unit per CU)
             unit_cycles = num_cus * c["GRBM_GUI_ACTIVE"] / 8.0
@@ -263,6 +369,9 @@ def main():
     ap.add_argument("--workload", default="cornell_1920x1080_64spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--atrium-tris", type=int, default=262144)
+    ap.add_argument("--headline-only", action="store_true", help="skip the other BASELINE.json workloads (N = 1 runs them after the headline)")
+    ap.add_argument("--scene", default=None, help="time this asset (.glb / .gltf / .obj, createScene's rules) instead of the procedural scene")
+    ap.add_argument("--camera", default=None, help="with --scene: 'inside' or cx,cy,cz,tx,ty,tz,yfov (default: createScene's (0,0,8) -> origin, yfov 20)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's peer-to-peer needs on this driver
@@ -294,8 +403,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     jtx._capi.check(jtx._capi.load().jtx_mi_set_device(local_rank))
 
-    factory, W, H, xs, ys, depth = WORKLOADS[args.workload]
-    data = getattr(jtx.scenes, factory)(args.atrium_tris) if factory == "atrium" else getattr(jtx.scenes, factory)()
+    wl_name, data, (W, H, xs, ys, depth) = load_workload(jtx, args.workload, args.atrium_tris, args.scene, args.camera)
     t0 = time.perf_counter()
     scene = jtx.Scene(data)
     scene.buildBVH()
@@ -327,16 +435,24 @@ def main():
     if gatherer is not None and os.environ.get("JTX_PIPELINE_EXCHANGE", "1") != "0":
         pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, gatherer, integrator=integrator)
 
+    xtimed = []                                              # serial exchange: (event before, event after) per frame, on the render stream
+
     def step(count=False, profile=False):
         if pipe is not None and gatherer is not None and not count and not profile:
             pipe.step(tstream)
             return
         jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count,
                                      integrator=integrator, profile_kernels=profile)
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(tstream)
         if gatherer is not None:
             gatherer.collect(acc, img)
         else:
             jtx.distributed.reduce_frame(acc, img, dst=0)
+        if world > 1:
+            e1.record(tstream)
+            xtimed.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
@@ -386,6 +502,9 @@ def main():
     fence()
     ms = C.c_float(); nl = C.c_int32()
     jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))   # drop warm-up events
+    del xtimed[:]
+    if pipe is not None:
+        pipe.reset_timing()
     t = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -405,12 +524,18 @@ def main():
         ddev = dev if backend == "nccl" else torch.device("cpu")          # (gloo rehearsals: host tensors)
         ones = torch.ones(1, dtype=torch.int32, device=ddev)
         dist.all_reduce(ones)
-        rowt = torch.tensor([float(rank), float(torch.cuda.current_device()), kernel_ms, float(mine["n_closest"] + mine["n_any"])],
-                            dtype=torch.float64, device=ddev)
+        # this rank's exchange (pack + gather / reduce + scatter): device time between events on the stream it runs on
+        if pipe is not None and gatherer is not None:
+            exchange_ms = pipe.exchange_ms()
+        else:
+            exchange_ms = sum(a.elapsed_time(b) for a, b in xtimed) / len(xtimed) if xtimed else None
+        rowt = torch.tensor([float(rank), float(torch.cuda.current_device()), kernel_ms, float(mine["n_closest"] + mine["n_any"]),
+                             -1.0 if exchange_ms is None else float(exchange_ms)], dtype=torch.float64, device=ddev)
         rows = [torch.zeros_like(rowt) for _ in range(world)]
         dist.all_gather(rows, rowt)
         ranks_diag = {"nranks_seen": int(ones.item()),
-                      "ranks": [{"rank": int(r[0]), "device": int(r[1]), "shard_kernel_ms": round(float(r[2]), 4), "shard_rays": int(r[3])}
+                      "ranks": [{"rank": int(r[0]), "device": int(r[1]), "shard_kernel_ms": round(float(r[2]), 4), "shard_rays": int(r[3]),
+                                 "exchange_ms": None if r[4] < 0 else round(float(r[4]), 4)}
                                 for r in (x.tolist() for x in rows)]}
 
     # N = 1: the same frames DELIVERED TO HOST buffers (jtx_mi_render: SURVEY 8d's wall time, first launch to last byte of
@@ -449,14 +574,14 @@ def main():
             kernel_name = names[dom]
             launches_per_frame = max(1, kind_ms[dom][1])
             kernel_ms = kind_ms[dom][0] / launches_per_frame          # average launch duration of that kernel
-        roof = roofline_block(args.workload if world == 1 else args.workload + f"@{world}", sinfo, roof_counters, kernel_name,
+        roof = roofline_block(wl_name if world == 1 else wl_name + f"@{world}", sinfo, roof_counters, kernel_name,
                               kernel_ms, launches_per_frame, info["num_cus"])
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene_triangles": data.num_triangles, "width": W, "height": H,
+            "config": {"workload": wl_name, "scene_triangles": data.num_triangles, "width": W, "height": H,
                        "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
                        "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu",
@@ -471,6 +596,19 @@ def main():
         if host_ms is not None:
             out["ms_per_step_host"] = round(host_ms, 3)
             out["value_host"] = round(rays_frame / host_ms / 1e3, 2)        # Mrays/s with the film delivered to host memory (PCIe-inclusive)
+        if world == 1 and not args.headline_only and args.scene is None:
+            # the other BASELINE.json workloads, a few frames each (C3 / C5 / C1 belong in the driver-written record);
+            # outside `value`, `steps`, `ms_per_step`, which stay the headline's
+            extras = {}
+            for name in WORKLOADS:
+                if name == args.workload:
+                    continue
+                try:
+                    n2, d2, dims2 = load_workload(jtx, name, args.atrium_tris)
+                    extras[n2] = time_workload(jtx, torch, dev, tstream, n2, d2, dims2, EXTRA_STEPS.get(name, 3), 1)
+                except Exception as e:                    # report, never hide
+                    extras[name] = {"failed": f"{type(e).__name__}: {e}"}
+            out["workloads"] = extras
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(data, W, H, xs, ys, depth)

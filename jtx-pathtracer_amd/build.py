@@ -14,11 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared"
          "-Wall", "-Wno-unused-function"]
 
 
-# experiment kernels that lost stay in the tree but out of the product library:
-# JTX_WITH_QUEUE=1 adds csrc/jtx_queue.hip (ray queues per lane, run with JTX_QUEUE=1)
-if os.environ.get("JTX_WITH_QUEUE") == "1":
-    SOURCES = SOURCES + ["jtx_queue.hip"]
-    FLAGS = FLAGS + ["-DJTX_WITH_QUEUE"]
+# (experiment kernels that lost -- DESIGN.md section 10 -- live in tools/experiments/, outside the library)
 
 
 def _hipcc():

@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) k_wide_cuts(const int *level_nodes, int b
     F[8 * (size_t) i] = W;
     for (int k = 2; k <= 8; ++k) F[8 * (size_t) i + k - 1] = best[k] < W ? best[k] : W;
 }
-struct WItem { int b, at; };
+struct WItem { int b, at; };           // binary node; granule of its wide node
 struct WideOut { uint4 *wide; int *wide_map; int *counters; long long cap; };    // counters: [0] granules used [1] wide nodes [2] failed [3] items of the next level
 __global__ void __launch_bounds__(64) k_wide_fill(const WItem *in, int nin, WItem *out, const float4 *nbox, const int *axisOf, const float *F, WideOut o) {
     const int j = blockIdx.x * 64 + threadIdx.x;
@@ -496,13 +496,13 @@ __global__ void __launch_bounds__(64) k_wide_fill(const WItem *in, int nin, WIte
     for (int k = 0; k < n; ++k) if (!leafNode(nbox, t[order[k]].node)) { slotOf[order[k]] = ni; child[ni++] = t[order[k]].node; }
     for (int k = 0; k < n; ++k) if (leafNode(nbox, t[order[k]].node)) { slotOf[order[k]] = ni + nl; child[ni + nl] = t[order[k]].node; ++nl; }
     float pmin[3], pmax[3]; cornersOf(nbox, b, pmin, pmax);
-    uint32_t ebyte[3]; float cell[3];
-    if (!jtxq::nodeGrid(pmin, pmax, ebyte, cell)) { atomicExch(&o.counters[2], 1); return; }
+    jtxq::NodeGrid grid;
+    if (!jtxq::nodeGrid(pmin, pmax, grid)) { atomicExch(&o.counters[2], 1); return; }
     uint8_t qlo[3][8] = {}, qhi[3][8] = {};
     for (int s = 0; s < ni + nl; ++s) {
         float cmin[3], cmax[3]; cornersOf(nbox, child[s], cmin, cmax);
         uint8_t lo3[3], hi3[3];
-        if (!jtxq::quantiseChild(pmin, pmax, cell, cmin, cmax, lo3, hi3)) { atomicExch(&o.counters[2], 1); return; }
+        if (!jtxq::quantiseChild(grid, pmin, pmax, cmin, cmax, lo3, hi3)) { atomicExch(&o.counters[2], 1); return; }
         for (int k = 0; k < 3; ++k) { qlo[k][s] = lo3[k]; qhi[k][s] = hi3[k]; }
     }
     uint32_t perm[8];
@@ -518,37 +518,38 @@ __global__ void __launch_bounds__(64) k_wide_fill(const WItem *in, int nin, WIte
         }
         perm[oc] = pm;
     }
-    static_assert(WIDE_NODE_G == 6, "the device builder lays the children blocks out packed");
-    const int need = 6 * ni + 2 * nl;
+    // children block [ni nodes][nl leaf records] (jtx_wide_quant.hpp)
+    const int need = (int) jtxq::blockGranules(ni, nl);
     const long long base = (long long) atomicAdd(&o.counters[0], need);
-    if (base + need > o.cap || base + need >= (1ll << 28)) { atomicExch(&o.counters[2], 1); return; }
-    uint32_t pw[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    for (int oc = 0; oc < 8; ++oc) {
-        const int bit = 24 * (oc & 3), w = bit >> 5, sh = bit & 31;
-        pw[oc >> 2][w] |= perm[oc] << sh;
-        if (sh > 8) pw[oc >> 2][w + 1] |= perm[oc] >> (32 - sh);
-    }
+    if (base + need > o.cap || base + need >= (long long) jtxq::kMaxGranules) { atomicExch(&o.counters[2], 1); return; }
+    uint32_t ndw[16], tw[8];
+    jtxq::encodeGridAndPlanes(ndw, grid, ni, ni + nl, qlo, qhi);
+    if (!jtxq::encodeTail(tw, (uint32_t) base, perm, ni + nl)) { atomicExch(&o.counters[2], 1); return; }
     uint4 *nd = o.wide + at;
-    nd[0] = make_uint4(__float_as_uint(pmin[0]), __float_as_uint(pmin[1]), __float_as_uint(pmin[2]),
-                       ebyte[0] | ebyte[1] << 8 | ebyte[2] << 16 | (uint32_t) ni << 24 | (uint32_t) (ni + nl) << 28);
-    nd[1] = make_uint4(jtxq::pack4(qlo[0]), jtxq::pack4(qlo[0] + 4), jtxq::pack4(qlo[1]), jtxq::pack4(qlo[1] + 4));
-    nd[2] = make_uint4(jtxq::pack4(qlo[2]), jtxq::pack4(qlo[2] + 4), jtxq::pack4(qhi[0]), jtxq::pack4(qhi[0] + 4));
-    nd[3] = make_uint4(jtxq::pack4(qhi[1]), jtxq::pack4(qhi[1] + 4), jtxq::pack4(qhi[2]), jtxq::pack4(qhi[2] + 4));
-    nd[4] = make_uint4((uint32_t) base, pw[0][0], pw[0][1], pw[0][2]);
-    nd[5] = make_uint4((uint32_t) base, pw[1][0], pw[1][1], pw[1][2]);
+    for (int g = 0; g < 4; ++g) nd[g] = make_uint4(ndw[4 * g], ndw[4 * g + 1], ndw[4 * g + 2], ndw[4 * g + 3]);
+    for (uint32_t t = 0; t < jtxq::kTails; ++t) nd[4 + t] = make_uint4(tw[4 * t], tw[4 * t + 1], tw[4 * t + 2], tw[4 * t + 3]);
+    if (b == 0) {                                             // the root-peel record: group word, orders, the children's exact boxes
+        uint32_t rec[4 * 14];
+        for (int i = 0; i < 4 * 14; ++i) rec[i] = 0u;
+        jtxq::encodePeelHeader(rec, (uint32_t) base, ni, ni + nl, tw);
+        for (int s = 0; s < ni + nl; ++s) { float cmin[3], cmax[3]; cornersOf(nbox, child[s], cmin, cmax); jtxq::encodePeelBox(rec, s, cmin, cmax); }
+        for (int g = 0; g < 14; ++g) o.wide[jtxq::kPeelRec + g] = make_uint4(rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
+        for (int g = 14; g < (int) jtxq::kRootNode; ++g) o.wide[g] = make_uint4(0u, 0u, 0u, 0u);
+        for (int g = (int) (jtxq::kRootNode + jtxq::kNodeG); g < (int) jtxq::kFirstBlock; ++g) o.wide[g] = make_uint4(0u, 0u, 0u, 0u);
+    }
     int *rec = o.wide_map + 16 * (size_t) atomicAdd(&o.counters[1], 1);
-    rec[0] = at; rec[1] = b; rec[2] = ni; rec[3] = nl; rec[4] = (int) (base + 6 * ni); rec[5] = rec[6] = rec[7] = 0;
+    rec[0] = at; rec[1] = b; rec[2] = ni; rec[3] = nl; rec[4] = (int) jtxq::leafAt((uint32_t) base, ni, 0); rec[5] = rec[6] = rec[7] = 0;
     for (int s = 0; s < 8; ++s) rec[8 + s] = s < ni + nl ? child[s] : -1;
     for (int s = ni; s < ni + nl; ++s) {                      // leaf records: the exact box + primitivesOffset + numPrimitives
         float cmin[3], cmax[3]; cornersOf(nbox, child[s], cmin, cmax);
         const float4 b1 = nbox[2 * (size_t) child[s] + 1];
-        uint4 *lr = o.wide + base + 6 * ni + 2 * (s - ni);
+        uint4 *lr = o.wide + jtxq::leafAt((uint32_t) base, ni, s - ni);
         lr[0] = make_uint4(__float_as_uint(cmin[0]), __float_as_uint(cmax[0]), __float_as_uint(cmin[1]), __float_as_uint(cmax[1]));
         lr[1] = make_uint4(__float_as_uint(cmin[2]), __float_as_uint(cmax[2]), __float_as_uint(b1.z), __float_as_uint(b1.w));
     }
     if (ni) {
         const int q = atomicAdd(&o.counters[3], ni);
-        for (int s = 0; s < ni; ++s) { out[q + s].b = child[s]; out[q + s].at = (int) (base + 6 * s); }
+        for (int s = 0; s < ni; ++s) { out[q + s].b = child[s]; out[q + s].at = (int) jtxq::nodeAt((uint32_t) base, s); }
     }
 }
 
@@ -677,8 +678,8 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStre
             const int count = R.level_begin[d + 1] - R.level_begin[d];
             if (count > 0) hipLaunchKernelGGL(k_wide_cuts, dim3(blocks(count, 256)), dim3(256), 0, st, B.level_nodes, R.level_begin[d], count, B.nbox, F);
         }
-        int wc[4] = {6, 0, 0, 0};
-        WItem rootItem{0, 0};
+        int wc[4] = {(int) jtxq::kFirstBlock, 0, 0, 0};
+        WItem rootItem{0, (int) jtxq::kRootNode};
         BCHK(hipStreamSynchronize(st));
         BCHK(hipMemcpy(wideCnt, wc, sizeof wc, hipMemcpyHostToDevice));
         BCHK(hipMemcpy(items[0], &rootItem, sizeof rootItem, hipMemcpyHostToDevice));

@@ -9,6 +9,11 @@
 
 #include <chrono>
 #include <cmath>
+#include <csignal>
+#include <cxxabi.h>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +58,7 @@ struct DeviceGuard {
 };
 
 constexpr size_t kMaxRadBytes = (size_t) 8 << 30;   // per-path radiance buffer of one pass (k_render_paths); env JTX_MAX_RAD_MB overrides
+constexpr int kWorkRing = 1024;                   // chunk counters of k_render_paths launches (power of two): at most half of them per pass
 constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + tris staged in LDS when they fit this (8 blocks/CU)
 
 } // namespace
@@ -94,8 +100,7 @@ struct jtx_mi_scene {
     bool xf_dirty = false;
     DevBuf<float4> lw_box; DevBuf<unsigned> lw_tab;   // flat leaf list of tiny scenes (traverseLeaves)
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
-    DevBuf<float4> qstate;           // k_render_queue: slot records + ray results of the persistent waves
-    DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (64, used round-robin)
+    DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (kWorkRing, used round-robin)
     unsigned work_slot = 0;
     unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
     // a pass whose radiance records exceed the buffer cap goes in several launches of consecutive strata, each resolved on its
@@ -287,15 +292,15 @@ struct WideBuilder {
         int child[8], ni = 0, nl = 0;
         for (int k = 0; k < n; ++k) if (!leaf(t[order[k]].node)) { slotOf[order[k]] = ni; child[ni++] = t[order[k]].node; }
         for (int k = 0; k < n; ++k) if (leaf(t[order[k]].node)) { slotOf[order[k]] = ni + nl; child[ni + nl] = t[order[k]].node; ++nl; }
-        // grid: origin = the node's min corner, cell = 2^e per axis with origin + 255 * 2^e >= max corner (exactly);
-        // children rounded outward on it (jtx_wide_quant.hpp: the same code refits the node on the device)
-        uint32_t ebyte[3]; float cell[3];
-        if (!jtxq::nodeGrid(nb.pmin, nb.pmax, ebyte, cell)) { ok = false; return; }
+        // grid: plane = (k + q) 2^e per axis, children rounded outward on it (jtx_wide_quant.hpp: the same code builds and refits
+        // the node on the device)
+        jtxq::NodeGrid grid;
+        if (!jtxq::nodeGrid(nb.pmin, nb.pmax, grid)) { ok = false; return; }
         uint8_t qlo[3][8] = {}, qhi[3][8] = {};
         for (int s = 0; s < ni + nl; ++s) {
             const jtx_mi_bvh_node &c = nodes[child[s]];
             uint8_t lo3[3], hi3[3];
-            if (!jtxq::quantiseChild(nb.pmin, nb.pmax, cell, c.pmin, c.pmax, lo3, hi3)) { ok = false; return; }
+            if (!jtxq::quantiseChild(grid, nb.pmin, nb.pmax, c.pmin, c.pmax, lo3, hi3)) { ok = false; return; }
             for (int k = 0; k < 3; ++k) { qlo[k][s] = lo3[k]; qhi[k][s] = hi3[k]; }
         }
         // visiting order per octant: the reference's near-first rule (scene.cpp:40-46) applied inside the treelet
@@ -312,34 +317,28 @@ struct WideBuilder {
             }
             perm[o] = pm;
         }
-        constexpr size_t G = jtx::WIDE_NODE_G;                          // granules per interior child (8: the block starts on a 128-byte line)
-        const size_t base = G == 8 ? (out.size() + 7) & ~(size_t) 7 : out.size();
-        if (base + G * (size_t) ni + 2 * (size_t) nl >= (1ull << 28)) { ok = false; return; }
-        out.resize(base + G * (size_t) ni + 2 * (size_t) nl);
-        auto fb = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-        auto pack = [](const uint8_t *q) { return jtxq::pack4(q); };
-        // 24-bit orders: octants 0-3 (z >= 0) back to back in 3 words behind the children base in granule 4, octants 4-7 the
-        // same way in granule 5: a lane reads the base AND its order with one 16-byte load
-        uint32_t pw[2][3] = {{0, 0, 0}, {0, 0, 0}};
-        for (int o = 0; o < 8; ++o) {
-            const int bit = 24 * (o & 3), w = bit >> 5, sh = bit & 31;
-            pw[o >> 2][w] |= perm[o] << sh;
-            if (sh > 8) pw[o >> 2][w + 1] |= perm[o] >> (32 - sh);
+        // children block: [ni nodes][nl leaf records] (jtx_wide_quant.hpp)
+        const size_t base = out.size();
+        if (base + jtxq::blockGranules(ni, nl) >= jtxq::kMaxGranules) { ok = false; return; }
+        out.resize(base + jtxq::blockGranules(ni, nl), make_uint4(0u, 0u, 0u, 0u));
+        uint32_t nd[16], tw[8];
+        jtxq::encodeGridAndPlanes(nd, grid, ni, ni + nl, qlo, qhi);
+        if (!jtxq::encodeTail(tw, (uint32_t) base, perm, ni + nl)) { ok = false; return; }
+        for (int g = 0; g < 4; ++g) out[at + g] = make_uint4(nd[4 * g], nd[4 * g + 1], nd[4 * g + 2], nd[4 * g + 3]);
+        for (uint32_t t = 0; t < jtxq::kTails; ++t) out[at + 4 + t] = make_uint4(tw[4 * t], tw[4 * t + 1], tw[4 * t + 2], tw[4 * t + 3]);
+        if (b == 0) {                                                   // the root-peel record: group word, orders, the children's exact boxes
+            uint32_t rec[4 * 14] = {};
+            jtxq::encodePeelHeader(rec, (uint32_t) base, ni, ni + nl, tw);
+            for (int s = 0; s < ni + nl; ++s) jtxq::encodePeelBox(rec, s, nodes[child[s]].pmin, nodes[child[s]].pmax);
+            for (int g = 0; g < 14; ++g) out[jtxq::kPeelRec + g] = make_uint4(rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
         }
-        out[at + 0] = make_uint4(fb(nb.pmin[0]), fb(nb.pmin[1]), fb(nb.pmin[2]),
-                                 ebyte[0] | ebyte[1] << 8 | ebyte[2] << 16 | (uint32_t) ni << 24 | (uint32_t) (ni + nl) << 28);
-        out[at + 1] = make_uint4(pack(qlo[0]), pack(qlo[0] + 4), pack(qlo[1]), pack(qlo[1] + 4));
-        out[at + 2] = make_uint4(pack(qlo[2]), pack(qlo[2] + 4), pack(qhi[0]), pack(qhi[0] + 4));
-        out[at + 3] = make_uint4(pack(qhi[1]), pack(qhi[1] + 4), pack(qhi[2]), pack(qhi[2] + 4));
-        out[at + 4] = make_uint4((uint32_t) base, pw[0][0], pw[0][1], pw[0][2]);
-        out[at + 5] = make_uint4((uint32_t) base, pw[1][0], pw[1][1], pw[1][2]);
         if (refit) {
-            int32_t rec[16] = {(int32_t) at, b, ni, nl, (int32_t) (base + G * (size_t) ni), 0, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1};
+            int32_t rec[16] = {(int32_t) at, b, ni, nl, (int32_t) jtxq::leafAt((uint32_t) base, ni, 0), 0, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1};
             for (int s2 = 0; s2 < ni + nl; ++s2) rec[8 + s2] = child[s2];
             refit->insert(refit->end(), rec, rec + 16);
         }
-        for (int s = ni; s < ni + nl; ++s) writeLeaf(base + G * (size_t) ni + 2 * (size_t) (s - ni), child[s]);
-        for (int s = 0; s < ni; ++s) fill(child[s], base + G * (size_t) s, level + 1);
+        for (int s = ni; s < ni + nl; ++s) writeLeaf(jtxq::leafAt((uint32_t) base, ni, s - ni), child[s]);
+        for (int s = 0; s < ni; ++s) fill(child[s], jtxq::nodeAt((uint32_t) base, s), level + 1);
     }
 };
 
@@ -358,8 +357,8 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
         }
     static const int sahCut = [] { const char *e = getenv("JTX_WIDE_SAH_CUT"); return e ? atoi(e) : 1; }();
     if (sahCut) wb.prepareCuts();                                     // JTX_WIDE_SAH_CUT=0: the greedy largest-box cut of round 1
-    out.resize(6);
-    wb.fill(0, 0, 0);
+    out.assign(jtxq::kFirstBlock, make_uint4(0u, 0u, 0u, 0u));         // root-peel record, root node (jtx_wide_quant.hpp)
+    wb.fill(0, jtxq::kRootNode, 0);
     depth = wb.depth;
     return wb.ok;
 }
@@ -873,20 +872,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 s.rad.alloc(need);
             }
             p.rad = s.rad.p;
-            // JTX_QUEUE=1: ray queues per lane for HBM-resident scenes (jtx_queue.hip: bit-identical, lane use 0.36 -> 0.56, but
-            // slower -- the memory system, not the issue slots, is what the 8-ary traversal waits for)
-            p.qstate = nullptr;
-#ifdef JTX_WITH_QUEUE             /* experiment builds only (JTX_WITH_QUEUE=1 python -m ... build): the product library does not carry the kernel */
-            static const int queueKernel = [] { const char *e = getenv("JTX_QUEUE"); return e ? atoi(e) : 0; }();
-            const bool queued = queueKernel && !s.dev.lds_threaded && s.dev.wide != nullptr;
-            if (queued) {
-                const size_t qn = jtx_queue_state_float4(s.num_cus);
-                if (s.qstate.n < qn) s.qstate.alloc(qn);
-                p.qstate = s.qstate.p;
-            }
-#else
-            constexpr bool queued = false;
-#endif
+            // one chunk counter per launch: a pass split into several launches (radiance buffer cap) and the pass pipelined behind it
+            // must never share one (passAbandoned() reads them per part) -- a ring of kWorkRing, at most half of it per pass
+            const int nparts = (se - sb + chunk - 1) / chunk;
+            if (nparts > kWorkRing / 2)
+                throw std::runtime_error("the radiance buffer cap splits this pass into " + std::to_string(nparts) + " launches (more than " +
+                                         std::to_string(kWorkRing / 2) + "): raise JTX_MAX_RAD_MB or render fewer strata per pass");
             for (int b0 = sb; b0 < se; b0 += chunk) {
                 RenderParams q = p;
                 q.sample_begin = b0; q.sample_end = b0 + chunk < se ? b0 + chunk : se;
@@ -894,16 +885,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.strata_per_group = (q.sample_end - q.sample_begin + g - 1) / g;
                 q.num_groups = (q.sample_end - q.sample_begin + q.strata_per_group - 1) / q.strata_per_group;
                 q.num_subblocks = owned * 16;
-                if (!s.work.p) s.work.alloc(64);
-                q.work = s.work.p + (s.work_slot++ & 63);                 // one counter per launch in flight
+                if (!s.work.p) s.work.alloc(kWorkRing);
+                q.work = s.work.p + (s.work_slot++ & (kWorkRing - 1));    // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
                 s.last_work = q.work;
                 s.pass_parts.push_back({q.work, q.sample_begin, q.sample_end});
-#ifdef JTX_WITH_QUEUE
-                if (queued) HIPCHK(jtx_launch_render_queue(q, owned, s.num_cus, stream)); else
-#endif
                 HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
-                (void) queued;
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }
@@ -931,6 +918,43 @@ extern "C" {
 
 const char *jtx_mi_last_error(void) { return g_err.c_str(); }
 int jtx_mi_version(void) { return JTX_MI_VERSION; }
+
+// JTX_ABORT_LOG=<file>: a std::terminate / SIGABRT inside the process leaves its reason and a native backtrace in that file.
+// (A test runner that captures file descriptor 2 swallows the C++ runtime's last words; an intermittent abort inside
+// jtx_mi_scene_create on the GPU box -- round 4 -- left nothing but "Fatal Python error: Aborted".  tests/conftest.py sets it.)
+namespace {
+int g_abortFd = -1;
+void abortTrace(const char *why) {
+    if (g_abortFd < 0) return;
+    (void) !write(g_abortFd, why, strlen(why));
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, g_abortFd);
+    (void) !write(g_abortFd, "\n", 1);
+}
+void onAbortSignal(int) { abortTrace("SIGABRT\n"); signal(SIGABRT, SIG_DFL); raise(SIGABRT); }
+void onTerminate() {
+    char msg[512] = "std::terminate without an active exception\n";
+    if (std::exception_ptr e = std::current_exception()) {
+        try { std::rethrow_exception(e); }
+        catch (const std::exception &x) { snprintf(msg, sizeof msg, "std::terminate: %s\n", x.what()); }
+        catch (...) { snprintf(msg, sizeof msg, "std::terminate: a non-std exception\n"); }
+    }
+    abortTrace(msg);
+    signal(SIGABRT, SIG_DFL);
+    abort();
+}
+struct AbortLogInstaller {
+    AbortLogInstaller() {
+        const char *f = getenv("JTX_ABORT_LOG");
+        if (!f || !*f) return;
+        g_abortFd = open(f, O_WRONLY | O_CREAT | O_APPEND, 0644);
+        if (g_abortFd < 0) return;
+        std::set_terminate(onTerminate);
+        signal(SIGABRT, onAbortSignal);
+    }
+} g_abortLogInstaller;
+}
 
 int jtx_mi_device_count(int32_t *count) {
     int n = 0;
@@ -1124,7 +1148,7 @@ int jtx_mi_scene_rebuild(jtx_mi_scene *s, int32_t max_prims_in_node) {
         nbox2.alloc(2 * maxN); hn.alloc(maxN); leaves2.alloc(maxN); levels2.alloc(maxN); pos.alloc(8 * maxN); size.alloc(maxN);
         const char *off = getenv("JTX_NO_WIDE");
         const bool wantWide = !(off && atoi(off));
-        const size_t wideCap = 6 * (size_t) np + 2 * (size_t) np + 8;     // every interior node its own wide node at worst
+        const size_t wideCap = jtxq::kNodeG * (size_t) np + 2 * (size_t) np + 32;     // every interior node its own wide node at worst
         if (wantWide) { wide2.alloc(wideCap); map2.alloc(16 * (size_t) np); }
         lap("allocate");
         DevBuildBuffers B{};
@@ -1305,13 +1329,6 @@ int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
     return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
-#ifdef JTX_PROFILE_QUEUE
-int jtx_mi_debug_queue(jtx_mi_scene *s, unsigned long long *out14) {   // diagnostic builds only (jtx_queue.hip)
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out14, s->counters.p + 24, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
 #ifdef JTX_PROFILE_TIMELINE
 int jtx_mi_debug_timeline(jtx_mi_scene *s, unsigned long long *out, int n) {   // diagnostic builds only: (start, end) wall clocks per wave
     if (!s || !s->counters.p) return 1;
@@ -1374,7 +1391,9 @@ int jtx_mi_cancel_pending(jtx_mi_scene *s, int32_t *out) {
         if (!s || !out || !s->stop_host) throw std::runtime_error("null argument");
         DeviceGuard dg(s->device);
         const bool pending = __atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE) != 0;
-        *out = pending ? (passAbandoned(*s) ? 2 : 1) : 0;
+        bool abandoned = false;
+        if (pending) { std::lock_guard<std::mutex> lk(s->mu); abandoned = passAbandoned(*s); }   // (reads and writes the pass records of the scene)
+        *out = pending ? (abandoned ? 2 : 1) : 0;
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
 }

@@ -31,6 +31,14 @@ namespace jtx {
 #ifndef JTX_WIDE_OCC
 #define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
 #endif
+#ifndef JTX_NUM_SGPR
+#define JTX_NUM_SGPR 0          // > 0: amdgpu_num_sgpr on k_render_paths (the compiler budgets 80 SGPRs by itself and spills 60-80 into VGPR lanes)
+#endif
+#if JTX_NUM_SGPR > 0
+#define JTX_SGPR_ATTR __attribute__((amdgpu_num_sgpr(JTX_NUM_SGPR)))
+#else
+#define JTX_SGPR_ATTR
+#endif
 constexpr int BLOCK = JTX_RP_BLOCK;          // threads per workgroup of the render / batch kernels
 constexpr int WAVES_PER_BLOCK = BLOCK / 64;
 constexpr int BLOCKS_PER_TILE = 16 / WAVES_PER_BLOCK;   // a 32x32 tile = 16 wave-sized 8x8 pixel blocks
@@ -281,7 +289,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 // while its other lanes are still finishing paths of the previous chunk: no wave ever drains except at the very end
 // of the launch (a wave of 4 paths per lane lost ~12 % to its own drain), and the scene is staged once per workgroup.
 template <int SRC, int MASK, int BS>
-__global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) k_render_paths(RenderParams p) {
+__global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) JTX_SGPR_ATTR k_render_paths(RenderParams p) {
     static_assert((SRC != SRC_LDS && SRC != SRC_LEAF) || BS == BLOCK, "stageScene strides by BLOCK");
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr bool LDS_SCENE = SRC == SRC_LDS || SRC == SRC_LEAF;

@@ -133,14 +133,14 @@ __global__ void __launch_bounds__(128) k_refit_wide(RefitArgs a) {
     const int at = rec[0], b = rec[1], ni = rec[2], nl = rec[3], leafBase = rec[4];
     float pmin[3], pmax[3];
     nodeCorners(a, b, pmin, pmax);
-    uint32_t ebyte[3]; float cell[3];
-    if (!jtxq::nodeGrid(pmin, pmax, ebyte, cell)) { atomicExch(a.wide_fail, 1); return; }
+    jtxq::NodeGrid grid;
+    if (!jtxq::nodeGrid(pmin, pmax, grid)) { atomicExch(a.wide_fail, 1); return; }
     uint8_t qlo[3][8] = {}, qhi[3][8] = {};
     for (int s = 0; s < ni + nl; ++s) {
         float cmin[3], cmax[3];
         nodeCorners(a, rec[8 + s], cmin, cmax);
         uint8_t lo3[3], hi3[3];
-        if (!jtxq::quantiseChild(pmin, pmax, cell, cmin, cmax, lo3, hi3)) { atomicExch(a.wide_fail, 1); return; }
+        if (!jtxq::quantiseChild(grid, pmin, pmax, cmin, cmax, lo3, hi3)) { atomicExch(a.wide_fail, 1); return; }
         for (int k = 0; k < 3; ++k) { qlo[k][s] = lo3[k]; qhi[k][s] = hi3[k]; }
         if (s >= ni) {                                        // leaf record: the exact box (offset / count stay)
             uint4 *lr = a.wide + leafBase + 2 * (s - ni);
@@ -148,14 +148,16 @@ __global__ void __launch_bounds__(128) k_refit_wide(RefitArgs a) {
             lr[0] = make_uint4(__float_as_uint(cmin[0]), __float_as_uint(cmax[0]), __float_as_uint(cmin[1]), __float_as_uint(cmax[1]));
             lr[1] = make_uint4(__float_as_uint(cmin[2]), __float_as_uint(cmax[2]), keep.z, keep.w);
         }
+        if (at == (int) jtxq::kRootNode) {                    // the root-peel record carries the exact boxes of the root's children
+            uint32_t *peel = (uint32_t *) (a.wide + jtxq::kPeelRec);
+            jtxq::encodePeelBox(peel, s, cmin, cmax);
+        }
     }
+    uint32_t nd[16];
     uint4 *n = a.wide + at;
-    n[0] = make_uint4(__float_as_uint(pmin[0]), __float_as_uint(pmin[1]), __float_as_uint(pmin[2]),
-                      ebyte[0] | ebyte[1] << 8 | ebyte[2] << 16 | (uint32_t) ni << 24 | (uint32_t) (ni + nl) << 28);
-    n[1] = make_uint4(jtxq::pack4(qlo[0]), jtxq::pack4(qlo[0] + 4), jtxq::pack4(qlo[1]), jtxq::pack4(qlo[1] + 4));
-    n[2] = make_uint4(jtxq::pack4(qlo[2]), jtxq::pack4(qlo[2] + 4), jtxq::pack4(qhi[0]), jtxq::pack4(qhi[0] + 4));
-    n[3] = make_uint4(jtxq::pack4(qhi[1]), jtxq::pack4(qhi[1] + 4), jtxq::pack4(qhi[2]), jtxq::pack4(qhi[2] + 4));
-    // granules 4, 5 (children base, visiting orders) depend on the topology only
+    jtxq::encodeGridAndPlanes(nd, grid, ni, ni + nl, qlo, qhi);
+    for (int g = 0; g < 4; ++g) n[g] = make_uint4(nd[4 * g], nd[4 * g + 1], nd[4 * g + 2], nd[4 * g + 3]);
+    // the tail granule (children base, visiting orders) and the head of the root-peel record depend on the topology only
 }
 
 } // namespace jtx

@@ -15,6 +15,7 @@
 // When the 8 orderings + tris fit the LDS budget they are staged into LDS once per workgroup (LdsSrc).
 #pragma once
 #include "jtx_bxdf.hpp"
+#include "jtx_wide_quant.hpp"
 
 namespace jtx {
 
@@ -252,25 +253,25 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 // leaf's box against the current interval; if it passes, test its triangles.  Any structure that walks
 // the leaves in that order and only skips leaves whose box test would fail gives bit-identical hits.
 // The uncounted kernels use that freedom (the counted ones keep the reference's node visits):
-//   wide node (96 B = 6 x 16 B): a treelet of the binary tree below a node, opened at the child with the
-//     largest box until 8 children stand; slots = its wide (interior) children first, then its leaves, each
-//     left to right; every child box quantised OUTWARD to 8 bits per plane on the node's own grid
-//     (plane = origin + q 2^e, checked in exact arithmetic on the host), so a slab test on it can only
-//     pass more often than on any exact box inside it.
+//   wide node (80 B = 5 x 16 B): a treelet of the binary tree below a node cut into at most 8
+//     children (the cut that minimises the summed box area of all wide nodes, jtx_capi.hip); slots = its wide (interior)
+//     children first, then its leaves, each left to right; every child box quantised OUTWARD to 8 bits per plane on the
+//     node's own grid (plane = origin + q 2^e, checked in exact arithmetic by the builder), so a slab test on it can only
+//     pass more often than on any exact box inside it.  Bit layout, children blocks and the root-peel record:
+//     jtx_wide_quant.hpp (the one place that encodes them).
 //       [origin.xyz | ex ey ez, #interior, #children] [lo.x x8 | lo.y x8] [lo.z x8 | hi.x x8] [hi.y x8 | hi.z x8]
-//       [children base | visiting orders of octants 0-3, 4 x 24 bit] [children base | ... of octants 4-7]
-//     children block (16-B granules): interior children (WIDE_NODE_G granules apart: 8 = one 128-byte line per node, the
-//     block starts on a line), then leaf records (2 each).
-//     visiting order of an octant: the slots in the order the reference's near-first rule (dirIsNeg[axis],
-//     scene.cpp:40-46) walks the treelet, 3 bits per position.
+//       [children base | the 24-bit visiting orders of octants 0-3]
+//     visiting order of an octant: the slots in the order the reference's near-first rule (dirIsNeg[axis], scene.cpp:40-46)
+//     walks the treelet, 3 bits per position; octant q >= 4 takes the order of octant 7 - q from its END (all three signs
+//     flipped = every near / far decision flipped = the same list backwards): one tail granule instead of round 3's two.
 //   leaf record (32 B): the exact leaf box + primitivesOffset + numPrimitives, tested with slabRegular.
-// The per-lane stack holds one 64-bit entry per wide level {children base, #interior, visiting order,
-// pending positions} in LDS.  A stale hit bit (t.max shrank since the node was tested) only
-// costs a visit.  Irregular rays (a zero / non-finite direction component ...) take the exact binary path.
-#ifndef JTX_WIDE_NODE_G
-#define JTX_WIDE_NODE_G 6         // granules (16 B) from one interior child to the next: 6 = packed, 8 = every node in ONE 128-byte line
-#endif
-constexpr unsigned WIDE_NODE_G = JTX_WIDE_NODE_G;
+//   first step (round 4, "root peel"): every lane of a wave enters at the root, so the root's children are tested on their
+//     EXACT boxes read with scalar loads (wave-uniform addresses, SGPR operands: no vector-memory instruction, no byte
+//     conversions) -- 1 of ~10 node steps per ray leaves the vector-memory pipeline.
+// The per-lane stack holds one 64-bit entry per wide level {header word, visiting order, pending positions} in LDS.
+// A stale hit bit (t.max shrank since the node was tested) only costs a visit.  Irregular rays (a zero / non-finite
+// direction component ...) take the exact binary path.
+constexpr unsigned WIDE_NODE_G = jtxq::kNodeG;   // granules (16 B) from one interior child to the next
 #ifndef JTX_WIDE_LEAF_VOTE
 #define JTX_WIDE_LEAF_VOTE 16
 #endif
@@ -279,6 +280,13 @@ constexpr unsigned WIDE_NODE_G = JTX_WIDE_NODE_G;
 #endif
 #ifndef JTX_WIDE_STEPS
 #define JTX_WIDE_STEPS 1
+#endif
+#ifndef JTX_WIDE_ROOT_PEEL
+#define JTX_WIDE_ROOT_PEEL 0         // 1: the first step reads the root's children through scalar loads (measured: C3 +2 %, C5 -2 %; the root's
+                                     // vector loads are one coalesced request per wave anyway -- DESIGN.md section 10)
+#endif
+#ifndef JTX_PEEL_GROUP
+#define JTX_PEEL_GROUP 8             // children of the root tested between two scheduling barriers (8: no barriers; 2 / 4 spill MORE SGPRs)
 #endif
 
 // outward slack of the wide-node slab test: mu = 2^-23 (4 |b| + 512 |a|) + 2^-100 per axis (error budget in DESIGN.md)
@@ -289,13 +297,14 @@ constexpr float WIDE_RANGE = 1099511627776.0f;   // 2^40: |1/d|, 1/|1/d| and |o|
 
 JD float ubyteToFloat(unsigned v, int k) { return (float) ((v >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
 
-struct WideRay { f3 o, d, inv; float tmin, tmax; int negmask; };
+// ocls: the octant whose stored order this ray walks (negmask, or 7 - negmask when the z sign is set), rev: from the end
+struct WideRay { f3 o, d, inv; float tmin, tmax; int negmask, ocls; bool rev; };
 struct WideState {
     unsigned gbase, gbits;       // current group: children base (28 bits) | interior children (4) ; order list (24) | pending (8)
     int sp, pendLeaf;            // stack entries in use; granule of the leaf record the lane is parked on (-1: none)
     bool done, hitAnything;
-    // group = the children of one wide node still to visit; the start group is "the root": one interior child at granule 0
-    JD void start() { gbase = 1u << 28; gbits = 1u; sp = 0; pendLeaf = -1; done = false; hitAnything = false; }
+    // group = the children of one wide node still to visit; the start group is "the root": a block of one interior child at kRootNode
+    JD void start() { gbase = jtxq::groupWord(jtxq::kRootNode, 1); gbits = 1u; sp = 0; pendLeaf = -1; done = false; hitAnything = false; }
     JD bool walking() const { return pendLeaf < 0 && !done; }
 };
 
@@ -335,25 +344,31 @@ JD unsigned wideBit(unsigned v, unsigned at) { return __builtin_amdgcn_ubfe(v, a
 JD unsigned wideField3(unsigned v, int at) { return (v >> at) & 7u; }
 JD unsigned wideBit(unsigned v, unsigned at) { return (v >> at) & 1u; }
 #endif
-// the visiting order of the ray's octant out of a node's tail granule (octant & 3 selects 24 of the 96 bits behind the base)
-JD unsigned wideOrderOf(const uint4 tl, int negmask) {
-    const int q = negmask & 3;
-    const unsigned lo = q < 2 ? tl.y : (q == 2 ? tl.z : tl.w), hi = q < 2 ? tl.z : tl.w;
+// the visiting order of octant class q (0..3) out of the three order words (4 x 24 bits back to back)
+JD unsigned wideOrderOf(unsigned wy, unsigned wz, unsigned ww, int q) {
+    const unsigned lo = q < 2 ? wy : (q == 2 ? wz : ww), hi = q < 2 ? wz : ww;
     return __funnelshift_r(lo, hi, (24 * q) & 31) & 0x00ffffffu;
+}
+// hit mask in slot space -> pending mask in the position space of an order list
+JD unsigned widePending(unsigned hits, unsigned perm) {
+    unsigned pend = 0u;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) pend |= wideBit(hits, wideField3(perm, 3 * k2)) << k2;     // 2 v_bfe_u32 + v_lshl_or_b32 per position
+    return pend;
 }
 
 // One interior step of a walking lane: take the next child of the current group (popping the stack when the
 // group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
-// ORD = 0 (anyHit: the answer does not depend on the order): children are taken in slot order; 1: the octant's visiting
-// order; 2: per lane, `orderedRt` decides (the ray-queue kernel walks shadow and extension rays in one loop).
+// ORD = 0 (anyHit: the answer does not depend on the order): children are taken in slot order, leaves first; 1: the octant's visiting order.
 template <int ORD>
-JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws, bool orderedRt = true) {
-    const bool ORDERED = ORD == 2 ? orderedRt : ORD == 1;
+JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws) {
+    constexpr bool ORDERED = ORD == 1;
     if ((ws.gbits & 0xffu) == 0u) {                          // group exhausted: pop
         if (ws.sp == 0) { ws.done = true; return; }
         --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
     }
-    const int k = ORDERED ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);   // next position in visiting order (anyHit: leaves first)
+    // next position in visiting order (a reversed list is walked from its end; anyHit: leaves first)
+    const int k = (ORDERED && !r.rev) ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);
     ws.gbits &= ~(1u << k);
     const unsigned slot = (ws.gbits >> (8 + 3 * k)) & 7u;
     const unsigned ni = ws.gbase >> 28, base = ws.gbase & 0x0fffffffu;
@@ -361,20 +376,53 @@ JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, con
     const unsigned a = base + WIDE_NODE_G * slot;
     if (ws.gbits & 0xffu) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
     const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
-    const uint4 tl = wide[a + 4 + (ORD != 0 ? (r.negmask >> 2) : 0)];   // [children base | the 24-bit visiting orders of 4 octants]
-    const unsigned cbase = tl.x;
+    const uint4 tl = wide[a + 4 + (jtxq::kTails == 2 && ORDERED ? (unsigned) (r.negmask >> 2) : 0u)];   // [children base | the 24-bit visiting orders of 4 octants]
     const unsigned hits = wideNodeHits(n0, n2, n3, n4, r.o, r.inv, r.tmin, r.tmax);
     // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first)
-    const unsigned perm = ORDERED ? wideOrderOf(tl, r.negmask) : 0x00fac688u;   // identity: slot k at position k
+    const unsigned perm = ORDERED ? wideOrderOf(tl.y, tl.z, tl.w, r.ocls) : 0x00fac688u;   // identity: slot k at position k
     const unsigned nchild = n0.w >> 28;
-    unsigned pend = 0u;
-    if (ORD != 0) {                                           // (the identity list leaves the hits where they are)
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) pend |= wideBit(hits, wideField3(perm, 3 * k2)) << k2;     // 2 v_bfe_u32 + v_lshl_or_b32 per position
-    } else pend = hits;
-    pend &= (1u << nchild) - 1u;
-    ws.gbase = cbase | (((n0.w >> 24) & 0xfu) << 28);
+    const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);   // (the identity list leaves the hits where they are)
+    ws.gbase = tl.x | (((n0.w >> 24) & 0xfu) << 28);
     ws.gbits = pend | (perm << 8);
+}
+
+// The first step of a traversal: all lanes stand at the root, so its children come through scalar loads (the root-peel record:
+// group word, the four orders, #children, the children's EXACT boxes -- a slab test on an exact child box passes whenever a leaf below would)
+template <int ORD>
+JD void wideRootStep(const uint4 *__restrict__ wide, const WideRay &r, WideState &ws) {
+    constexpr bool ORDERED = ORD == 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) unsigned *CW;
+    typedef const __attribute__((address_space(4))) float *CF;
+#else
+    typedef const unsigned *CW;
+    typedef const float *CF;
+#endif
+    const CW rec = (CW) (const void *) wide;
+    const CF box = (CF) (const void *) (wide + jtxq::kPeelBoxes);
+    const unsigned grp = rec[0], nchild = rec[4];
+    const bool openEnd = r.tmax == __builtin_inff();          // closestHit's interval (integrator.cpp:181): see slabRegularOpen
+    unsigned hits = 0u;
+    // JTX_PEEL_GROUP children at a time, the groups kept apart by scheduling barriers: all 48 box words at once cost the kernel
+    // 10 more spilled SGPRs and ~85 more v_readlane per bounce than the step saves (measured: C3 +2 %)
+#pragma unroll
+    for (int g = 0; g < 8; g += JTX_PEEL_GROUP) {
+#pragma unroll
+        for (int s = g; s < g + JTX_PEEL_GROUP; ++s) {
+            const float4 na = make_float4(box[6 * s], box[6 * s + 1], box[6 * s + 2], box[6 * s + 3]);
+            const float4 nb = make_float4(box[6 * s + 4], box[6 * s + 5], 0.0f, 0.0f);
+            const bool pass = openEnd ? slabRegularOpen(na, nb, r.o, r.inv, r.tmin) : slabRegular(na, nb, r.o, r.inv, r.tmin, r.tmax);
+            hits |= (pass ? 1u : 0u) << s;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (JTX_PEEL_GROUP < 8) __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    const bool hiOct = jtxq::kTails == 2 && (r.negmask & 4);
+    const unsigned perm = ORDERED ? wideOrderOf(hiOct ? rec[5] : rec[1], hiOct ? rec[6] : rec[2], hiOct ? rec[7] : rec[3], r.ocls) : 0x00fac688u;
+    const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);
+    ws.gbase = grp; ws.gbits = pend | (perm << 8);
+    ws.sp = 0; ws.pendLeaf = -1; ws.done = false; ws.hitAnything = false;
 }
 
 // The leaf a lane is parked on: AABB::hit on the exact box, then the leaf's triangles (mesh.hpp:106-192)
@@ -399,11 +447,21 @@ JD void wideLeafStep(const uint4 *__restrict__ wide, const Src &src, bool any, W
     ws.pendLeaf = -1;
 }
 
+JD void wideRaySetup(WideRay &r, f3 o, f3 d, f3 inv, int negmask, float tmin, float tmax) {
+    r.o = o; r.d = d; r.inv = inv; r.tmin = tmin; r.tmax = tmax; r.negmask = negmask;
+    r.rev = jtxq::kTails == 1 && (negmask & 4) != 0; r.ocls = (r.rev ? ~negmask : negmask) & 3;
+}
+
 template <bool ANY, class Src>
 JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk, int stride, f3 o, f3 d, f3 inv,
                      int negmask, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
-    WideRay r; r.o = o; r.d = d; r.inv = inv; r.tmin = tmin; r.tmax = tmax; r.negmask = negmask;
-    WideState ws; ws.start();
+    WideRay r; wideRaySetup(r, o, d, inv, negmask, tmin, tmax);
+    WideState ws;
+#if JTX_WIDE_ROOT_PEEL
+    wideRootStep<ANY ? 0 : 1>(wide, r, ws);
+#else
+    ws.start();
+#endif
     WSTAT(cnt.w_calls++;)
     while (true) {
         while (true) {

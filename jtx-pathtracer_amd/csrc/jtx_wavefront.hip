@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(WBLOCK, WIDE ? JTX_WF_WIDE_OCC : 1) k_wf_trace
     const int want = ANY ? WF_SH_PENDING : WF_LIVE;
     const float tmin = ANY ? 0.0f : 0.001f;
     WideRay wr; WideState ws; ws.start(); ws.done = true;
-    wr.o = mk3(0.0f); wr.d = mk3(1.0f); wr.inv = mk3(1.0f); wr.tmin = tmin; wr.tmax = 0.0f; wr.negmask = 0;
+    wideRaySetup(wr, mk3(0.0f), mk3(1.0f), mk3(1.0f), 0, tmin, 0.0f);
 
     Counters9 cnt = {};
     if (sc.num_nodes == 0) {
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(WBLOCK, WIDE ? JTX_WF_WIDE_OCC : 1) k_wf_trace
                                  fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
                                  tmax == tmax;
             cur = negmask * sc.num_nodes; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
-            if (WIDE) { wr.o = o; wr.d = d; wr.inv = inv; wr.tmin = tmin; wr.tmax = tmax; wr.negmask = negmask; ws.start(); }
+            if (WIDE) { wideRaySetup(wr, o, d, inv, negmask, tmin, tmax); if (JTX_WIDE_ROOT_PEEL) wideRootStep<ANY == 0>(sc.wide, wr, ws); else ws.start(); }
             if (!regular || (WIDE && !wideRayOk(o, inv, tmin, tmax))) {
                 // axis-parallel / non-finite rays: the exact slab test, traced to the end right here
                 // (rare; keeps the main loop on the min/max form only)

@@ -1,11 +1,36 @@
-// jtx_wide_quant.hpp -- outward quantisation of the child boxes of an 8-ary node (host builder AND device refit).
+// jtx_wide_quant.hpp -- the 8-ary node set of traverseWide: its layout in memory, the outward quantisation of child boxes and the
+// encoders, shared by the host builder (jtx_capi.hip), the device builder (jtx_build_dev.hip) and the device refit (jtx_refit.hip):
+// ONE piece of code decides every bit of a node, whoever writes it.
 //
-// A wide node stores its children's boxes on a grid of its own: plane = origin + q * 2^e per axis, q in 0..255, origin =
-// the node's min corner, e the smallest exponent with origin + 255 * 2^e >= max corner.  Child planes are rounded OUTWARD
-// (q_lo = the largest grid plane <= the child's min, q_hi = the smallest >= its max), decided in EXACT arithmetic
-// (gridCmp: an error-free two-sum in double), so the quantised box provably contains the exact one -- the premise of the
-// traversal's equivalence argument.  Shared between jtx_capi.hip's WideBuilder (host) and
-// jtx_refit.hip (device): the same code decides both.
+// Layout, round 4 (16-byte granules):
+//   root-peel record   granules 0..13 (kPeelRec): what a peeled first step (JTX_WIDE_ROOT_PEEL=1, off by default) reads with scalar loads:
+//                      [group word | the visiting orders of octants 0-3][#children | orders of octants 4-7][8 children x exact box, 6 floats]
+//   root node          granules 16.. (kRootNode): the root as an ordinary node
+//   children blocks    from granule 24 (kFirstBlock): for a node with ni interior children and nl leaves
+//                          [ni x node, kNodeG granules each][nl x leaf record, 2 granules]
+//   node (96 B)        g0 [origin.xyz (float: the node's min corner) | ex ey ez, ni << 24, (ni + nl) << 28]   plane = origin + q 2^e
+//                      g1 [lo.x x8 | lo.y x8]  g2 [lo.z x8 | hi.x x8]  g3 [hi.y x8 | hi.z x8]   (8-bit planes, slot s = byte s)
+//                      g4 [children block granule | the 24-bit visiting orders (3 bits per position) of direction-sign octants 0..3,
+//                          back to back in 3 words]   g5 the same for octants 4..7 (a ray reads the tail of its z sign: base AND order
+//                          in one load)
+//   leaf record (32 B) the exact leaf box + primitivesOffset + numPrimitives  [min.x max.x min.y max.y][min.z max.z offset count]
+// This IS round 3's node.  Four other layouts were built, taken through the whole parity suite and measured this round (DESIGN.md
+// section 10; profiles/r04_wide_layouts.md), each behind the encoders of this file:
+//   * the children base packed INTO the header beside a 24-bit integer origin (plane = (k + q) 2^e), so that an anyHit step reads four
+//     granules instead of five: (a) 64-byte nodes on 64-byte boundaries, order granules at the end of the block: C3 339 ms against 319;
+//     (b) order granule behind its node: 331 ms.  3.4 % fewer load instructions, but unpacking the header costs 12-16 VALU
+//     instructions per node step (+4.0 % SQ_INSTS_VALU), and the kernel is short of issue slots first;
+//   * JTX_WIDE_TAILS=1: ONE tail granule (80-byte nodes), octant q >= 4 walking the order of octant 7 - q backwards (all three signs
+//     flipped = every near / far decision of the treelet flipped): same instruction count in the node loop, C3 326 / C5 317 ms
+//     against 321 / 303 -- the per-ray direction flag and class cost two more live registers in kernels that spill 94-161;
+//   * JTX_WIDE_ROOT_PEEL=1: the root's children on their exact boxes through scalar loads: C3 327 (+2 %),
+//     C5 297 (-2 %); the 48 box words take 10 more spilled SGPRs and ~85 v_readlane per bounce, and the five vector loads it
+//     removes were ONE coalesced request per wave each (all 64 lanes read the root), not 64.
+//
+// Quantisation: a node's grid is plane = origin + q * 2^e per axis, q in 0..255, origin = the node's min corner, e the smallest
+// exponent with origin + 255 * 2^e >= max corner.  Child planes are rounded OUTWARD (q_lo = the largest grid plane <= the child's min,
+// q_hi = the smallest >= its max), decided in EXACT arithmetic (gridCmp: an error-free two-sum in double), so the quantised box
+// provably contains the exact one -- the premise of the traversal's equivalence argument.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -20,6 +45,19 @@ namespace jtxq {
 constexpr int kWideMinExp = -60, kWideMaxExp = 40;   // cell = 2^e; with |1/d| in [2^-40, 2^40] (WIDE_RANGE) cell / d is exact
 constexpr float kWideCoordMax = 1099511627776.0f;    // 2^40
 
+constexpr uint32_t kPeelRec = 0, kPeelBoxes = 2, kRootNode = 16, kFirstBlock = 24;
+#ifndef JTX_WIDE_TAILS
+#define JTX_WIDE_TAILS 2                             // 2: round 3's two tail granules (octants 0-3 / 4-7); 1: one, octants 4..7 walk the orders of 3..0
+                                                     // backwards: 80-byte nodes, but the per-ray direction flag costs C3 +1.7 %, C5 +4.6 % (measured)
+#endif
+constexpr uint32_t kTails = JTX_WIDE_TAILS;
+constexpr uint32_t kNodeG = 4 + kTails;              // granules of a node record
+constexpr uint32_t kMaxGranules = 1u << 28;          // the children base shares its word with a 4-bit count in the kernel's group state
+JTXQ_HD uint32_t blockGranules(int ni, int nl) { return kNodeG * (uint32_t) ni + 2u * (uint32_t) nl; }
+JTXQ_HD uint32_t nodeAt(uint32_t base, int s) { return base + kNodeG * (uint32_t) s; }
+JTXQ_HD uint32_t leafAt(uint32_t base, int ni, int l) { return base + kNodeG * (uint32_t) ni + 2u * (uint32_t) l; }
+JTXQ_HD uint32_t groupWord(uint32_t base, int ni) { return base | (uint32_t) ni << 28; }   // the kernel's per-group state: where the children stand
+
 // sign of (p + q * cell) - x in exact arithmetic (q * cell is exact in double; two-sum for the addition)
 JTXQ_HD int gridCmp(float p, int q, float cell, float x) {
     const double a = (double) p, b = (double) q * (double) cell;
@@ -29,9 +67,11 @@ JTXQ_HD int gridCmp(float p, int q, float cell, float x) {
 }
 JTXQ_HD bool finite3(const float v[3]) { return isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]); }
 
+struct NodeGrid { uint32_t ebyte[3]; float cell[3], origin[3]; };
+
 // grid of a node: exponent byte (e + 127) and cell per axis.  false: the node cannot carry a grid (the scene then keeps
 // the binary records only)
-JTXQ_HD bool nodeGrid(const float pmin[3], const float pmax[3], uint32_t ebyte[3], float cell[3]) {
+JTXQ_HD bool nodeGrid(const float pmin[3], const float pmax[3], NodeGrid &g) {
     if (!finite3(pmin) || !finite3(pmax)) return false;
     for (int k = 0; k < 3; ++k) {
         const double ext = (double) pmax[k] - (double) pmin[k];
@@ -39,17 +79,17 @@ JTXQ_HD bool nodeGrid(const float pmin[3], const float pmax[3], uint32_t ebyte[3
         if (e < kWideMinExp) e = kWideMinExp;              // cell / d must stay a normal float (exact scaling)
         while (e <= kWideMaxExp && gridCmp(pmin[k], 255, ldexpf(1.0f, e), pmax[k]) < 0) ++e;
         if (e > kWideMaxExp || fabsf(pmin[k]) > kWideCoordMax || fabsf(pmax[k]) > kWideCoordMax) return false;
-        ebyte[k] = (uint32_t) (e + 127); cell[k] = ldexpf(1.0f, e);
+        g.ebyte[k] = (uint32_t) (e + 127); g.cell[k] = ldexpf(1.0f, e); g.origin[k] = pmin[k];
     }
     return true;
 }
 
 // one child box on the node's grid, rounded outward.  false: the child does not nest in the node (or is inverted)
-JTXQ_HD bool quantiseChild(const float pmin[3], const float pmax[3], const float cell[3], const float cmin[3], const float cmax[3],
+JTXQ_HD bool quantiseChild(const NodeGrid &g, const float pmin[3], const float pmax[3], const float cmin[3], const float cmax[3],
                            uint8_t qlo[3], uint8_t qhi[3]) {
     for (int k = 0; k < 3; ++k) {
         if (!(cmin[k] >= pmin[k] && cmax[k] <= pmax[k] && cmin[k] <= cmax[k])) return false;   // nesting is the premise
-        const float p = pmin[k], sc = cell[k];
+        const float p = g.origin[k], sc = g.cell[k];
         int q = (int) floor(((double) cmin[k] - (double) p) / (double) sc);
         q = q < 0 ? 0 : (q > 255 ? 255 : q);
         while (q > 0 && gridCmp(p, q, sc, cmin[k]) > 0) --q;
@@ -67,5 +107,44 @@ JTXQ_HD bool quantiseChild(const float pmin[3], const float pmax[3], const float
 }
 
 JTXQ_HD uint32_t pack4(const uint8_t *q) { return (uint32_t) q[0] | (uint32_t) q[1] << 8 | (uint32_t) q[2] << 16 | (uint32_t) q[3] << 24; }
+
+// the node's first four granules: nd[0..15]
+JTXQ_HD void encodeGridAndPlanes(uint32_t *nd, const NodeGrid &g, int ni, int nchild, const uint8_t qlo[3][8], const uint8_t qhi[3][8]) {
+    union { float f; uint32_t u; } c;
+    for (int a = 0; a < 3; ++a) { c.f = g.origin[a]; nd[a] = c.u; }
+    nd[3] = g.ebyte[0] | g.ebyte[1] << 8 | g.ebyte[2] << 16 | (uint32_t) ni << 24 | (uint32_t) nchild << 28;
+    nd[4] = pack4(qlo[0]); nd[5] = pack4(qlo[0] + 4); nd[6] = pack4(qlo[1]); nd[7] = pack4(qlo[1] + 4);
+    nd[8] = pack4(qlo[2]); nd[9] = pack4(qlo[2] + 4); nd[10] = pack4(qhi[0]); nd[11] = pack4(qhi[0] + 4);
+    nd[12] = pack4(qhi[1]); nd[13] = pack4(qhi[1] + 4); nd[14] = pack4(qhi[2]); nd[15] = pack4(qhi[2] + 4);
+}
+
+// the node's tail granule from the children base and the visiting orders of the 8 octants (3 bits per position, first visited
+// first).  false: octant 7 - q is not the reverse of octant q (cannot happen for orders made by the near-first rule)
+JTXQ_HD bool encodeTail(uint32_t *w, uint32_t base, const uint32_t perm[8], int nchild) {      // w: 4 * kTails words
+    for (int q = 0; q < 4; ++q)
+        for (int p = 0; p < nchild; ++p)
+            if (((perm[q] >> (3 * p)) & 7u) != ((perm[7 - q] >> (3 * (nchild - 1 - p))) & 7u)) return false;
+    for (uint32_t t = 0; t < kTails; ++t) {
+        const uint32_t *pm = perm + 4 * t;
+        w[4 * t + 0] = base;
+        w[4 * t + 1] = pm[0] | (pm[1] & 0xffu) << 24;
+        w[4 * t + 2] = pm[1] >> 8 | (pm[2] & 0xffffu) << 16;
+        w[4 * t + 3] = pm[2] >> 16 | pm[3] << 8;
+    }
+    return true;
+}
+
+// the root-peel record (14 granules = 56 words): group word + the orders, #children, then the EXACT boxes of the root's children in slot order
+// [min.x max.x min.y max.y min.z max.z]; unused slots zero (masked by nchild in the kernel)
+JTXQ_HD void encodePeelHeader(uint32_t *rec, uint32_t base, int ni, int nchild, const uint32_t *tail) {
+    rec[0] = groupWord(base, ni); rec[1] = tail[1]; rec[2] = tail[2]; rec[3] = tail[3];
+    rec[4] = (uint32_t) nchild; rec[5] = rec[6] = rec[7] = 0u;
+    if (kTails == 2) { rec[5] = tail[5]; rec[6] = tail[6]; rec[7] = tail[7]; }       // octants 4..7
+}
+JTXQ_HD void encodePeelBox(uint32_t *rec, int slot, const float cmin[3], const float cmax[3]) {
+    union { float f; uint32_t u; } c;
+    uint32_t *b = rec + 4 * kPeelBoxes + 6 * slot;
+    for (int a = 0; a < 3; ++a) { c.f = cmin[a]; b[2 * a] = c.u; c.f = cmax[a]; b[2 * a + 1] = c.u; }
+}
 
 } // namespace jtxq

@@ -171,6 +171,17 @@ class ShardPipeline:
         self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
         self.exchanged = [torch.cuda.Event(), torch.cuda.Event()]
         self.n = 0
+        self.timed = []                  # per frame: (event before, event after) the exchange on the side stream
+
+    def reset_timing(self):
+        self.timed = []
+
+    def exchange_ms(self):
+        """average device time of one frame's exchange (pack + gather + scatter on the side stream) since reset_timing();
+        call after torch.cuda.synchronize().  None before the first frame."""
+        if not self.timed:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.timed) / len(self.timed)
 
     def step(self, render_stream):
         """`render_stream`: a non-default torch.cuda.Stream the shard kernel is launched on"""
@@ -183,5 +194,9 @@ class ShardPipeline:
         self.rendered[b].record(render_stream)
         with torch.cuda.stream(self.xstream):
             self.xstream.wait_event(self.rendered[b])
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record(self.xstream)
             self.gatherer.collect(self.accs[b], self.imgs[b], self.frame_acc, self.frame_img)
+            t1.record(self.xstream)
             self.exchanged[b].record(self.xstream)
+            self.timed.append((t0, t1))

@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the runner captures file descriptor 2, so the C++ runtime's last words before an abort are lost: the library writes them
+    # (reason + native backtrace) here instead (jtx_capi.hip, JTX_ABORT_LOG)
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        os.environ.setdefault("JTX_ABORT_LOG", os.path.join(out, "jtx_abort.log"))
+    except OSError:
+        pass
 
 
 def _has_gpu():

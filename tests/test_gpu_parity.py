@@ -1261,6 +1261,30 @@ def test_device_rebuild_gives_the_reference_tree(gpu, which, max_prims):
     fresh.destroy(); sc.destroy()
 
 
+def test_device_rebuild_full_size_atrium(gpu, atrium_full):
+    """the 256 k-triangle device rebuild under test (what tools/rebuild_time.py prints, asserted): the tree of
+    jtx_mi_scene_rebuild equals the host build's node for node and primitive for primitive (283 657 nodes, depth 22, 114 k
+    two-primitive leaves), and the uncounted 480x270x16 frame on the device-built structures -- their 8-ary nodes are laid out level
+    by level instead of depth first -- equals the host-built scene's bit for bit; a second rebuild (the steady state of an edit
+    loop: no allocation) gives the same again."""
+    data, sc, osc = atrium_full
+    fresh = gpu.Scene(data); fresh.buildBVH()
+    try:
+        n0, r0 = sc.bvh()
+        W, H = 480, 270
+        ref = gpu.StaticCamera(W, H, data.camera, 4, 4, 8); ref.render(sc, count_rays=False)
+        for again in range(2):
+            fresh.rebuildBVHOnDevice()
+            info = fresh.info()
+            assert info["device_built"] and not info["refitted"] and info["wide_depth"] >= 2
+            n1, r1 = fresh.bvh()
+            _same_tree(n0, r0, n1, r1, f"atrium_full rebuilt ({again})")
+            g = gpu.StaticCamera(W, H, data.camera, 4, 4, 8); g.render(fresh, count_rays=False)
+            assert_same_f32(g.acc_, ref.acc_, f"atrium_full: frame on the device-built structures ({again})"); assert (g.img_ == ref.img_).all()
+    finally:
+        fresh.destroy()
+
+
 def test_device_rebuild_edge_cases(gpu):
     """the corners of buildTree (bvh.cpp:18-57) through jtx_mi_scene_rebuild: one primitive (a leaf root), a quad whose halves
     share their centroid (degenerate centroid bounds: one leaf of two), two separate triangles in either input order
@@ -1373,41 +1397,6 @@ def _tri_world(data, ref):
     for r in range(3):                                               # applyToPoint row by row, fp32 left to right
         out[:, r] = ((T[r, 0] * v[:, 0] + T[r, 1] * v[:, 1]) + T[r, 2] * v[:, 2]) + T[r, 3]
     return out
-
-
-_QUEUE_SCRIPT = r"""
-import sys, zlib, numpy as np
-sys.path.insert(0, sys.argv[1])
-import jtx_pathtracer_amd as gpu
-out = []
-for which in ("atrium", "axis", "mixed"):
-    data = gpu.scenes.mixed() if which == "mixed" else gpu.scenes.atrium(target_tris=20000)
-    if which == "axis":                      # a DISTANT light straight overhead: every shadow ray is irregular (1/d = inf)
-        data.lights = [gpu.scenes.light(gpu.scenes.DISTANT, (0.0, -1.0, 0.0), (1, 1, 1), 3.0)]
-    sc = gpu.Scene(data); sc.buildBVH()
-    assert not sc.info()["lds_resident"] and sc.info()["wide_depth"] >= 3
-    cam = gpu.StaticCamera(200, 120, data.camera, 2, 3, 8)
-    cam.render(sc, count_rays=False, integrator=1)
-    out.append("%08x %08x" % (zlib.crc32(np.ascontiguousarray(cam.acc_).tobytes()), zlib.crc32(np.ascontiguousarray(cam.img_).tobytes())))
-print("|".join(out))
-"""
-
-
-def test_ray_queue_kernel_is_bit_identical(gpu):
-    """JTX_QUEUE=1 routes HBM-resident scenes through k_render_queue (csrc/jtx_queue.hip: several paths per lane, every lane
-    walks its own queue of shadow and extension rays, path state in wave-private records): the film must be the one the
-    default kernel -- itself checked against the oracle above -- produces, bit for bit; incl. irregular rays."""
-    import os, subprocess, sys
-    if os.environ.get("JTX_WITH_QUEUE") != "1":
-        pytest.skip("experiment kernel: the product library is built without csrc/jtx_queue.hip (build and run with JTX_WITH_QUEUE=1)")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for q in ("0", "1"):
-        env = dict(os.environ, JTX_QUEUE=q)
-        r = subprocess.run([sys.executable, "-c", _QUEUE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[q] = r.stdout.strip().splitlines()[-1]
-    assert res["0"] == res["1"] and res["0"].count("|") == 2
 
 
 def test_closed_form_films_on_the_gpu(gpu):

@@ -28,12 +28,13 @@ def slab_q(nd, s, o, inv, tmin, tmax):
     return t0 <= t1
 
 
-NODE_G = 6        # granules from one interior child to the next (WIDE_NODE_G in jtx_scene_dev.hpp: one 128-byte line per node)
+ROOT_NODE, ROOT_ORDER, FIRST_BLOCK, PEEL_BOXES, NODE_G = 16, 20, 24, 2, 6      # jtx_wide_quant.hpp: kRootNode (+ 4), kFirstBlock, kPeelBoxes, kNodeG
 
 
-def decode(w, a):
-    """wide node at granule a -> dict (layout: jtx_scene_dev.hpp)"""
+def decode(w, a, oa=None):
+    """wide node at granule a -> dict (layout: jtx_wide_quant.hpp)"""
     n0, n1, n2, n3, n4, n5 = (w[a + i] for i in range(6))
+    assert oa is None or oa == a + 4
     origin = n0[:3].view(np.float32)
     cell = [np.array([((int(n0[3]) >> (8 * k)) & 0xff) << 23], np.uint32).view(np.float32)[0] for k in range(3)]
     byts = lambda u0, u1: [(int(u0) >> (8 * i)) & 0xff for i in range(4)] + [(int(u1) >> (8 * i)) & 0xff for i in range(4)]
@@ -45,13 +46,17 @@ def decode(w, a):
     for half in (n4, n5):                                 # octants 0-3 / 4-7: 4 x 24 bit behind the base
         bits = int(half[1]) | int(half[2]) << 32 | int(half[3]) << 64
         order += [[(bits >> (24 * o + 3 * k)) & 7 for k in range(n)] for o in range(4)]
+    for o in range(4):                                    # every sign flipped = the same list backwards (what JTX_WIDE_TAILS=1 builds on)
+        assert order[7 - o] == list(reversed(order[o]))
     return dict(origin=origin, cell=cell, base=int(n4[0]), ni=(int(n0[3]) >> 24) & 0xf, n=n, lo=lo, hi=hi, order=order)
 
 
 def child_addr(nd, slot):
-    if slot < nd["ni"]:
-        return nd["base"] + NODE_G * slot, False
-    return nd["base"] + NODE_G * nd["ni"] + 2 * (slot - nd["ni"]), True
+    """-> (granule of the child's node or leaf record, granule of its tail or None, is it a leaf)"""
+    ni = nd["ni"]
+    if slot < ni:
+        return nd["base"] + NODE_G * slot, nd["base"] + NODE_G * slot + 4, False
+    return nd["base"] + NODE_G * ni + 2 * (slot - ni), None, True
 
 
 def slab(pmin, pmax, o, inv, tmin, tmax):
@@ -85,22 +90,61 @@ def wide_leaves(w, o, inv, neg, tmin, tmax):
     octant = neg[0] | neg[1] << 1 | neg[2] << 2
     out = []
 
-    def visit(a):
-        nd = decode(w, a)
+    def visit(a, oa):
+        nd = decode(w, a, oa)
         hits = [s for s in range(nd["n"]) if slab_q(nd, s, o, inv, tmin, tmax)]
         for s in nd["order"][octant]:
             if s not in hits:
                 continue
-            addr, is_leaf = child_addr(nd, s)
+            addr, oaddr, is_leaf = child_addr(nd, s)
             if is_leaf:
                 la, lb = w[addr].view(np.float32), w[addr + 1]
                 pmin = [la[0], la[2], lb[:2].view(np.float32)[0]]; pmax = [la[1], la[3], lb[:2].view(np.float32)[1]]
                 if slab(pmin, pmax, o, inv, tmin, tmax):
                     out.append((int(lb[2]), int(lb[3])))
             else:
-                visit(addr)
+                visit(addr, oaddr)
 
-    visit(0)
+    visit(ROOT_NODE, ROOT_ORDER)
+    return out
+
+
+def wide_leaves_peeled(w, o, inv, neg, tmin, tmax):
+    """the same walk entered through the root-peel record, as traverseWide does: the root's children on their EXACT boxes"""
+    octant = neg[0] | neg[1] << 1 | neg[2] << 2
+    root = decode(w, ROOT_NODE, ROOT_ORDER)
+    assert int(w[0][0]) == (root["base"] | root["ni"] << 28) and int(w[1][0]) == root["n"]
+    assert [int(x) for x in w[0][1:4]] == [int(x) for x in w[ROOT_ORDER][1:4]] and [int(x) for x in w[1][1:4]] == [int(x) for x in w[ROOT_ORDER + 1][1:4]]
+    boxes = w[PEEL_BOXES:PEEL_BOXES + 12].reshape(-1).view(np.float32).reshape(8, 6)
+    out = []
+    for s in root["order"][octant]:
+        bx = boxes[s]
+        if not slab([bx[0], bx[2], bx[4]], [bx[1], bx[3], bx[5]], o, inv, tmin, tmax):
+            continue
+        addr, oaddr, is_leaf = child_addr(root, s)
+        if is_leaf:
+            la, lb = w[addr].view(np.float32), w[addr + 1]
+            assert [la[0], la[1], la[2], la[3]] == [bx[0], bx[1], bx[2], bx[3]]
+            out.append((int(lb[2]), int(lb[3])))
+        else:
+            sub = []
+            nd0 = decode(w, addr, oaddr)
+
+            def visit(nd):
+                hits = [t for t in range(nd["n"]) if slab_q(nd, t, o, inv, tmin, tmax)]
+                for t in nd["order"][octant]:
+                    if t not in hits:
+                        continue
+                    a2, o2, leaf2 = child_addr(nd, t)
+                    if leaf2:
+                        la, lb = w[a2].view(np.float32), w[a2 + 1]
+                        pmin = [la[0], la[2], lb[:2].view(np.float32)[0]]; pmax = [la[1], la[3], lb[:2].view(np.float32)[1]]
+                        if slab(pmin, pmax, o, inv, tmin, tmax):
+                            sub.append((int(lb[2]), int(lb[3])))
+                    else:
+                        visit(decode(w, a2, o2))
+            visit(nd0)
+            out += sub
     return out
 
 
@@ -136,19 +180,21 @@ def test_wide_nodes_contain_their_children(small_atrium):
         """binary leaf (offset, nprims) list below wide node at a, in slot order"""
         res = []
         for s in range(nd["n"]):
-            addr, is_leaf = child_addr(nd, s)
+            addr, oaddr, is_leaf = child_addr(nd, s)
             res.append([(int(w[addr + 1][2]), int(w[addr + 1][3]))] if is_leaf else
-                       [x for part in subtree_leaves(decode(w, addr), addr) for x in part])
+                       [x for part in subtree_leaves(decode(w, addr, oaddr), addr) for x in part])
         return res
 
-    todo = [(0, 0)]
+    todo = [(0, ROOT_NODE, ROOT_ORDER)]
     while todo:
-        b, a = todo.pop()
-        nd = decode(w, a)
+        b, a, oa = todo.pop()
+        nd = decode(w, a, oa)
         seen_wide += 1
         full += nd["n"] == 8
         assert 2 <= nd["n"] <= 8 and nd["ni"] <= nd["n"]
         assert (nd["origin"] == nodes[b]["pmin"]).all()
+        for k in range(3):
+            assert plane(255, nd["cell"][k], nd["origin"][k]) >= Fraction(float(nodes[b]["pmax"][k]))
         # the binary nodes standing at the slots: cut the binary subtree of b where the wide node cut it
         parts = subtree_leaves(nd, a)
         key = lambda i: (int(nodes[i]["offset"]), int(nodes[i]["num_prims"]))
@@ -170,13 +216,16 @@ def test_wide_nodes_contain_their_children(small_atrium):
                 cmin, cmax, cell = Fraction(float(nodes[c]["pmin"][k])), Fraction(float(nodes[c]["pmax"][k])), Fraction(float(nd["cell"][k]))
                 assert lo <= cmin and hi >= cmax, (b, s, k)                     # contains the exact box -- in exact arithmetic
                 assert cmin - lo < cell and hi - cmax < cell, (b, s, k)         # and is the tightest such box on the grid
-            addr, is_leaf = child_addr(nd, s)
+            addr, oaddr, is_leaf = child_addr(nd, s)
             assert is_leaf == bool(nodes[c]["num_prims"]) and is_leaf == (s >= nd["ni"])
             if is_leaf:
                 seen_leaves += 1
                 assert (w[addr].view(np.float32) == [nodes[c]["pmin"][0], nodes[c]["pmax"][0], nodes[c]["pmin"][1], nodes[c]["pmax"][1]]).all()
             else:
-                todo.append((c, addr))
+                todo.append((c, addr, oaddr))
+            if b == 0:                                                          # the root-peel record: the children's exact boxes in slot order
+                bx = w[PEEL_BOXES:PEEL_BOXES + 12].reshape(-1).view(np.float32).reshape(8, 6)[s]
+                assert [bx[0], bx[2], bx[4]] == list(nodes[c]["pmin"]) and [bx[1], bx[3], bx[5]] == list(nodes[c]["pmax"])
         # visiting order of every octant = the reference's near-first order of the binary subtree, cut at the slots
         for octant in range(8):
             want = [key(x) for x in _binary_leaf_order(nodes, b, octant)]
@@ -206,6 +255,7 @@ def test_wide_walk_reaches_the_reference_leaves_in_order(small_atrium):
         a = binary_leaves(nodes, o, inv, neg, f32(0.001), tmax)
         b = wide_leaves(w, o, inv, neg, f32(0.001), tmax)
         assert a == b, f"ray {i}"
+        assert wide_leaves_peeled(w, o, inv, neg, f32(0.001), tmax) == a, f"ray {i} (root peel)"
         nonempty += bool(a)
     assert nonempty > 60
 
@@ -214,7 +264,7 @@ def test_wide_build_small_and_degenerate_inputs():
     nodes, _, _ = api.bvh_build_host(scenes.cornell())
     w, depth = api.wide_build_host(nodes)
     n_leaves = int((nodes["num_prims"] > 0).sum())
-    assert depth >= 2 and (len(w) - 2 * n_leaves) % 6 == 0
+    assert depth >= 2 and len(w) >= FIRST_BLOCK + 2 * n_leaves
     nodes, _, _ = api.bvh_build_host(scenes.quad_scene())  # a single leaf: nothing to collapse
     assert len(nodes) == 1
     w, depth = api.wide_build_host(nodes)
