@@ -100,6 +100,7 @@ struct jtx_mi_scene {
     bool xf_dirty = false;
     DevBuf<float4> lw_box; DevBuf<unsigned> lw_tab;   // flat leaf list of tiny scenes (traverseLeaves)
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
+    DevBuf<float4> slip_park;        // k_render_paths, JTX_SLIP_K > 0: extension rays parked across bounces
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (kWorkRing, used round-robin)
     unsigned work_slot = 0;
     unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
@@ -806,6 +807,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
     p.acc = d_acc; p.img = d_img;
     p.stop = s.stop_dev;
+    p.slip = nullptr;
+    if (jtx_render_paths_slip_k() > 0 && s.dev.wide && !s.dev.lds_threaded) {        // parked extension rays: 2 float4 per lane of the persistent grid
+        int bs = 0; const size_t lanes = (size_t) jtx_render_paths_grid(s.dev, s.num_cus, &bs) * (size_t) bs;
+        if (s.slip_park.n < 2 * lanes) s.slip_park.alloc(2 * lanes);
+        p.slip = s.slip_park.p;
+    }
     const bool count = o.count_rays != 0;
     if (count) {
         if (!s.counters.p) s.counters.alloc(64);

@@ -31,6 +31,10 @@ namespace jtx {
 #ifndef JTX_WIDE_OCC
 #define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
 #endif
+#ifndef JTX_LANE_COLUMN
+#define JTX_LANE_COLUMN 0       // 1: k_render_paths over the 8-ary nodes recomputes the LDS stack column from the lane id instead of keeping a pointer live
+                                // (what the slip kernel needs to stay free of scratch reloads inside its node loop; by itself C3 +1.1 %)
+#endif
 #ifndef JTX_NUM_SGPR
 #define JTX_NUM_SGPR 0          // > 0: amdgpu_num_sgpr on k_render_paths (the compiler budgets 80 SGPRs by itself and spills 60-80 into VGPR lanes)
 #endif
@@ -71,6 +75,9 @@ struct PathState {
     f3 o, d, beta, radiance;
     Rng rng;
     int depth;
+#if JTX_SLIP_K > 0
+    bool slip;                   // its extension ray is under way across bounces, state parked in memory (k_render_paths over the 8-ary nodes)
+#endif
 #ifdef JTX_PROFILE_PHASES
     long long ph[6];
 #endif
@@ -101,17 +108,34 @@ JD void exportWideStats(const RenderParams &p, const Counters9 &cnt) {
 }
 #endif
 
-template <bool COUNT, int MASK, class Src>
-JD bool pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &ps, Counters9 &cnt) {
+// -> BOUNCE_NEXT: the path goes on with its next extension ray; BOUNCE_DONE: finished (radiance final); BOUNCE_PENDING (slip
+// builds only, -DJTX_SLIP_K=n): its extension ray is still under way -- call again
+#if JTX_SLIP_K > 0
+typedef int BounceResult;
+enum { BOUNCE_NEXT = 0, BOUNCE_DONE = 1, BOUNCE_PENDING = 2 };
+#else
+typedef bool BounceResult;
+constexpr bool BOUNCE_NEXT = false, BOUNCE_DONE = true;
+#endif
+template <bool COUNT, int MASK, class Src, bool SLIP = false>
+JD BounceResult pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &ps, Counters9 &cnt, float4 *slipBase = nullptr) {
     HitRec h;
     PH_DECL
+#if JTX_SLIP_K > 0
+    bool hit;
+    if constexpr (SLIP) {
+        if (traverseWideSlip(src, sc.num_nodes, ps.o, ps.d, 0.001f, slipBase, ps.slip, h, hit, cnt)) { PH(0) return BOUNCE_PENDING; }
+    } else hit = traverseNoStack<false, COUNT>(src, sc.num_nodes, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
+#else
+    (void) slipBase;
     const bool hit = traverseNoStack<false, COUNT>(src, sc.num_nodes, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
+#endif
     PH(0)
     if (!hit) {                                                       // integrator.cpp:183-187
         ps.radiance = ps.radiance + ps.beta * a3(sc.sky);
-        return true;
+        return BOUNCE_DONE;
     }
-    if (ps.depth++ == maxDepth) return true;                           // integrator.cpp:191
+    if (ps.depth++ == maxDepth) return BOUNCE_DONE;                           // integrator.cpp:191
     const Surface sf = makeSurface(sc.shade, h, ps.o, ps.d);
     const DMaterial &mat = sc.materials[sf.material];
     ShadeCtx ctx; ctx.materials = sc.materials; ctx.textures = sc.textures; ctx.texels = sc.texels;
@@ -147,18 +171,21 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &
     f2 u2; u2.x = ps.rng.f(); u2.y = ps.rng.f();
     BSample bs;
     if (COUNT) cnt.n_shade++;
-    if (!sampleBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) return true;
+    if (!sampleBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) return BOUNCE_DONE;
     if (bs.pdf > 0.0f) ps.beta = ps.beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);
     ps.o = sf.point + bs.wi * RAY_EPSILON;                             // integrator.cpp:212
     ps.d = bs.wi;
     PH(4)
-    return false;
+    return BOUNCE_NEXT;
 }
 
 JD void startPath(const DCam &cam, uint32_t row, uint32_t col, uint32_t s, PathState &ps) {
     ps.rng.seed(row, col, s + 1u);                                     // camera.cpp:101
     cameraRay(cam, col, row, s, ps.rng, ps.o, ps.d);
     ps.beta = mk3(1.0f); ps.radiance = mk3(0.0f); ps.depth = 0;
+#if JTX_SLIP_K > 0
+    ps.slip = false;
+#endif
 }
 
 JD unsigned char toByte(float v) {                                     // image.hpp:9-16,47-52
@@ -213,12 +240,12 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         while (alive) {
             bool done;
             if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes; src.np = sc.num_prims;
-                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
+                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BLOCK;
-                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
+                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
-                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt); }
+                                  done = pathBounce<COUNT, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             if (done) {
                 f3 c = ps.radiance;                                    // camera.cpp:110-112
                 if (c.x > 1.0f) c.x = 1.0f;
@@ -318,6 +345,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
 
     Counters9 cnt = {};
     PathState ps;
+#if JTX_SLIP_K > 0
+    ps.slip = false;
+#endif
 #ifdef JTX_PROFILE_PHASES
     for (int i = 0; i < 6; ++i) ps.ph[i] = 0;
     const long long k0 = clock64();
@@ -389,15 +419,19 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
         if (alive) {
             bool done;
             if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes; src.np = sc.num_prims;
-                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
                                   src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad;
-                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
-            else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
-                                  src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS;
-                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
+            else if constexpr (SRC == SRC_WIDE) {
+                                  // single-wave workgroups: the stack column is found from the lane id at every push / pop (JTX_LANE_COLUMN)
+                                  constexpr bool LC = BS == 64 && JTX_LANE_COLUMN;
+                                  WideSrcT<LC> src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                                  src.stk = (uint2 *) smem + (LC ? 0 : threadIdx.x); src.stride = BS;
+                                  // (a pending extension ray -- JTX_SLIP_K > 0 -- is neither done nor in need of a path: the lane calls again)
+                                  done = pathBounce<false, MASK, WideSrcT<LC>, (JTX_SLIP_K > 0)>(sc, src, p.max_depth, ps, cnt, JTX_SLIP_K > 0 ? p.slip : nullptr) == BOUNCE_DONE; }
             else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
-                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt); }
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             if (done) {
                 f3 c = ps.radiance;                                    // camera.cpp:110-112
                 if (c.x > 1.0f) c.x = 1.0f;
@@ -520,7 +554,7 @@ __global__ void __launch_bounds__(BLOCK) k_radiance_samples(DevScene sc, DCam ca
     PathState ps;
     startPath(cam, row[i], col[i], sample[i], ps);
     GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
-    while (!pathBounce<false, MAT_ALL>(sc, src, maxDepth, ps, cnt)) {}
+    while (pathBounce<false, MAT_ALL>(sc, src, maxDepth, ps, cnt) != BOUNCE_DONE) {}
     f3 c = ps.radiance;
     if (c.x > 1.0f) c.x = 1.0f;
     if (c.y > 1.0f) c.y = 1.0f;
@@ -607,6 +641,8 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
     }
 }
 } // namespace jtx
+
+int jtx_render_paths_slip_k() { return JTX_SLIP_K; }     // > 0: RenderParams::slip must hold 2 float4 per lane of the persistent grid
 
 int jtx_render_paths_grid(const DevScene &sc, int num_cus, int *block_size) {
     const bool lds = sc.lds_threaded != 0, wide = !lds && sc.wide != nullptr;

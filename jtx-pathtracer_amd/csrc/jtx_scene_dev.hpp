@@ -360,26 +360,38 @@ JD unsigned widePending(unsigned hits, unsigned perm) {
 // One interior step of a walking lane: take the next child of the current group (popping the stack when the
 // group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
 // ORD = 0 (anyHit: the answer does not depend on the order): children are taken in slot order, leaves first; 1: the octant's visiting order.
-template <int ORD>
+// LANECOL (single-wave workgroups): `stk` is the wave's stack BASE and the lane's column is recomputed from the lane id at every push /
+// pop (two v_mbcnt) -- a per-lane column pointer kept across the traversal is one more live register, and the allocator's answer to
+// that in the slip kernel was a scratch reload inside the node loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+JD unsigned wideLaneId() {      // volatile: the builtins are loop-invariant, get hoisted out of the node loop -- and then spilled and reloaded in it
+    unsigned x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+#else
+JD unsigned wideLaneId() { return 0u; }
+#endif
+template <int ORD, bool LANECOL = false>
 JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws) {
     constexpr bool ORDERED = ORD == 1;
     if ((ws.gbits & 0xffu) == 0u) {                          // group exhausted: pop
         if (ws.sp == 0) { ws.done = true; return; }
-        --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
+        --ws.sp; const uint2 e = stk[ws.sp * stride + (LANECOL ? wideLaneId() : 0u)]; ws.gbase = e.x; ws.gbits = e.y;
     }
     // next position in visiting order (a reversed list is walked from its end; anyHit: leaves first)
-    const int k = (ORDERED && !r.rev) ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);
+    const int k = (ORDERED && !(jtxq::kTails == 1 && r.rev)) ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);
     ws.gbits &= ~(1u << k);
     const unsigned slot = (ws.gbits >> (8 + 3 * k)) & 7u;
     const unsigned ni = ws.gbase >> 28, base = ws.gbase & 0x0fffffffu;
     if (slot >= ni) { ws.pendLeaf = (int) (base + WIDE_NODE_G * ni + 2u * (slot - ni)); return; }
     const unsigned a = base + WIDE_NODE_G * slot;
-    if (ws.gbits & 0xffu) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
+    if (ws.gbits & 0xffu) { stk[ws.sp * stride + (LANECOL ? wideLaneId() : 0u)] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
     const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
     const uint4 tl = wide[a + 4 + (jtxq::kTails == 2 && ORDERED ? (unsigned) (r.negmask >> 2) : 0u)];   // [children base | the 24-bit visiting orders of 4 octants]
     const unsigned hits = wideNodeHits(n0, n2, n3, n4, r.o, r.inv, r.tmin, r.tmax);
     // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first)
-    const unsigned perm = ORDERED ? wideOrderOf(tl.y, tl.z, tl.w, r.ocls) : 0x00fac688u;   // identity: slot k at position k
+    const unsigned perm = ORDERED ? wideOrderOf(tl.y, tl.z, tl.w, jtxq::kTails == 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;   // identity: slot k at position k
     const unsigned nchild = n0.w >> 28;
     const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);   // (the identity list leaves the hits where they are)
     ws.gbase = tl.x | (((n0.w >> 24) & 0xfu) << 28);
@@ -419,7 +431,7 @@ JD void wideRootStep(const uint4 *__restrict__ wide, const WideRay &r, WideState
 #endif
     }
     const bool hiOct = jtxq::kTails == 2 && (r.negmask & 4);
-    const unsigned perm = ORDERED ? wideOrderOf(hiOct ? rec[5] : rec[1], hiOct ? rec[6] : rec[2], hiOct ? rec[7] : rec[3], r.ocls) : 0x00fac688u;
+    const unsigned perm = ORDERED ? wideOrderOf(hiOct ? rec[5] : rec[1], hiOct ? rec[6] : rec[2], hiOct ? rec[7] : rec[3], jtxq::kTails == 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;
     const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);
     ws.gbase = grp; ws.gbits = pend | (perm << 8);
     ws.sp = 0; ws.pendLeaf = -1; ws.done = false; ws.hitAnything = false;
@@ -449,10 +461,11 @@ JD void wideLeafStep(const uint4 *__restrict__ wide, const Src &src, bool any, W
 
 JD void wideRaySetup(WideRay &r, f3 o, f3 d, f3 inv, int negmask, float tmin, float tmax) {
     r.o = o; r.d = d; r.inv = inv; r.tmin = tmin; r.tmax = tmax; r.negmask = negmask;
-    r.rev = jtxq::kTails == 1 && (negmask & 4) != 0; r.ocls = (r.rev ? ~negmask : negmask) & 3;
+    if (jtxq::kTails == 1) { r.rev = (negmask & 4) != 0; r.ocls = (r.rev ? ~negmask : negmask) & 3; }
+    else { r.rev = false; r.ocls = 0; }                    // (two tails: the octant's own order, negmask & 3 inside the tail of its z sign)
 }
 
-template <bool ANY, class Src>
+template <bool ANY, bool LANECOL = false, class Src>
 JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk, int stride, f3 o, f3 d, f3 inv,
                      int negmask, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     WideRay r; wideRaySetup(r, o, d, inv, negmask, tmin, tmax);
@@ -473,7 +486,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
                 WSTAT(if (ws.pendLeaf >= 0) cnt.w_np++; else if (ws.done) cnt.w_nd++;)
                 if (ws.walking()) {
                     WSTAT(cnt.w_node_steps++; const int leafBefore = ws.pendLeaf; const bool doneBefore = ws.done;)
-                    wideNodeStep<ANY ? 0 : 1>(wide, stk, stride, r, ws);
+                    wideNodeStep<ANY ? 0 : 1, LANECOL>(wide, stk, stride, r, ws);
                     WSTAT(if (ws.pendLeaf < 0 && !ws.done) cnt.w_fetch++; (void) leafBefore; (void) doneBefore;)
                 }
             }
@@ -504,24 +517,107 @@ JD bool wideRayOk(f3 o, f3 inv, float tmin, float tmax) {
            fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= WIDE_RANGE;
 }
 
+// ---- closestHit that lets its stragglers slip (round 4) ---------------------------------------------------------------------
+// A wave leaves traverseWide when its LAST ray is through: on the atrium 22 % of the node iterations of a frame run with one or two
+// walking lanes, 37 % with at most eight (tools/tools_wide_stats.py) -- while half of the lanes of the NEXT traversal idle in turn.
+// Here the wave leaves the loop when at most JTX_SLIP_K rays are still under way (and at least JTX_SLIP_MIN_DONE came through in
+// this call): the stragglers keep their traversal state -- group, pending children, stack depth, t.max, the hit so far; the stack
+// itself stays where it is, in the lane's LDS column -- sit out the rest of the bounce, and walk on in the wave's next closestHit,
+// beside 60 fresh rays.  Nothing about a ray's own walk changes (same nodes, same order, same shrinking t.max): bit-identical.
+#ifndef JTX_SLIP_K
+#define JTX_SLIP_K 0                 // 0: off (every ray finishes in the call that started it).  Measured with 4: node iterations of the C3 frame
+                                     // -8.8 %, traversal calls +3.6 %, frame +1.6 %
+#endif
+#ifndef JTX_SLIP_MIN_DONE
+#define JTX_SLIP_MIN_DONE 24
+#endif
+#if JTX_SLIP_K > 0
+// The interrupted state is PARKED IN MEMORY (two float4 per lane of the persistent grid, written by the few lanes that slip, read by
+// the few that resume), not carried in registers: eight more values live across the whole bounce made the compiler spill inside the
+// node loops (first version: C3 364 ms against 320).
+
+// -> true: this lane's ray is UNFINISHED (state in park[0..1], `on` set); false: finished, `hit` / `rec` as traverseNoStack<false> gives them
+template <class Src>
+JD bool traverseWideSlip(const Src &src, int num_nodes, f3 o, f3 d, float tmin, float4 *parkBase, bool &on, HitRec &rec, bool &hit, Counters9 &cnt) {
+    hit = false;
+    if (num_nodes == 0) return false;
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
+    const float tmax0 = __builtin_inff();
+    if (__builtin_expect(__ballot(!on && !wideRayOk(o, inv, tmin, tmax0)) != 0ull, 0)) {
+        // an irregular ray among the fresh ones: they walk the exact binary records together; resumed rays wait for the next call
+        if (on) return true;
+        hit = traverseThreaded<false, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax0, rec, cnt);
+        return false;
+    }
+    const uint4 *__restrict__ wide = src.wide;
+    uint2 *stk = src.stk; const int stride = src.stride;
+    WideRay r; wideRaySetup(r, o, d, inv, negmask, tmin, tmax0);
+    WideState ws; ws.start();
+    if (on) {
+        const float4 *park = parkBase + 2 * ((size_t) blockIdx.x * blockDim.x + threadIdx.x);
+        const float4 s0 = park[0], s1 = park[1];
+        ws.gbase = __float_as_uint(s0.x); ws.gbits = __float_as_uint(s0.y); ws.sp = __float_as_int(s0.z);
+        rec.prim = __float_as_int(s0.w); ws.hitAnything = rec.prim >= 0;
+        r.tmax = s1.x; rec.t = s1.x; rec.b1 = s1.y; rec.b2 = s1.z;
+    }
+    bool slipped = false;
+    WSTAT(cnt.w_calls++; if (on) cnt.w_pops++;)
+    while (true) {
+        while (true) {
+            WSTAT(cnt.w_node_iters++;
+                  { const int na = __popcll(__ballot(ws.walking()));
+                    cnt.w_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++; })
+            WSTAT(if (ws.pendLeaf >= 0) cnt.w_np++; else if (ws.done) cnt.w_nd++;)
+            WSTAT(if (ws.walking()) cnt.w_node_steps++;)
+            if (ws.walking()) wideNodeStep<1, Src::LANE_COLUMN>(wide, stk, stride, r, ws);
+            const unsigned long long walking = __ballot(ws.walking());
+            const unsigned long long parked = __ballot(ws.pendLeaf >= 0);
+            if (walking == 0ull || __popcll(parked) >= JTX_WIDE_LEAF_VOTE) break;
+            if (parked != 0ull && __popcll(walking) <= JTX_WIDE_FEW_WALKERS) break;
+            if (__popcll(walking | parked) <= JTX_SLIP_K && __popcll(__ballot(ws.done)) >= JTX_SLIP_MIN_DONE) break;
+        }
+        WSTAT(if (__ballot(ws.pendLeaf >= 0)) { cnt.w_leaf_iters++; if (ws.pendLeaf < 0) { if (ws.done) cnt.w_ld++; else cnt.w_lw++; } else cnt.w_leaf_steps++; })
+        if (ws.pendLeaf >= 0) wideLeafStep(wide, src, false, r, ws, rec);
+        const unsigned long long busy = __ballot(!ws.done);
+        if (busy == 0ull) break;
+        if (__popcll(busy) <= JTX_SLIP_K && __popcll(__ballot(ws.done)) >= JTX_SLIP_MIN_DONE) { slipped = true; break; }
+    }
+    if (slipped && !ws.done) {
+        float4 *park = parkBase + 2 * ((size_t) blockIdx.x * blockDim.x + threadIdx.x);
+        park[0] = make_float4(__uint_as_float(ws.gbase), __uint_as_float(ws.gbits), __int_as_float(ws.sp), __int_as_float(ws.hitAnything ? rec.prim : -1));
+        park[1] = make_float4(r.tmax, rec.b1, rec.b2, 0.0f);
+        on = true;
+        return true;
+    }
+    on = false;
+    hit = ws.hitAnything;
+    return false;
+}
+
+#endif
+
 // HBM-resident scene, uncounted kernels: wide traversal; a wave with an irregular ray walks the binary records
-struct WideSrc {
+template <bool LANECOL>
+struct WideSrcT {
+    static constexpr bool LANE_COLUMN = LANECOL;
     const uint4 *wide;
     const float4 *tnodes, *tris;
-    uint2 *stk;               // this lane's LDS stack column
+    uint2 *stk;               // LANECOL: the workgroup's (= wave's) stack base; else this lane's LDS stack column
     int stride;               // entries between two levels (= workgroup size)
     JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
 };
+typedef WideSrcT<false> WideSrc;
 
-template <bool ANY, bool COUNT>
-JD bool traverseNoStack(const WideSrc &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
+template <bool ANY, bool COUNT, bool LANECOL>
+JD bool traverseNoStack(const WideSrcT<LANECOL> &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     static_assert(!COUNT, "the counted kernels reproduce the reference's node visits: binary records only");
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
     if (__builtin_expect(__ballot(!wideRayOk(o, inv, tmin, tmax)) == 0ull, 1))
-        return traverseWide<ANY>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
+        return traverseWide<ANY, LANECOL>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
     return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
 }
 
