@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JTX_MI_VERSION 3
+#define JTX_MI_VERSION 4
 #define JTX_MI_CANCELLED 2   /* jtx_mi_render: stopped by the callback / jtx_mi_cancel; the film holds the completed passes */
 
 /* LinearBVHNode, src/bvh.hpp:7-15 (32 B) */
@@ -205,6 +205,13 @@ int  jtx_mi_scene_refit(jtx_mi_scene *scene);
  * orderings, the 8-ary quantised nodes with their surface-area cut, triangle / shading records, refit sources).
  * max_prims_in_node <= 0: 1. */
 int  jtx_mi_scene_rebuild(jtx_mi_scene *scene, int32_t max_prims_in_node);
+/* The edit loop's memory, ahead of the first edit (display.cpp:545-588 arms rebuildBVH_, :902-905 rebuilds): jtx_mi_scene_rebuild
+ * writes a SECOND set of every structure it replaces and swaps the two when all of it stands (a failed rebuild leaves the scene as it
+ * was); that set and the builder's scratch come into being with the first rebuild (~330 MB for 256 k triangles; device memory is
+ * mapped at first touch and the builder's code object loaded at its first launch: 26-33 ms against 6.8 ms for every later rebuild)
+ * -- or here, e.g. right after loading: a dry run of the rebuild that stops before the commit, so that the first edit costs what
+ * every later one does.  The scene is not changed.  Optional; may be called again. */
+int  jtx_mi_scene_reserve_rebuild(jtx_mi_scene *scene);
 int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
 int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
 

@@ -106,6 +106,7 @@ SYMBOLS = {
     "jtx_mi_scene_set_transform": (C.c_int, [_scene, C.c_int32, _f]),
     "jtx_mi_scene_refit": (C.c_int, [_scene]),
     "jtx_mi_scene_rebuild": (C.c_int, [_scene, C.c_int32]),
+    "jtx_mi_scene_reserve_rebuild": (C.c_int, [_scene]),
     "jtx_mi_cancel": (C.c_int, [_scene]),
     "jtx_mi_pin_host": (C.c_int, [C.c_void_p, C.c_uint64]),
     "jtx_mi_unpin_host": (C.c_int, [C.c_void_p]),

@@ -89,6 +89,11 @@ class Scene:
         binned-SAH tree for the edited geometry, node for node and primitive for primitive (`device_built` records where it was built)."""
         check(self._lib.jtx_mi_scene_rebuild(self.handle, int(maxPrimsInNode)))
 
+    def reserveRebuild(self):
+        """allocate the second buffer set and the builder's scratch of rebuildBVHOnDevice now (jtx_mi_scene_reserve_rebuild), so that
+        the first edit of a session costs what every later one does"""
+        check(self._lib.jtx_mi_scene_reserve_rebuild(self.handle))
+
     def bvh(self):
         i = self.info()
         nodes = (capi.BvhNode * max(1, i["num_nodes"]))()

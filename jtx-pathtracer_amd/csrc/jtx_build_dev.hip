@@ -76,6 +76,15 @@ struct Box { float lo[3], hi[3];
     JD void growPoint(const float p[3]) { grow(p, p); } };
 
 struct Counters { int nodes, large; };       // nodes created so far; bucket tables handed out for the NEXT round
+// The level a round works on lives ON THE DEVICE (round 4): the host enqueues rounds in batches with grids sized for the widest level
+// the round could have (2^round nodes, at most one per primitive) and reads the state back once per batch -- three or four
+// synchronisations per build instead of one per level (31 on the atrium).
+struct LevelState { int ls, le, nlarge, pad; };   // the open level = nodes [ls, le); its nodes of more than SMALL primitives
+__global__ void k_advance_level(Counters *cnt, LevelState *lv) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    lv->ls = lv->le; lv->le = cnt->nodes; lv->nlarge = cnt->large;
+    cnt->large = 0;                               // the tables of the next level are handed out while its nodes are created
+}
 
 // a freshly created node decides at once whether it is a leaf (bvh.cpp:18-28, 30-46) or stays open for the next round
 JD void classify(BNode &n, Counters *cnt) {
@@ -145,16 +154,17 @@ __global__ void k_root_init(BNode *nodes, const int *rootKeys, int np, Counters 
 }
 
 // ---- one round ----
-__global__ void __launch_bounds__(256) k_table_init(int *table, int entries) {
+__global__ void __launch_bounds__(256) k_table_init(int *table, const LevelState *lv) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= entries) return;
+    if (e >= lv->nlarge * NB) return;
     int *t = table + (size_t) e * TAB;
     t[0] = 0;
     for (int k = 0; k < 3; ++k) { t[1 + k] = fkey(FLT_MAX); t[4 + k] = fkey(-FLT_MAX); t[7 + k] = fkey(FLT_MAX); t[10 + k] = fkey(-FLT_MAX); }
 }
 
 __global__ void __launch_bounds__(256) k_bin_large(const BNode *nodes, const int *order, const int *prim_node, const float4 *blo, const float4 *bhi,
-                                                   int np, int *table) {
+                                                   int np, int *table, const LevelState *lv) {
+    if (lv->nlarge == 0) return;                  // (uniform: the whole grid leaves)
     __shared__ int ltab[MAXSLOT * NB * TAB];
     __shared__ int slotAux[MAXSLOT];
     __shared__ int waveTot[4];
@@ -214,9 +224,9 @@ __global__ void __launch_bounds__(256) k_bin_large(const BNode *nodes, const int
 }
 
 // bvh.cpp:69-127 on the 12 buckets of one node
-__global__ void __launch_bounds__(64) k_decide_large(BNode *nodes, int ls, int le, const int *table, int maxPrims, Counters *cnt) {
-    const int id = ls + blockIdx.x * 64 + threadIdx.x;
-    if (id >= le) return;
+__global__ void __launch_bounds__(64) k_decide_large(BNode *nodes, const LevelState *lv, const int *table, int maxPrims, Counters *cnt) {
+    const int id = lv->ls + blockIdx.x * 64 + threadIdx.x;
+    if (id >= lv->le || lv->nlarge == 0) return;
     BNode &n = nodes[id];
     if (n.child != -2 || n.count <= SMALL) return;
     const int *t = table + (size_t) n.aux * NB * TAB;
@@ -249,10 +259,10 @@ __global__ void __launch_bounds__(64) k_decide_large(BNode *nodes, int ls, int l
 
 // nodes of 2..SMALL primitives: one thread; the 11 candidate splits evaluated directly from the primitives (same sums:
 // counts are integers, boxes min / max)
-__global__ void __launch_bounds__(64) k_split_small(BNode *nodes, int ls, int le, const int *order, const float4 *blo, const float4 *bhi,
+__global__ void __launch_bounds__(64) k_split_small(BNode *nodes, const LevelState *lv, const int *order, const float4 *blo, const float4 *bhi,
                                                     int maxPrims, Counters *cnt) {
-    const int id = ls + blockIdx.x * 64 + threadIdx.x;
-    if (id >= le) return;
+    const int id = lv->ls + blockIdx.x * 64 + threadIdx.x;
+    if (id >= lv->le) return;
     BNode &n = nodes[id];
     if (n.child != -2 || n.count > SMALL) return;
     const int dim = n.dim, cnt_n = n.count, start = n.start;
@@ -396,6 +406,12 @@ __global__ void __launch_bounds__(256) k_emit(const BNode *nodes, const int *val
     else atomicAdd(&o.depthCount[n.depth], 1);
     atomicMax(&o.counters3[1], n.depth);
 }
+// wide levels: counters [0] granules used [1] wide nodes [2] failed [3] items of the next level [4] items of this level [5] levels filled
+__global__ void k_wide_advance(int *c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (c[4] > 0) c[5]++;
+    c[4] = c[3]; c[3] = 0;
+}
 __global__ void __launch_bounds__(256) k_level_nodes(const BNode *nodes, const int *vals, int nn, const int *levelBegin, int *cursor, int *level_nodes) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= nn) return;
@@ -460,10 +476,10 @@ __global__ void __launch_bounds__(256) k_wide_cuts(const int *level_nodes, int b
     for (int k = 2; k <= 8; ++k) F[8 * (size_t) i + k - 1] = best[k] < W ? best[k] : W;
 }
 struct WItem { int b, at; };           // binary node; granule of its wide node
-struct WideOut { uint4 *wide; int *wide_map; int *counters; long long cap; };    // counters: [0] granules used [1] wide nodes [2] failed [3] items of the next level
-__global__ void __launch_bounds__(64) k_wide_fill(const WItem *in, int nin, WItem *out, const float4 *nbox, const int *axisOf, const float *F, WideOut o) {
+struct WideOut { uint4 *wide; int *wide_map; int *counters; long long cap; };    // counters: see k_wide_advance
+__global__ void __launch_bounds__(64) k_wide_fill(const WItem *in, WItem *out, const float4 *nbox, const int *axisOf, const float *F, WideOut o) {
     const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= nin) return;
+    if (j >= o.counters[4] || o.counters[2]) return;
     const int b = in[j].b, at = in[j].at;
     struct TNode { int node, left, right; };
     TNode t[15]; int nt = 1;
@@ -566,9 +582,37 @@ struct Arena {            // one allocation for all temporaries of a build
 
 using namespace jtx;
 
-#define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (arena.base) (void) hipFree(arena.base); return e_; } } while (0)
+#define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+#define LAUNCH(kernel, grid, block, ...) do { hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__); BCHK(hipGetLastError()); } while (0)
 
-hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStream_t st) {
+// `arena`: the builder's temporaries, owned by the caller (the scene handle) and only ever grown -- an edit loop rebuilds without a
+// single allocation (round 3 took and gave back ~100 MB per call).  R.declined != nullptr: the build was not done for a stated reason
+// (nothing written that the caller may use); the caller falls back to the host build.
+static size_t arenaBytes(int np, size_t &scanBytes, size_t &sortBytes, hipStream_t st) {
+    const size_t maxNodes = 2 * (size_t) np;
+    scanBytes = sortBytes = 0;
+    (void) hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, (int *) nullptr, (int *) nullptr, np, st);
+    (void) hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, (unsigned long long *) nullptr, (unsigned long long *) nullptr, (int *) nullptr, (int *) nullptr,
+                                              (int) maxNodes, 0, 64, st);
+    const size_t maxLarge = (size_t) np / (SMALL + 1) + 2;
+    return maxNodes * sizeof(BNode) + 2 * (size_t) np * sizeof(float4) + 8 * (size_t) np * sizeof(int) + 2 * maxLarge * NB * TAB * sizeof(int)
+           + scanBytes + sortBytes + maxNodes * (2 * sizeof(unsigned long long) + 6 * sizeof(int)) + 8 * maxNodes * sizeof(float)
+           + 2 * maxNodes * sizeof(WItem) + (64 << 10);
+}
+
+hipError_t jtx_device_build_reserve(int np, DevBuildArena &arenaMem, hipStream_t st) {
+    if (np <= 0) return hipSuccess;
+    size_t a, b;
+    const size_t need = arenaBytes(np, a, b, st);
+    if (arenaMem.cap < need) {
+        if (arenaMem.base) { BCHK(hipStreamSynchronize(st)); (void) hipFree(arenaMem.base); arenaMem.base = nullptr; arenaMem.cap = 0; }
+        BCHK(hipMalloc(&arenaMem.base, need));
+        arenaMem.cap = need;
+    }
+    return hipSuccess;
+}
+
+hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildArena &arenaMem, DevBuildResult &R, hipStream_t st) {
     const int np = B.np;
     R = DevBuildResult{};
     if (np <= 0) return hipSuccess;
@@ -576,15 +620,10 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStre
     Arena arena;
     // ---- temporaries ----
     size_t scanBytes = 0, sortBytes = 0;
-    (void) hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, (int *) nullptr, (int *) nullptr, np, st);
-    (void) hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, (unsigned long long *) nullptr, (unsigned long long *) nullptr, (int *) nullptr, (int *) nullptr,
-                                              (int) maxNodes, 0, 64, st);
+    arena.cap = arenaBytes(np, scanBytes, sortBytes, st);
     const size_t maxLarge = (size_t) np / (SMALL + 1) + 2;
-    arena.cap = maxNodes * sizeof(BNode) + 2 * (size_t) np * sizeof(float4) + 8 * (size_t) np * sizeof(int) + 2 * maxLarge * NB * TAB * sizeof(int)
-              + scanBytes + sortBytes + maxNodes * (2 * sizeof(unsigned long long) + 6 * sizeof(int)) + 8 * maxNodes * sizeof(float)
-              + 2 * maxNodes * sizeof(WItem) + (64 << 10);
-    hipError_t e0 = hipMalloc((void **) &arena.base, arena.cap);
-    if (e0 != hipSuccess) return e0;
+    BCHK(jtx_device_build_reserve(np, arenaMem, st));
+    arena.base = (char *) arenaMem.base;
     BNode *nodes = arena.take<BNode>(maxNodes);
     float4 *blo = arena.take<float4>(np), *bhi = arena.take<float4>(np);
     int *order[2] = {arena.take<int>(np), arena.take<int>(np)};
@@ -597,60 +636,59 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStre
     int *parentDfs = arena.take<int>(maxNodes), *axisOf = arena.take<int>(maxNodes);
     float *F = arena.take<float>(8 * maxNodes);
     WItem *items[2] = {arena.take<WItem>(maxNodes), arena.take<WItem>(maxNodes)};
-    int *small = arena.take<int>(512);            // rootKeys[12] | Counters[2] @16 | counters3 @32 | depthCount[128] @64 | cursor[128] @192 | levelBegin[129] @320 | wide counters[4] @480
-    int *rootKeys = small; Counters *cnt = (Counters *) (small + 16); int *counters3 = small + 32, *depthCount = small + 64, *cursor = small + 192,
-        *levelBeginDev = small + 320, *wideCnt = small + 480;
-    if (arena.used > arena.cap) { (void) hipFree(arena.base); return hipErrorOutOfMemory; }
+    int *small = arena.take<int>(512);            // rootKeys[12] | Counters[2] @16 | LevelState @24 | counters3 @32 | depthCount[128] @64 | cursor[128] @192 | levelBegin[129] @320 | wide counters[6] @480
+    int *rootKeys = small; Counters *cnt = (Counters *) (small + 16); LevelState *lv = (LevelState *) (small + 24);
+    int *counters3 = small + 32, *depthCount = small + 64, *cursor = small + 192, *levelBeginDev = small + 320, *wideCnt = small + 480;
+    if (arena.used > arena.cap) return hipErrorOutOfMemory;
 
     BCHK(hipMemsetAsync(small, 0, 512 * sizeof(int), st));
-    hipLaunchKernelGGL(k_root_keys_init, dim3(1), dim3(64), 0, st, rootKeys, cnt);
-    hipLaunchKernelGGL(k_prim_boxes, dim3(blocks(np, 256)), dim3(256), 0, st, B.prim_src, B.mesh_xf, np, blo, bhi, rootKeys);
-    hipLaunchKernelGGL(k_root_init, dim3(blocks(np, 256)), dim3(256), 0, st, nodes, rootKeys, np, cnt, B.orig, order[0], pnode[0]);
+    LAUNCH(k_root_keys_init, dim3(1), dim3(64), rootKeys, cnt);
+    LAUNCH(k_prim_boxes, dim3(blocks(np, 256)), dim3(256), B.prim_src, B.mesh_xf, np, blo, bhi, rootKeys);
+    LAUNCH(k_root_init, dim3(blocks(np, 256)), dim3(256), nodes, rootKeys, np, cnt, B.orig, order[0], pnode[0]);
+    LAUNCH(k_advance_level, dim3(1), dim3(1), cnt, lv);                                   // level 0 = the root
 
-    // ---- the rounds: one level of the tree each ----
-    int ls = 0, le = 1, cur = 0;
-    Counters h{1, 0};
-    BCHK(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, st));
-    BCHK(hipStreamSynchronize(st));
-    int rounds = 0;
-    while (le > ls) {
-        if (++rounds > 120) { (void) hipFree(arena.base); return hipErrorUnknown; }      // deeper than any tree the traversal could walk (64-entry stack, scene.cpp:13)
-        const int nlarge = h.large;
-        // the tables of this round's large nodes were handed out while the nodes were created: reset the counter for the next
-        BCHK(hipMemsetAsync(&cnt->large, 0, sizeof(int), st));
-        if (nlarge > 0) {
-            hipLaunchKernelGGL(k_table_init, dim3(blocks((size_t) nlarge * NB, 256)), dim3(256), 0, st, table, nlarge * NB);
-            hipLaunchKernelGGL(k_bin_large, dim3(blocks(np, 256)), dim3(256), 0, st, nodes, order[cur], pnode[cur], blo, bhi, np, table);
-            hipLaunchKernelGGL(k_decide_large, dim3(blocks(le - ls, 64)), dim3(64), 0, st, nodes, ls, le, table, B.max_prims, cnt);
+    // ---- the rounds: one level of the tree each, enqueued in batches ----
+    int cur = 0, rounds = 0;
+    LevelState h{};
+    while (true) {
+        const int batch = rounds == 0 ? 12 : 6;
+        for (int b = 0; b < batch; ++b, ++rounds) {
+            const size_t wl = rounds < 30 ? ((size_t) 1 << rounds < (size_t) np ? (size_t) 1 << rounds : (size_t) np) : (size_t) np;   // nodes a level can have
+            const size_t wlarge = wl < maxLarge ? wl : maxLarge;
+            LAUNCH(k_table_init, dim3(blocks(wlarge * NB, 256)), dim3(256), table, lv);
+            LAUNCH(k_bin_large, dim3(blocks(np, 256)), dim3(256), nodes, order[cur], pnode[cur], blo, bhi, np, table, lv);
+            LAUNCH(k_decide_large, dim3(blocks(wl, 64)), dim3(64), nodes, lv, table, B.max_prims, cnt);
+            LAUNCH(k_split_small, dim3(blocks(wl, 64)), dim3(64), nodes, lv, order[cur], blo, bhi, B.max_prims, cnt);
+            LAUNCH(k_flags, dim3(blocks(np, 256)), dim3(256), nodes, order[cur], pnode[cur], blo, bhi, np, flags);
+            BCHK(hipcub::DeviceScan::ExclusiveSum(scanTmp, scanBytes, flags, scan, np, st));
+            LAUNCH(k_partition_slots, dim3(blocks(np, 256)), dim3(256), nodes, pnode[cur], flags, scan, np, slotF, slotT);
+            LAUNCH(k_scatter, dim3(blocks(np, 256)), dim3(256), nodes, order[cur], pnode[cur], flags, scan, slotF, slotT, np, order[cur ^ 1], pnode[cur ^ 1]);
+            cur ^= 1;
+            LAUNCH(k_advance_level, dim3(1), dim3(1), cnt, lv);
         }
-        hipLaunchKernelGGL(k_split_small, dim3(blocks(le - ls, 64)), dim3(64), 0, st, nodes, ls, le, order[cur], blo, bhi, B.max_prims, cnt);
-        hipLaunchKernelGGL(k_flags, dim3(blocks(np, 256)), dim3(256), 0, st, nodes, order[cur], pnode[cur], blo, bhi, np, flags);
-        BCHK(hipcub::DeviceScan::ExclusiveSum(scanTmp, scanBytes, flags, scan, np, st));
-        hipLaunchKernelGGL(k_partition_slots, dim3(blocks(np, 256)), dim3(256), 0, st, nodes, pnode[cur], flags, scan, np, slotF, slotT);
-        hipLaunchKernelGGL(k_scatter, dim3(blocks(np, 256)), dim3(256), 0, st, nodes, order[cur], pnode[cur], flags, scan, slotF, slotT, np, order[cur ^ 1],
-                           pnode[cur ^ 1]);
-        cur ^= 1;
-        BCHK(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, st));
+        BCHK(hipMemcpyAsync(&h, lv, sizeof h, hipMemcpyDeviceToHost, st));
         BCHK(hipStreamSynchronize(st));
-        ls = le; le = h.nodes;
-        if ((size_t) le > maxNodes) { (void) hipFree(arena.base); return hipErrorUnknown; }
+        if ((size_t) h.le > maxNodes) return hipErrorUnknown;
+        if (h.le == h.ls) break;                                                           // the last round opened nothing: the tree stands
+        if (rounds > 120) { R.declined = "the tree is deeper than 120 levels (the reference's traversal stack holds 64, scene.cpp:13)"; return hipSuccess; }
     }
-    const int nn = le;
+    const int nn = h.le;
     R.nn = nn;
 
     // ---- depth-first numbering, host-format nodes, sizes, lists ----
     int endBit = 8; while (endBit < 64 && ((unsigned long long) np << 8) >> endBit) ++endBit;
-    hipLaunchKernelGGL(k_sort_keys, dim3(blocks(nn, 256)), dim3(256), 0, st, nodes, nn, keys, vals);
+    LAUNCH(k_sort_keys, dim3(blocks(nn, 256)), dim3(256), nodes, nn, keys, vals);
     BCHK(hipcub::DeviceRadixSort::SortPairs(sortTmp, sortBytes, keys, keys2, vals, vals2, nn, 0, endBit, st));
-    hipLaunchKernelGGL(k_dfs_of, dim3(blocks(nn, 256)), dim3(256), 0, st, vals2, nn, dfsOf);
+    LAUNCH(k_dfs_of, dim3(blocks(nn, 256)), dim3(256), vals2, nn, dfsOf);
     EmitOut eo{B.nbox, (jtx_mi_bvh_node *) B.hnodes, parentDfs, axisOf, B.size, B.leaf_nodes, depthCount, counters3};
-    hipLaunchKernelGGL(k_emit, dim3(blocks(nn, 256)), dim3(256), 0, st, nodes, vals2, dfsOf, keys2, nn, eo);
+    LAUNCH(k_emit, dim3(blocks(nn, 256)), dim3(256), nodes, vals2, dfsOf, keys2, nn, eo);
     int hs[3 + 128];
     BCHK(hipMemcpyAsync(hs, counters3, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
     BCHK(hipMemcpyAsync(hs + 3, depthCount, 128 * sizeof(int), hipMemcpyDeviceToHost, st));
     BCHK(hipStreamSynchronize(st));
     R.nleaves = hs[0]; R.max_depth = hs[1];
-    if (R.max_depth >= 127 || hs[2]) { (void) hipFree(arena.base); return hipErrorUnknown; }
+    if (R.max_depth >= 127) { R.declined = "the tree is deeper than 126 levels"; return hipSuccess; }
+    if (hs[2]) { R.declined = "a leaf holds more than 65535 primitives (LinearBVHNode::numPrimitives is 16 bits, bvh.hpp:13)"; return hipSuccess; }
     int maxInterior = -1;
     for (int d = 0; d < 128; ++d) if (hs[3 + d] > 0) maxInterior = d;
     R.level_begin.assign((maxInterior > 0 ? maxInterior : 0) + 2, 0);                      // as jtx_mi_scene_create lays it out
@@ -658,46 +696,49 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildResult &R, hipStre
     {
         // (a SYNCHRONOUS copy: the runtime may read a pageable source of hipMemcpyAsync when the copy EXECUTES, not when it is
         //  enqueued -- a block-scoped array was gone by then, and k_level_nodes scattered through garbage offsets: an intermittent
-        //  illegal access, caught by the round-3 test runs)
+        //  illegal access, caught by the round-3 test runs.  The stream is idle here: the sync above.)
         int lb[129] = {0};
         for (size_t d = 0; d < R.level_begin.size() && d < 129; ++d) lb[d] = R.level_begin[d];
-        BCHK(hipStreamSynchronize(st));
         BCHK(hipMemcpy(levelBeginDev, lb, 129 * sizeof(int), hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(k_level_nodes, dim3(blocks(nn, 256)), dim3(256), 0, st, nodes, vals2, nn, levelBeginDev, cursor, B.level_nodes);
-    hipLaunchKernelGGL(k_positions, dim3(blocks(nn, 256)), dim3(256), 0, st, B.nbox, parentDfs, axisOf, B.size, nn, B.pos);
-    hipLaunchKernelGGL(k_gather_prims, dim3(blocks(np, 256)), dim3(256), 0, st, order[cur], np, B.prim_src, B.tris, B.shade, B.orig, B.prim_src_out, B.tris_out,
-                       B.shade_out, B.orig_out);
+    LAUNCH(k_level_nodes, dim3(blocks(nn, 256)), dim3(256), nodes, vals2, nn, levelBeginDev, cursor, B.level_nodes);
+    LAUNCH(k_positions, dim3(blocks(nn, 256)), dim3(256), B.nbox, parentDfs, axisOf, B.size, nn, B.pos);
+    LAUNCH(k_gather_prims, dim3(blocks(np, 256)), dim3(256), order[cur], np, B.prim_src, B.tris, B.shade, B.orig, B.prim_src_out, B.tris_out, B.shade_out, B.orig_out);
     BCHK(hipMemcpyAsync(B.order, order[cur], (size_t) np * sizeof(int), hipMemcpyDeviceToDevice, st));
 
-    // ---- the 8-ary nodes ----
+    // ---- the 8-ary nodes: levels enqueued in batches of 8, the work queue and its counters stay on the device ----
     R.wide_ok = false; R.num_wide = 0; R.wide_depth = 0; R.wide_granules = 0;
     if (B.wide && nn >= 2 && R.level_begin.size() >= 2) {
         BCHK(hipMemsetAsync(F, 0, 8 * (size_t) nn * sizeof(float), st));
         for (int d = (int) R.level_begin.size() - 2; d >= 0; --d) {
             const int count = R.level_begin[d + 1] - R.level_begin[d];
-            if (count > 0) hipLaunchKernelGGL(k_wide_cuts, dim3(blocks(count, 256)), dim3(256), 0, st, B.level_nodes, R.level_begin[d], count, B.nbox, F);
+            if (count > 0) LAUNCH(k_wide_cuts, dim3(blocks(count, 256)), dim3(256), B.level_nodes, R.level_begin[d], count, B.nbox, F);
         }
-        int wc[4] = {(int) jtxq::kFirstBlock, 0, 0, 0};
+        int wc[6] = {(int) jtxq::kFirstBlock, 0, 0, 0, 1, 0};
         WItem rootItem{0, (int) jtxq::kRootNode};
         BCHK(hipStreamSynchronize(st));
         BCHK(hipMemcpy(wideCnt, wc, sizeof wc, hipMemcpyHostToDevice));
         BCHK(hipMemcpy(items[0], &rootItem, sizeof rootItem, hipMemcpyHostToDevice));
         WideOut wo{B.wide, B.wide_map, wideCnt, (long long) B.wide_cap};
-        int nin = 1, wcur = 0, levels = 0;
+        const size_t maxWide = (size_t) nn / 2 + 1;
+        int wcur = 0, level = 0;
         bool ok = true;
-        while (nin > 0) {
-            if (++levels > 64) { ok = false; break; }
-            hipLaunchKernelGGL(k_wide_fill, dim3(blocks(nin, 64)), dim3(64), 0, st, items[wcur], nin, items[wcur ^ 1], B.nbox, axisOf, F, wo);
+        while (true) {
+            for (int b = 0; b < 8; ++b, ++level) {
+                size_t wl = 1; for (int i = 0; i < level && wl < maxWide; ++i) wl *= 8;
+                if (wl > maxWide) wl = maxWide;
+                LAUNCH(k_wide_fill, dim3(blocks(wl, 64)), dim3(64), items[wcur], items[wcur ^ 1], B.nbox, axisOf, F, wo);
+                LAUNCH(k_wide_advance, dim3(1), dim3(1), wideCnt);
+                wcur ^= 1;
+            }
             BCHK(hipMemcpyAsync(wc, wideCnt, sizeof wc, hipMemcpyDeviceToHost, st));
             BCHK(hipStreamSynchronize(st));
             if (wc[2]) { ok = false; break; }
-            nin = wc[3]; wcur ^= 1;
-            BCHK(hipMemsetAsync(wideCnt + 3, 0, sizeof(int), st));
+            if (wc[4] == 0) break;
+            if (level >= 64) { ok = false; break; }
         }
-        R.wide_ok = ok; R.wide_depth = levels; R.num_wide = wc[1]; R.wide_granules = (size_t) wc[0];
+        R.wide_ok = ok; R.wide_depth = wc[5]; R.num_wide = wc[1]; R.wide_granules = (size_t) wc[0];
     }
     BCHK(hipStreamSynchronize(st));
-    (void) hipFree(arena.base);
     return hipGetLastError();
 }

@@ -36,11 +36,13 @@ int fail(const std::string &msg) { g_err = msg; return 1; }
     } while (0)
 
 template <class T> struct DevBuf {
-    T *p = nullptr; size_t n = 0;
-    void alloc(size_t count) { release(); n = count; if (count) HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); }
+    T *p = nullptr; size_t n = 0, cap = 0;       // n: elements in use; cap: elements allocated
+    void alloc(size_t count) { release(); if (count) HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); n = cap = count; }
+    void ensure(size_t count) { if (count <= cap) n = count; else alloc(count); }     // grow-only: an edit loop re-uses its buffers
     void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
-    void release() { if (p) (void) hipFree(p); p = nullptr; n = 0; }
-    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
+    void fill(const std::vector<T> &v) { ensure(v.size()); if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    void release() { if (p) (void) hipFree(p); p = nullptr; n = cap = 0; }
+    void swap(DevBuf &o) noexcept { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
     ~DevBuf() { release(); }
 };
 
@@ -94,11 +96,22 @@ struct jtx_mi_scene {
     DevBuf<float> mesh_xf;
     DevBuf<int> leaf_nodes, level_nodes, rec_node, wide_map, wide_fail;
     std::vector<float> mesh_xf_host;
+    float *mesh_xf_pinned = nullptr;  // page-locked copy the uploads read: the first PAGEABLE host-to-device copy after a render took 8-20 ms (round 4 trace)
     std::vector<int> level_begin;    // per interior depth: offsets into level_nodes
     DevBuf<int> orig_id;             // per BVH-ordered primitive: its index in the scene's own Scene::triangles (input order of a device rebuild)
     int num_leaves = 0, num_wide = 0, refitted = 0, device_built = 0;
     bool xf_dirty = false;
     DevBuf<float4> lw_box; DevBuf<unsigned> lw_tab;   // flat leaf list of tiny scenes (traverseLeaves)
+    // jtx_mi_scene_rebuild: the SECOND set of every structure a rebuild replaces, plus the builder's scratch.  A rebuild writes the
+    // spare set while the live one stays untouched, and swaps the two when everything stands (failure-atomic; no allocation from the
+    // second rebuild on).  Costs the geometry's device memory twice -- HBM is sized for it.
+    struct RebuildSpare {
+        DevBuf<float4> src, tris, shade, nbox, tnodes, lw_box; DevBuf<int> orig, leaves, levels, rec_node, map; DevBuf<uint4> wide;
+        DevBuf<unsigned> lw_tab; DevBuf<DLight> lights;
+        DevBuf<int> order, pos, size; DevBuf<jtx_mi_bvh_node> hn;       // scratch
+        DevBuildArena arena;
+        ~RebuildSpare() { if (arena.base) (void) hipFree(arena.base); }
+    } spare;
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
     DevBuf<float4> slip_park;        // k_render_paths, JTX_SLIP_K > 0: extension rays parked across bounces
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (kWorkRing, used round-robin)
@@ -136,6 +149,7 @@ struct jtx_mi_scene {
         for (auto &e : free_events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         if (stream) (void) hipStreamDestroy(stream);
         if (stop_host) (void) hipHostFree(stop_host);
+        if (mesh_xf_pinned) (void) hipHostFree(mesh_xf_pinned);
         if (pin_img) (void) hipHostFree(pin_img);
         if (pin_acc) (void) hipHostFree(pin_acc);
     }
@@ -366,41 +380,40 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
 
 // Tiny scenes: the flat leaf list of traverseLeaves (leaves in b.nodes order; per octant: leaf at position p, position of
 // leaf l -- read off the threaded orderings).  pos[k * nn + g]: node g's place in octant k's order.
-void buildLeafTables(jtx_mi_scene &s, const std::vector<int> &pos) {
-    const jtxh::BvhResult &b = s.bvh;
-    const size_t nn = b.nodes.size();
-    s.lw_box.release(); s.lw_tab.release(); s.dev.lw_box = nullptr; s.dev.lw_tab = nullptr; s.dev.lw_leaves = 0;
-    {
-        std::vector<int> leafId(nn, -1); int nl = 0;
-        for (size_t i = 0; i < nn; ++i) if (b.nodes[i].num_prims) leafId[i] = nl++;
-        if (nl > 0 && nl <= 32 && nn > 1) {
-            const int npad = (nl + 3) & ~3;                                     // phase A of traverseLeaves runs in groups of four
-            std::vector<float4> lb(2 * (size_t) npad, make_float4(0.f, 0.f, 0.f, 0.f));
-            for (size_t i = 0; i < nn; ++i) if (leafId[i] >= 0) {
-                const jtx_mi_bvh_node &n = b.nodes[i];
-                const int z = n.offset, w = n.num_prims; float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
-                lb[2 * (size_t) leafId[i]] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
-                lb[2 * (size_t) leafId[i] + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
-            }
-            std::vector<unsigned> tab(128, 0u);
-            for (int k = 0; k < 8; ++k) {
-                std::vector<int> at(nn, -1);                                    // node standing at position i of octant k's order
-                for (size_t g = 0; g < nn; ++g) at[(size_t) pos[(size_t) k * nn + g]] = (int) g;
-                int p2 = 0;
-                for (size_t i = 0; i < nn; ++i) {
-                    const int l = leafId[at[i]];
-                    if (l < 0) continue;
-                    tab[16 * k + (p2 >> 2)] |= (unsigned) l << (8 * (p2 & 3));                    // leaf visited at position p2
-                    tab[16 * k + 8 + (l >> 2)] |= (unsigned) p2 << (8 * (l & 3));                 // position of leaf l
-                    ++p2;
-                }
-                for (int l = nl; l < npad; ++l) tab[16 * k + 8 + (l >> 2)] |= (unsigned) l << (8 * (l & 3));   // padding: positions >= nl
-            }
-            s.lw_box.upload(lb); s.lw_tab.upload(tab);
-            s.dev.lw_box = s.lw_box.p; s.dev.lw_tab = s.lw_tab.p; s.dev.lw_leaves = nl;
-        }
+// -> number of leaves in the list (0: none -- more than 32 leaves, or a single node); box / tab filled (grow-only) when > 0
+int buildLeafTables(const std::vector<jtx_mi_bvh_node> &nodes, const std::vector<int> &pos, DevBuf<float4> &box, DevBuf<unsigned> &tabBuf) {
+    const size_t nn = nodes.size();
+    std::vector<int> leafId(nn, -1); int nl = 0;
+    for (size_t i = 0; i < nn; ++i) if (nodes[i].num_prims) leafId[i] = nl++;
+    if (!(nl > 0 && nl <= 32 && nn > 1)) return 0;
+    const int npad = (nl + 3) & ~3;                                     // phase A of traverseLeaves runs in groups of four
+    std::vector<float4> lb(2 * (size_t) npad, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t i = 0; i < nn; ++i) if (leafId[i] >= 0) {
+        const jtx_mi_bvh_node &n = nodes[i];
+        const int z = n.offset, w = n.num_prims; float fz, fw; std::memcpy(&fz, &z, 4); std::memcpy(&fw, &w, 4);
+        lb[2 * (size_t) leafId[i]] = make_float4(n.pmin[0], n.pmax[0], n.pmin[1], n.pmax[1]);
+        lb[2 * (size_t) leafId[i] + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
     }
-
+    std::vector<unsigned> tab(128, 0u);
+    for (int k = 0; k < 8; ++k) {
+        std::vector<int> at(nn, -1);                                    // node standing at position i of octant k's order
+        for (size_t g = 0; g < nn; ++g) at[(size_t) pos[(size_t) k * nn + g]] = (int) g;
+        int p2 = 0;
+        for (size_t i = 0; i < nn; ++i) {
+            const int l = leafId[at[i]];
+            if (l < 0) continue;
+            tab[16 * k + (p2 >> 2)] |= (unsigned) l << (8 * (p2 & 3));                    // leaf visited at position p2
+            tab[16 * k + 8 + (l >> 2)] |= (unsigned) p2 << (8 * (l & 3));                 // position of leaf l
+            ++p2;
+        }
+        for (int l = nl; l < npad; ++l) tab[16 * k + 8 + (l >> 2)] |= (unsigned) l << (8 * (l & 3));   // padding: positions >= nl
+    }
+    box.fill(lb); tabBuf.fill(tab);
+    return nl;
+}
+void buildLeafTables(jtx_mi_scene &s, const std::vector<int> &pos) {
+    const int nl = buildLeafTables(s.bvh.nodes, pos, s.lw_box, s.lw_tab);
+    s.dev.lw_box = nl ? s.lw_box.p : nullptr; s.dev.lw_tab = nl ? s.lw_tab.p : nullptr; s.dev.lw_leaves = nl;
 }
 
 // Flatten the scene into the kernel layout documented in jtx_scene_dev.hpp.
@@ -1061,6 +1074,8 @@ int jtx_mi_scene_set_transform(jtx_mi_scene *s, int32_t mesh, const float *m16) 
     return 0;
 }
 
+namespace { void uploadTransforms(jtx_mi_scene &sc); }
+
 // Scene::rebuildBVH's place in the edit loop (display.cpp:902-905), on the device and with the topology kept (jtx_refit.hip)
 int jtx_mi_scene_refit(jtx_mi_scene *s) {
     try {
@@ -1077,7 +1092,8 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
             fprintf(stderr, "[jtx refit] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count());
             t0 = n;
         };
-        HIPCHK(hipMemcpyAsync(s->mesh_xf.p, s->mesh_xf_host.data(), s->mesh_xf_host.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        uploadTransforms(*s);
+        lap("transforms to the device");
         HIPCHK(hipMemsetAsync(s->wide_fail.p, 0, sizeof(int), s->stream));
         RefitArgs a{};
         a.prim_src = s->prim_src.p; a.mesh_xf = s->mesh_xf.p; a.tris = s->tris.p; a.shade = s->shade.p; a.pbox = s->pbox.p;
@@ -1130,7 +1146,46 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
 
 // Scene::rebuildBVH (scene.hpp:66-69) in the edit loop (display.cpp:545-588, 902-905), ON THE DEVICE: a new TOPOLOGY for the
 // edited geometry -- the reference's binned-SAH tree, node for node (jtx_build_dev.hip) -- and every structure derived from it.
-int jtx_mi_scene_rebuild(jtx_mi_scene *s, int32_t max_prims_in_node) {
+namespace {
+// the spare set of jtx_mi_scene_rebuild and the builder's scratch, sized for the scene's primitives (grow-only: a second call allocates nothing)
+void reserveRebuild(jtx_mi_scene &sc, bool &wantWide, bool &wideOnDevice, size_t &wideCap) {
+    jtx_mi_scene::RebuildSpare &sp = sc.spare;
+    const int np = sc.dev.num_prims;
+    const size_t maxN = 2 * (size_t) np;
+    sp.src.ensure(5 * (size_t) np); sp.tris.ensure(3 * (size_t) np); sp.shade.ensure(4 * (size_t) np); sp.orig.ensure(np); sp.order.ensure(np);
+    sp.nbox.ensure(2 * maxN); sp.hn.ensure(maxN); sp.leaves.ensure(maxN); sp.levels.ensure(maxN); sp.pos.ensure(8 * maxN); sp.size.ensure(maxN);
+    const char *off = getenv("JTX_NO_WIDE");
+    wantWide = !(off && atoi(off));
+    // the device builder knows the area-optimal treelet cut only: under JTX_WIDE_SAH_CUT=0 (the greedy cut of round 1, a diagnostic)
+    // the 8-ary nodes come from the host's buildWide, as at scene creation
+    static const int sahCut = [] { const char *e = getenv("JTX_WIDE_SAH_CUT"); return e ? atoi(e) : 1; }();
+    wideOnDevice = wantWide && sahCut;
+    wideCap = jtxq::kNodeG * (size_t) np + 2 * (size_t) np + 32;     // every interior node its own wide node at worst
+    if (wideOnDevice) { sp.wide.ensure(wideCap); sp.map.ensure(16 * (size_t) np); }
+}
+}
+
+static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit);
+
+// A DRY RUN of the rebuild: everything jtx_mi_scene_rebuild does except its commit section.  hipMalloc alone would not do: device
+// memory is mapped at first touch and a translation unit's code object is loaded at its first launch -- measured on the atrium,
+// allocation 0.9 ms, but the first rebuild still 26 ms against 6.8 for the second.  After the dry run the first rebuild is a second one.
+int jtx_mi_scene_reserve_rebuild(jtx_mi_scene *s) { return rebuildImpl(s, 1, false); }
+
+namespace {
+// Mesh::transform of every mesh to the device (enqueued on the scene's stream), from page-locked memory
+void uploadTransforms(jtx_mi_scene &sc) {
+    const size_t n = sc.mesh_xf_host.size();
+    if (!n) return;
+    if (!sc.mesh_xf_pinned) HIPCHK(hipHostMalloc((void **) &sc.mesh_xf_pinned, n * sizeof(float), hipHostMallocDefault));
+    std::memcpy(sc.mesh_xf_pinned, sc.mesh_xf_host.data(), n * sizeof(float));
+    HIPCHK(hipMemcpyAsync(sc.mesh_xf.p, sc.mesh_xf_pinned, n * sizeof(float), hipMemcpyHostToDevice, sc.stream));
+}
+}
+
+int jtx_mi_scene_rebuild(jtx_mi_scene *s, int32_t max_prims_in_node) { return rebuildImpl(s, max_prims_in_node, true); }
+
+static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit) {
     try {
         if (!s) throw std::runtime_error("null scene");
         DeviceGuard dg(s->device);
@@ -1146,84 +1201,101 @@ int jtx_mi_scene_rebuild(jtx_mi_scene *s, int32_t max_prims_in_node) {
             fprintf(stderr, "[jtx rebuild] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t0).count());
             t0 = n;
         };
-        HIPCHK(hipStreamSynchronize(s->stream));                  // frames in flight read the buffers that are replaced below
-        HIPCHK(hipMemcpyAsync(s->mesh_xf.p, s->mesh_xf_host.data(), s->mesh_xf_host.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
-        const size_t maxN = 2 * (size_t) np;
-        DevBuf<float4> src2, tris2, shade2, nbox2; DevBuf<int> orig2, order, leaves2, levels2, pos, size, map2; DevBuf<uint4> wide2;
-        DevBuf<jtx_mi_bvh_node> hn;
-        src2.alloc(5 * (size_t) np); tris2.alloc(3 * (size_t) np); shade2.alloc(4 * (size_t) np); orig2.alloc(np); order.alloc(np);
-        nbox2.alloc(2 * maxN); hn.alloc(maxN); leaves2.alloc(maxN); levels2.alloc(maxN); pos.alloc(8 * maxN); size.alloc(maxN);
-        const char *off = getenv("JTX_NO_WIDE");
-        const bool wantWide = !(off && atoi(off));
-        const size_t wideCap = jtxq::kNodeG * (size_t) np + 2 * (size_t) np + 32;     // every interior node its own wide node at worst
-        if (wantWide) { wide2.alloc(wideCap); map2.alloc(16 * (size_t) np); }
-        lap("allocate");
+        // FAILURE-ATOMIC: everything is built into the spare set (jtx_mi_scene::spare) and into locals; the scene is touched
+        // only in the commit section at the end, which cannot throw.  Whatever fails before leaves the scene as it was (copies that
+        // were enqueued into locals are drained first: ~Drain).
+        struct Drain { hipStream_t st; ~Drain() { (void) hipStreamSynchronize(st); } } drain{s->stream};
+        jtx_mi_scene::RebuildSpare &sp = s->spare;
+        HIPCHK(hipStreamSynchronize(s->stream));                  // frames in flight read the live set; the spare set may still be read by them too
+        lap("wait for frames in flight");
+        uploadTransforms(*s);
+        lap("transforms to the device");
+        bool wantWide, wideOnDevice; size_t wideCap;
+        reserveRebuild(*s, wantWide, wideOnDevice, wideCap);
+        lap("buffers (allocated by the first rebuild only)");
         DevBuildBuffers B{};
         B.prim_src = s->prim_src.p; B.tris = s->tris.p; B.shade = s->shade.p; B.orig = s->orig_id.p; B.mesh_xf = s->mesh_xf.p; B.np = np;
         B.max_prims = max_prims_in_node > 0 ? max_prims_in_node : 1;
-        B.prim_src_out = src2.p; B.tris_out = tris2.p; B.shade_out = shade2.p; B.orig_out = orig2.p;
-        B.nbox = nbox2.p; B.hnodes = hn.p; B.order = order.p; B.leaf_nodes = leaves2.p; B.level_nodes = levels2.p; B.pos = pos.p; B.size = size.p;
-        B.wide = wantWide ? wide2.p : nullptr; B.wide_map = map2.p; B.wide_cap = wideCap;
+        B.prim_src_out = sp.src.p; B.tris_out = sp.tris.p; B.shade_out = sp.shade.p; B.orig_out = sp.orig.p;
+        B.nbox = sp.nbox.p; B.hnodes = sp.hn.p; B.order = sp.order.p; B.leaf_nodes = sp.leaves.p; B.level_nodes = sp.levels.p; B.pos = sp.pos.p; B.size = sp.size.p;
+        B.wide = wideOnDevice ? sp.wide.p : nullptr; B.wide_map = sp.map.p; B.wide_cap = wideCap;
         DevBuildResult R;
-        HIPCHK(jtx_device_build(B, R, s->stream));
+        HIPCHK(jtx_device_build(B, sp.arena, R, s->stream));
+        if (R.declined)
+            throw std::runtime_error(std::string("the device builder declined: ") + R.declined + "; the scene is unchanged -- rebuild it on the host (Scene::buildBVH)");
         lap("device build");
         const int nn = R.nn;
-        // ---- the host's copy: nodes, Scene::triangles_ in leaf order ----
+        // ---- host copies (locals): nodes, Scene::triangles_ in leaf order ----
+        std::vector<jtx_mi_bvh_node> nodes2((size_t) nn);
         std::vector<int> ord(np);
-        s->bvh.nodes.resize(nn);
-        HIPCHK(hipMemcpyAsync(s->bvh.nodes.data(), hn.p, (size_t) nn * sizeof(jtx_mi_bvh_node), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(ord.data(), order.p, (size_t) np * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        // ---- swap the new structures in; triangle / shading records recomputed from the re-ordered sources ----
-        s->prim_src.swap(src2); s->tris.swap(tris2); s->shade.swap(shade2); s->orig_id.swap(orig2);
-        s->nbox.swap(nbox2); s->leaf_nodes.swap(leaves2); s->level_nodes.swap(levels2);
-        if ((size_t) s->pbox.n < 2 * (size_t) np) s->pbox.alloc(2 * (size_t) np);
-        s->tnodes.alloc(2 * 8 * (size_t) nn); s->rec_node.alloc(8 * (size_t) nn);
+        HIPCHK(hipMemcpyAsync(nodes2.data(), sp.hn.p, (size_t) nn * sizeof(jtx_mi_bvh_node), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(ord.data(), sp.order.p, (size_t) np * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        // ---- triangle / shading records recomputed from the re-ordered sources; the 8 threaded orderings ----
+        if (s->pbox.cap < 2 * (size_t) np) s->pbox.alloc(2 * (size_t) np);          // (scratch of the refit kernels, not read by any render)
+        sp.tnodes.ensure(2 * 8 * (size_t) nn); sp.rec_node.ensure(8 * (size_t) nn);
         RefitArgs a{};
-        a.prim_src = s->prim_src.p; a.mesh_xf = s->mesh_xf.p; a.tris = s->tris.p; a.shade = s->shade.p; a.pbox = s->pbox.p; a.num_prims = np;
+        a.prim_src = sp.src.p; a.mesh_xf = s->mesh_xf.p; a.tris = sp.tris.p; a.shade = sp.shade.p; a.pbox = s->pbox.p; a.num_prims = np;
         HIPCHK(jtx_launch_refit_prims(a, s->stream));
-        HIPCHK(jtx_launch_build_threaded(s->nbox.p, pos.p, size.p, nn, s->tnodes.p, s->rec_node.p, s->stream));
+        HIPCHK(jtx_launch_build_threaded(sp.nbox.p, sp.pos.p, sp.size.p, nn, sp.tnodes.p, sp.rec_node.p, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         lap("records, 8 threaded orderings");
-        {
-            std::vector<jtx_mi_tri_ref> refs(np); std::vector<int32_t> orig(np);
-            for (int i = 0; i < np; ++i) { refs[i] = s->bvh.refs[ord[i]]; orig[i] = s->bvh.orig[ord[i]]; }
-            s->bvh.refs.swap(refs); s->bvh.orig.swap(orig);
+        std::vector<jtx_mi_tri_ref> refs(np); std::vector<int32_t> orig(np);
+        for (int i = 0; i < np; ++i) { refs[i] = s->bvh.refs[ord[i]]; orig[i] = s->bvh.orig[ord[i]]; }
+        // ---- 8-ary nodes ----
+        bool wideOk = wideOnDevice && R.wide_ok && R.wide_depth <= kMaxWideDepth;
+        int wideDepth = R.wide_depth, numWide = R.num_wide; size_t wideGranules = R.wide_granules;
+        if (wantWide && !wideOnDevice) {
+            std::vector<uint4> wh; std::vector<int32_t> wm; int wd = 0;
+            if (buildWide(nodes2, wh, wd, &wm) && wd <= kMaxWideDepth) {
+                sp.wide.fill(wh); sp.map.ensure(wm.size());
+                if (!wm.empty()) HIPCHK(hipMemcpy(sp.map.p, wm.data(), wm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                wideOk = true; wideDepth = wd; numWide = (int) (wm.size() / 16); wideGranules = wh.size();
+            }
         }
-        s->bvh.max_depth = R.max_depth;
-        s->level_begin = R.level_begin;
+        if (!s->wide_fail.p) s->wide_fail.alloc(1);
+        // ---- tiny scenes: the flat leaf list needs the positions on the host ----
+        int nleafList = 0;
+        {
+            int nl = 0; for (const jtx_mi_bvh_node &n : nodes2) if (n.num_prims) ++nl;
+            if (nl > 0 && nl <= 32 && nn > 1) {
+                std::vector<int> hpos(8 * (size_t) nn);
+                HIPCHK(hipMemcpy(hpos.data(), sp.pos.p, hpos.size() * sizeof(int), hipMemcpyDeviceToHost));
+                nleafList = buildLeafTables(nodes2, hpos, sp.lw_box, sp.lw_tab);
+            }
+        }
+        // ---- scene radius (scene.hpp:81-84) and with it the DISTANT lights (scene.cpp:128-134) ----
+        const jtx_mi_bvh_node &r = nodes2[0];
+        const float dx = r.pmax[0] - r.pmin[0], dy = r.pmax[1] - r.pmin[1], dz = r.pmax[2] - r.pmin[2];
+        const float radius = std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
+        bool newLights = false;
+        if (s->lights.n) {
+            std::vector<DLight> ls(s->lights.n);
+            HIPCHK(hipMemcpy(ls.data(), s->lights.p, ls.size() * sizeof(DLight), hipMemcpyDeviceToHost));
+            for (auto &l : ls) if (l.type == 1) { l.scene_radius = radius; newLights = true; }
+            if (newLights) sp.lights.fill(ls);
+        }
+        if (!commit) return 0;                                                 // jtx_mi_scene_reserve_rebuild: memory touched, kernels loaded, scene untouched
+        if (getenv("JTX_FAIL_REBUILD_BEFORE_COMMIT")) throw std::runtime_error("injected failure before the commit (JTX_FAIL_REBUILD_BEFORE_COMMIT)");   // tests: failure atomicity
+        // ---- commit: swaps and assignments only -- nothing below can throw ----
+        s->prim_src.swap(sp.src); s->tris.swap(sp.tris); s->shade.swap(sp.shade); s->orig_id.swap(sp.orig);
+        s->nbox.swap(sp.nbox); s->leaf_nodes.swap(sp.leaves); s->level_nodes.swap(sp.levels);
+        s->tnodes.swap(sp.tnodes); s->rec_node.swap(sp.rec_node);
+        s->bvh.nodes.swap(nodes2); s->bvh.refs.swap(refs); s->bvh.orig.swap(orig);
+        s->bvh.max_depth = R.max_depth; s->bvh.scene_radius = radius;
+        s->level_begin.swap(R.level_begin);
         s->num_leaves = R.nleaves;
         s->dev.tnodes = s->tnodes.p; s->dev.tris = s->tris.p; s->dev.shade = s->shade.p;
         s->dev.num_nodes = nn;
         s->dev.lds_threaded = (nn > 0 && 8 * (size_t) nn * 32 + (size_t) np * 48 <= kLdsThreadedBudget) ? 1 : 0;
-        // ---- 8-ary nodes ----
         s->dev.wide = nullptr; s->dev.wide_depth = 0; s->num_wide = 0;
-        if (wantWide && R.wide_ok && R.wide_depth <= kMaxWideDepth) {
-            s->wide.swap(wide2); s->wide_map.swap(map2);
-            s->wide.n = R.wide_granules;                                    // (the allocation is larger; n = granules in use, as after a host build)
-            s->dev.wide = s->wide.p; s->dev.wide_depth = R.wide_depth; s->num_wide = R.num_wide;
+        if (wideOk) {
+            s->wide.swap(sp.wide); s->wide_map.swap(sp.map);
+            s->wide.n = wideGranules;                                       // (the allocation is larger; n = granules in use, as after a host build)
+            s->dev.wide = s->wide.p; s->dev.wide_depth = wideDepth; s->num_wide = numWide;
         }
-        if (!s->wide_fail.p) s->wide_fail.alloc(1);
-        // ---- tiny scenes: the flat leaf list needs the positions on the host ----
-        {
-            int nl = 0; for (const jtx_mi_bvh_node &n : s->bvh.nodes) if (n.num_prims) ++nl;
-            std::vector<int> hpos;
-            if (nl > 0 && nl <= 32 && nn > 1) { hpos.resize(8 * (size_t) nn); HIPCHK(hipMemcpy(hpos.data(), pos.p, hpos.size() * sizeof(int), hipMemcpyDeviceToHost)); }
-            else hpos.assign(8 * (size_t) nn, 0);
-            buildLeafTables(*s, hpos);
-        }
-        // ---- scene radius (scene.hpp:81-84) and with it the DISTANT lights (scene.cpp:128-134) ----
-        {
-            const jtx_mi_bvh_node &r = s->bvh.nodes[0];
-            const float dx = r.pmax[0] - r.pmin[0], dy = r.pmax[1] - r.pmin[1], dz = r.pmax[2] - r.pmin[2];
-            s->bvh.scene_radius = std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
-            if (s->lights.n) {
-                std::vector<DLight> ls(s->lights.n);
-                HIPCHK(hipMemcpy(ls.data(), s->lights.p, ls.size() * sizeof(DLight), hipMemcpyDeviceToHost));
-                bool any = false;
-                for (auto &l : ls) if (l.type == 1) { l.scene_radius = s->bvh.scene_radius; any = true; }
-                if (any) HIPCHK(hipMemcpy(s->lights.p, ls.data(), ls.size() * sizeof(DLight), hipMemcpyHostToDevice));
-            }
-        }
+        s->lw_box.swap(sp.lw_box); s->lw_tab.swap(sp.lw_tab);
+        s->dev.lw_box = nleafList ? s->lw_box.p : nullptr; s->dev.lw_tab = nleafList ? s->lw_tab.p : nullptr; s->dev.lw_leaves = nleafList;
+        if (newLights) { s->lights.swap(sp.lights); s->dev.lights = s->lights.p; }
         s->refitted = 0; s->device_built = 1; s->xf_dirty = false;
         lap("host copies, lights");
         return 0;

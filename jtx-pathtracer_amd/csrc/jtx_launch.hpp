@@ -91,14 +91,18 @@ struct DevBuildBuffers {               // caller-allocated device buffers, sized
     // out: the primitives in the new leaf order, the nodes in depth-first order, lists for the refit / threading stages
     float4 *prim_src_out, *tris_out, *shade_out; int *orig_out;
     float4 *nbox; void *hnodes; int *order; int *leaf_nodes, *level_nodes; int *pos, *size;
-    uint4 *wide; int *wide_map; size_t wide_cap;     // wide == nullptr: no 8-ary nodes wanted
+    uint4 *wide; int *wide_map; size_t wide_cap;     // wide == nullptr: no 8-ary nodes wanted (the builder knows the area-optimal cut only:
+                                                     // under JTX_WIDE_SAH_CUT=0 the caller builds them on the host, as scene_create does)
 };
+struct DevBuildArena { void *base = nullptr; size_t cap = 0; };   // the builder's temporaries: owned by the caller, grown on demand, never shrunk
 struct DevBuildResult {
     int nn = 0, nleaves = 0, max_depth = 0, num_wide = 0, wide_depth = 0; size_t wide_granules = 0; bool wide_ok = false;
     std::vector<int> level_begin;      // interior nodes by depth: offsets into level_nodes
+    const char *declined = nullptr;    // != nullptr: the device builder did not build, for this reason (the caller builds on the host)
 };
 } // namespace jtx
-hipError_t jtx_device_build(const jtx::DevBuildBuffers &b, jtx::DevBuildResult &r, hipStream_t st);
+hipError_t jtx_device_build(const jtx::DevBuildBuffers &b, jtx::DevBuildArena &arena, jtx::DevBuildResult &r, hipStream_t st);
+hipError_t jtx_device_build_reserve(int np, jtx::DevBuildArena &arena, hipStream_t st);      // the builder's scratch for np primitives, ahead of the first build
 hipError_t jtx_launch_refit_prims(const jtx::RefitArgs &a, hipStream_t st);
 hipError_t jtx_launch_build_threaded(const float4 *nbox, const int *pos, const int *size, int nn, float4 *tnodes, int *rec_node, hipStream_t st);
 hipError_t jtx_launch_refit(const jtx::RefitArgs &a, const int *level_begin, int num_levels, hipStream_t st);

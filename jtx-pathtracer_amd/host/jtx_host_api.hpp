@@ -131,6 +131,8 @@ public:
     // Scene::rebuildBVH for the edit loop without the host: the edited transforms go to the device, where the reference's
     // binned-SAH tree (bvh.cpp:9-133) is built anew, node for node and primitive for primitive, with everything derived from it
     // (jtx_mi_scene_rebuild).  Single-device scenes only.
+    // the second buffer set of rebuildBVHOnDevice, allocated ahead of the first edit (jtx_mi_scene_reserve_rebuild); optional
+    void reserveRebuild() { if (handle_) check(jtx_mi_scene_reserve_rebuild(handle_)); }
     void rebuildBVHOnDevice(int maxPrimsInNode = 1) {
         if (!handle_) { buildBVH(maxPrimsInNode); return; }
         for (size_t i = 0; i < meshes.size(); ++i) check(jtx_mi_scene_set_transform(handle_, (int) i, &meshes[i].transform.m[0][0]));

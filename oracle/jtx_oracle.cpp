@@ -1432,32 +1432,33 @@ void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int
                 cv.notify_all();
             } else cv.wait(lk, [&] { return generation != gen; });
         };
-        // (a thread that cannot be created -- a container's thread limit -- must not take the process down: probe how many there
-        //  are to be had first, the barrier needs the exact number)
-        {
-            std::vector<std::thread> probe; std::atomic<bool> go{false};
-            struct JoinAll { std::vector<std::thread> &v; std::atomic<bool> &g; ~JoinAll() { g.store(true); for (auto &t : v) if (t.joinable()) t.join(); } } ja{probe, go};
-            probe.reserve(threads);
-            int got = 0;
-            for (int t = 0; t < threads; ++t) {
-                try { probe.emplace_back([&go] { while (!go.load()) std::this_thread::yield(); }); ++got; } catch (const std::system_error &) { break; }
-            }
-            if (got < threads) threads = got > 1 ? got / 2 : 1;
-        }
+        // (a thread that cannot be created -- a container's thread limit -- must not take the process down, and the barrier needs the
+        //  exact number of participants: the workers wait at a gate until the pool stands, the barrier then counts the threads that
+        //  exist -- ADVICE r3: the earlier probe-then-create left a window in which the limit could change)
+        std::atomic<int> gate{0};                                               // 0: wait, 1: go
         std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t)
-            pool.emplace_back([&, t] {
+        struct JoinAll { std::vector<std::thread> &v; std::atomic<int> &g; ~JoinAll() { g.store(1); for (auto &t : v) if (t.joinable()) t.join(); } } ja{pool, gate};
+        pool.reserve(threads);
+        auto worker = [&](int t) {
+            while (gate.load() == 0) std::this_thread::yield();
+            while (true) {
+                const int cs = current.load();
+                if (cs >= sample_end) break;                                    // stopRender_
                 while (true) {
-                    const int cs = current.load();
-                    if (cs >= sample_end) break;                                // stopRender_
-                    while (true) {
-                        size_t j = next.fetch_add(1, std::memory_order_relaxed);
-                        if (j >= jobs.size()) break;
-                        tileSamples(jobs[j], cs, cs + 1, count ? &tc[t] : nullptr);
-                    }
-                    arriveAndWait();
+                    size_t j = next.fetch_add(1, std::memory_order_relaxed);
+                    if (j >= jobs.size()) break;
+                    tileSamples(jobs[j], cs, cs + 1, count ? &tc[t] : nullptr);
                 }
-            });
+                arriveAndWait();
+            }
+        };
+        int got = 1;                                                            // the calling thread is participant 0
+        for (int t = 1; t < threads; ++t) {
+            try { pool.emplace_back(worker, t); ++got; } catch (const std::system_error &) { break; }
+        }
+        threads = got;                                                          // what arriveAndWait counts to (nobody has passed the gate yet)
+        gate.store(1);
+        worker(0);
         for (auto &th : pool) th.join();
     } else {
         std::atomic<size_t> next{0};

@@ -1224,6 +1224,8 @@ def test_device_rebuild_gives_the_reference_tree(gpu, which, max_prims):
     osc = ol.OracleScene(data)
     cam = data.camera_desc(W, H, 2, 2, 5)
     acc, img, cnt = osc.render(cam)
+    if which == "atrium":
+        sc.reserveRebuild(); sc.reserveRebuild()                        # the edit loop's memory ahead of the first edit (idempotent)
     sc.rebuildBVHOnDevice(max_prims)
     info = sc.info()
     assert info["device_built"] and not info["refitted"]
@@ -1283,6 +1285,35 @@ def test_device_rebuild_full_size_atrium(gpu, atrium_full):
             assert_same_f32(g.acc_, ref.acc_, f"atrium_full: frame on the device-built structures ({again})"); assert (g.img_ == ref.img_).all()
     finally:
         fresh.destroy()
+
+
+def test_device_rebuild_is_failure_atomic(gpu, monkeypatch):
+    """a rebuild that fails late -- here right before its commit section, after every kernel has run and every
+    new buffer has been written -- leaves the scene exactly as it was: same tree, same frame, and the next rebuild works."""
+    data = gpu.scenes.atrium(target_tris=12000)
+    sc = gpu.Scene(data); sc.buildBVH()
+    try:
+        n0, r0 = sc.bvh()
+        ref = gpu.StaticCamera(160, 90, data.camera, 2, 2, 5); ref.render(sc, count_rays=False)
+        m = np.eye(4, dtype=np.float32); m[0, 3] = 2.5
+        sc.setTransform(0, m)
+        monkeypatch.setenv("JTX_FAIL_REBUILD_BEFORE_COMMIT", "1")
+        with pytest.raises(gpu._capi.JtxMiError, match="injected failure"):
+            sc.rebuildBVHOnDevice()
+        monkeypatch.delenv("JTX_FAIL_REBUILD_BEFORE_COMMIT")
+        n1, r1 = sc.bvh()
+        _same_tree(n0, r0, n1, r1, "after the failed rebuild")
+        assert not sc.info()["device_built"]
+        g = gpu.StaticCamera(160, 90, data.camera, 2, 2, 5); g.render(sc, count_rays=False)
+        assert_same_f32(g.acc_, ref.acc_, "frame after the failed rebuild")
+        sc.rebuildBVHOnDevice()                                       # the edit is still pending: now it takes effect
+        fresh_data = gpu.scenes.atrium(target_tris=12000); fresh_data.meshes[0]["transform"] = m.copy()
+        fresh = gpu.Scene(fresh_data); fresh.buildBVH()
+        nf, rf = fresh.bvh(); n2, r2 = sc.bvh()
+        _same_tree(nf, rf, n2, r2, "rebuild after the failed one")
+        fresh.destroy()
+    finally:
+        sc.destroy()
 
 
 def test_device_rebuild_edge_cases(gpu):

@@ -15,17 +15,23 @@ cam = data.camera_desc(W, H, xs, ys, depth)
 dev = torch.device("cuda", 0)
 acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev); img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
 ms = C.c_float(); nl = C.c_int32()
-def frames(n):
+def frames(n, film=True):
     st = torch.cuda.current_stream().cuda_stream
     jtx.distributed.render_shard(sc, cam, 0, 1, acc, img, stream=st); torch.cuda.synchronize()
     lib.jtx_mi_kernel_time(sc.handle, C.byref(ms), C.byref(nl))
     for _ in range(n):
         jtx.distributed.render_shard(sc, cam, 0, 1, acc, img, stream=st)
     torch.cuda.synchronize(); lib.jtx_mi_kernel_time(sc.handle, C.byref(ms), C.byref(nl))
-    return ms.value / max(1, nl.value), acc.cpu().numpy().copy()
+    return ms.value / max(1, nl.value), (acc.cpu().numpy().copy() if film else None)
+if "--reserve" in sys.argv:
+    t = time.perf_counter(); sc.reserveRebuild(); print(f"jtx_mi_scene_reserve_rebuild: {(time.perf_counter() - t) * 1e3:.2f} ms", flush=True)
 t_host, film_host = frames(3)
 print(f"C3 frame on the host-built scene: {t_host:.2f} ms", flush=True)
+# as in the edit loop (display.cpp:893-905: render, edit, rebuild, render ...): every rebuild follows a frame.  (No film copy in between: torch's
+# PAGEABLE 25 MB device-to-host copy makes the next command on another stream wait ~20 ms now and then -- tools/rebuild_probe.py -- which is the
+# harness, not the builder.)
 for i in range(4):
+    frames(0, film=False)
     t = time.perf_counter(); sc.rebuildBVHOnDevice(); dt = time.perf_counter() - t
     print(f"jtx_mi_scene_rebuild {i}: {dt * 1e3:.2f} ms", flush=True)
 n1, r1 = sc.bvh()
