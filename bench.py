@@ -132,8 +132,10 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup):
             roof = roofline_block(name, sinfo, mine, "k_render_paths", kernel_ms, 1, info["num_cus"])
             for k in ("useful_frac", "frac", "traffic", "vector_memory", "lane_util", "issue_model", "pmc_stale"):
                 if k in roof:
-                    out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"]}
+                    out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"], "busy_upper_bound": roof[k]["busy_upper_bound"]}
             out["hbm_measured_frac"] = roof["hbm"].get("measured_frac")
+            out["useful_lane_ops_per_launch"] = roof["useful"]["lane_ops_per_launch"]; out["num_cus"] = roof["num_cus"]
+            out["kernel"] = roof["kernel"]
         return out
     finally:
         scene.destroy()
@@ -188,9 +190,29 @@ def source_hash():
     d = os.path.join(ROOT, "jtx-pathtracer_amd", "csrc")
     # what the timed kernel (k_render_paths + k_resolve_samples) is compiled from; the wide-node BUILDER lives in
     # jtx_capi.hip and shows in the counter file's wide_stats (node steps per ray) instead
-    for f in ("jtx_kernels.hip", "jtx_scene_dev.hpp", "jtx_bxdf.hpp", "jtx_device_math.hpp", "jtx_launch.hpp", "jtx_tiles.hpp"):
+    for f in ("jtx_kernels.hip", "jtx_scene_dev.hpp", "jtx_wide_quant.hpp", "jtx_bxdf.hpp", "jtx_device_math.hpp", "jtx_launch.hpp", "jtx_tiles.hpp"):
         h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def issue_calibration(lds_resident):
+    """measured / priced cycles of the kernels' own loop bodies replayed at saturation (tools/isa_replay.py on the GPU box ->
+    profiles/rNN_issue_replay.txt): the flat-leaf-list kernels (LDS-resident scenes) are calibrated on phase A, the 8-ary
+    traversal on the mean of its closestHit and anyHit node steps.  None: no record."""
+    import glob, re
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_issue_replay.txt")))
+    if not cands:
+        return None
+    ratio = {}
+    for line in open(cands[-1]):
+        m = re.match(r"(\w+): (\d+) VALU instructions.*measured / model = ([0-9.]+)", line)
+        if m:
+            ratio[m.group(1)] = (float(m.group(3)), int(m.group(2)))
+    want = ["c2_phase_a_closest"] if lds_resident else ["c3_node_closest", "c3_node_any"]
+    have = [ratio[k][0] for k in want if k in ratio]
+    if not have:
+        return None
+    return {"measured_over_priced": round(sum(have) / len(have), 4), "loops": want, "source": os.path.relpath(cands[-1], ROOT)}
 
 
 def cpu_baseline(data, width, height, xs, ys, depth, budget_s=9.0):
@@ -316,24 +338,31 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
         hbm["measured_bytes_per_launch"] = int(measured)
         hbm["measured_frac"] = round(measured / t / 1e9 / 8000.0, 4)
         hbm["raw_kib"] = {"FETCH_SIZE": c["FETCH_SIZE"], "WRITE_SIZE": c["WRITE_SIZE"]}
-        # Issue-cycle model (round 3): a wave64 VALU instruction does NOT issue every 2 cycles on gfx950 -- measured with every SIMD
-        # holding 8 waves of independent instructions (tools/micro/rate4.hip, profiles/r03_valu_rates.txt): v_add / v_mul / v_fma /
-        # v_mov on VGPR or inline-constant operands 2.4 cycles; everything else (min / max / max3, compares, v_cndmask, conversions,
-        # bit operations, ANY instruction with an SGPR or literal operand) 4.4; transcendentals 8.4.  With the dynamic mix of the
-        # launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32) that gives the cycles the instruction stream needs; >= 1.0 of the SIMDs'
-        # cycles means the kernel is VALU-issue saturated (the per-class costs are upper bounds: part of the add / mul / fma
-        # instructions counted as fast carry an SGPR operand, and a forwarded operand can make an instruction cheaper).
+        # Issue-cycle model: a wave64 VALU instruction does NOT issue every 2 cycles on gfx950 -- measured with every SIMD holding 8 waves
+        # of independent instructions (tools/micro/rate4.hip, profiles/r03_valu_rates.txt): v_add / v_mul / v_fma / v_mov on VGPR or
+        # inline-constant operands 2.4 cycles; everything else (min / max / max3, compares, v_cndmask, conversions, bit operations, ANY
+        # instruction with an SGPR or literal operand) 4.4; transcendentals 8.4.  Priced like that, the dynamic mix of the launch
+        # (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32) gives an UPPER BOUND of the cycles it needs (a forwarded operand makes an instruction
+        # cheaper, part of the slow class -- v_and, v_add_u32, a compare + select pair -- costs 2.9-3.8): round 3 read 1.18-1.20 "busy".
+        # Round 4 calibrates it on the real thing: the VALU stream of the kernels' own loop bodies (node step of the 8-ary traversal, phase
+        # A of the flat leaf list), replayed with its real operands, registers and order by 8 waves per SIMD with nothing else to wait for
+        # (tools/isa_replay.py -> profiles/r04_issue_replay.txt), takes 0.83-0.86 of what the classes price it at.  `busy` is the priced
+        # demand times that factor over the cycles the SIMDs have: ~1.0 = issue-saturated.
         if c.get("SQ_INSTS_VALU_FMA_F32") is not None:
             fast = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + c["SQ_INSTS_VALU_FMA_F32"]
             trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
             slow = insts - fast - trans
             need = fast * 2.4 + slow * 4.4 + trans * 8.4
+            cal = issue_calibration(bool(scene_info["lds_resident"]))
             out["issue_model"] = {"fast_class_insts": int(fast), "slow_class_insts": int(slow), "transcendental_insts": int(trans),
                                   "cycles_per_inst": {"fast": 2.4, "slow": 4.4, "transcendental": 8.4},
-                                  "cycles_needed": int(need), "simd_cycles_available": int(SIMDS * t * CLK),
-                                  "busy": round(need / (SIMDS * t * CLK), 3),
-                                  "note": "VALU cycles the launch's instruction mix needs at the issue rates measured on this chip "
-                                          "(profiles/r03_valu_rates.txt) / cycles the SIMDs have in the kernel's duration; >= 1: issue-saturated"}
+                                  "cycles_priced": int(need), "simd_cycles_available": int(SIMDS * t * CLK),
+                                  "busy_upper_bound": round(need / (SIMDS * t * CLK), 3),
+                                  "calibration": cal,
+                                  "busy": round(need * cal["measured_over_priced"] / (SIMDS * t * CLK), 3) if cal else None,
+                                  "note": "VALU cycles the launch's instruction mix is priced at by class (an upper bound) x the ratio measured / priced of "
+                                          "the kernel's own loop body replayed at saturation (profiles/r04_issue_replay.txt), over the cycles the SIMDs have "
+                                          "in the kernel's duration (nominal 2.4 GHz); ~1.0: issue-saturated"}
         if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
             # the second ceiling of the HBM-resident kernels: the vector-memory pipeline (one address unit and one data-return unit per CU)
             unit_cycles = num_cus * c["GRBM_GUI_ACTIVE"] / 8.0

@@ -1,12 +1,47 @@
 """bench.py's roofline arithmetic on recorded inputs (no GPU): the useful-work fraction is reference-algorithm lane-operations over
-the fp32 lane peak, the issue model prices the instruction mix with the measured per-class rates, stale
-counters are withheld -- recomputed here from profiles/r03_bench.json and profiles/r03_pmc.json the way a reader would."""
+the fp32 lane peak, the issue model prices the instruction mix with the measured per-class rates and is
+calibrated on the kernels' own loop bodies, stale counters are withheld -- recomputed here from profiles/r04_bench*.json,
+profiles/r04_pmc.json and profiles/r04_issue_replay.txt the way a reader would.  Round 4: the line carries the other BASELINE
+workloads too (`workloads`), and they re-derive the same way."""
 import json
 import os
+import re
 
 import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PMC = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))["workloads"]
+
+
+def _line(name):
+    return json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
+
+
+def _replay():
+    out = {}
+    for l in open(os.path.join(ROOT, "profiles", "r04_issue_replay.txt")):
+        m = re.match(r"(\w+): .*measured / model = ([0-9.]+)", l)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+    return out
+
+
+def _check(workload, kernel_ms, cus, lane_ops, useful_frac, frac, busy, busy_ub, traffic):
+    t = kernel_ms * 1e-3
+    # useful_frac: lane-ops / time / (CUs x 128 lanes x 2.4 GHz)
+    assert abs(lane_ops / t / (cus * 128 * 2.4e9) - useful_frac) < 2e-4
+    pmc = PMC[workload]["counters"]
+    # frac: SQ_INSTS_VALU / time / (CUs x 4 SIMDs x 2.4 GHz / 2)
+    assert abs(pmc["SQ_INSTS_VALU"] / t / (cus * 4 * 2.4e9 / 2) - frac) < 2e-3
+    fast = pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + pmc["SQ_INSTS_VALU_FMA_F32"]
+    trans = pmc["SQ_INSTS_VALU_TRANS_F32"]
+    priced = fast * 2.4 + (pmc["SQ_INSTS_VALU"] - fast - trans) * 4.4 + trans * 8.4
+    assert abs(priced / (cus * 4 * t * 2.4e9) - busy_ub) < 2e-3
+    rp = _replay()
+    cal = rp["c2_phase_a_closest"] if workload.startswith("cornell") else 0.5 * (rp["c3_node_closest"] + rp["c3_node_any"])
+    assert abs(priced * cal / (cus * 4 * t * 2.4e9) - busy) < 3e-3
+    assert 0.95 <= busy <= 1.05 < busy_ub                                      # calibrated, it reads ~1.0 at saturation
+    assert abs((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 - traffic) < 1e6
 
 
 def test_useful_ops_table():
@@ -17,23 +52,38 @@ def test_useful_ops_table():
 
 
 def test_recorded_bench_line_is_reproducible_from_profiles():
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().strip().splitlines()[-1])
+    line = _line("r04_bench.json")
     r = line["roofline"]
-    t = r["kernel_ms"] * 1e-3
-    cus = r["num_cus"]
-    # useful_frac: lane-ops / time / (CUs x 128 lanes x 2.4 GHz)
-    assert abs(r["useful"]["lane_ops_per_launch"] / t / (cus * 128 * 2.4e9) - r["useful_frac"]) < 2e-4
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))["workloads"][line["config"]["workload"]]["counters"]
-    # frac: SQ_INSTS_VALU / time / (CUs x 4 SIMDs x 2.4 GHz / 2)
-    assert abs(pmc["SQ_INSTS_VALU"] / t / (cus * 4 * 2.4e9 / 2) - r["frac"]) < 2e-3
-    fast = pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + pmc["SQ_INSTS_VALU_FMA_F32"]
-    trans = pmc["SQ_INSTS_VALU_TRANS_F32"]
-    need = fast * 2.4 + (pmc["SQ_INSTS_VALU"] - fast - trans) * 4.4 + trans * 8.4
-    assert abs(need / (cus * 4 * t * 2.4e9) - r["issue_model"]["busy"]) < 2e-3
-    assert r["issue_model"]["busy"] > 1.0 and 0.15 < r["useful_frac"] < 0.3
-    assert abs((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 - r["traffic"]) < 1e6
-    assert line["value"] == round(line["config"]["rays_per_frame"] * line["steps"] / (line["ms_per_step"] * line["steps"] * 1e-3) / 1e6, 2) or \
-        abs(line["value"] - line["config"]["rays_per_frame"] / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
+    _check(line["config"]["workload"], r["kernel_ms"], r["num_cus"], r["useful"]["lane_ops_per_launch"], r["useful_frac"], r["frac"],
+           r["issue_model"]["busy"], r["issue_model"]["busy_upper_bound"], r["traffic"])
+    assert 0.15 < r["useful_frac"] < 0.3 and not r["pmc_stale"]
+    assert abs(line["value"] - line["config"]["rays_per_frame"] / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
+    # the kernel's average duration in the rocprofv3 --kernel-trace --stats summary of the same command agrees with the HIP events
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv"))))
+    row = next(x for x in rows if "k_render_paths" in x["Name"])
+    assert abs(float(row["AverageNs"]) / 1e6 - r["kernel_ms"]) / r["kernel_ms"] < 0.01
+
+
+def test_the_other_workloads_ride_in_the_same_line_and_re_derive():
+    """C3, C5 and C1 in the driver-written record"""
+    line = _line("r04_bench.json")
+    w = line["workloads"]
+    assert set(w) == {"atrium_1920x1080_64spp_d8", "mixed_1920x1080_128spp_d8", "cornell_512x512_16spp_d4"}
+    for name in ("atrium_1920x1080_64spp_d8", "mixed_1920x1080_128spp_d8"):
+        e = w[name]
+        _check(name, e["kernel_ms"], e["num_cus"], e["useful_lane_ops_per_launch"], e["useful_frac"], e["frac"], e["issue_model"]["busy"],
+               e["issue_model"]["busy_upper_bound"], e["traffic"])
+        assert abs(e["value"] - e["rays_per_frame"] / (e["ms_per_step"] * 1e-3) / 1e6) / e["value"] < 1e-3
+        assert e["vector_memory"]["ta_busy"] > 0.75                         # the second ceiling of the HBM-resident kernels (DESIGN.md section 6)
+        assert e["kernel_ms"] <= e["ms_per_step"]
+    c1 = w["cornell_512x512_16spp_d4"]
+    assert c1["frac"] is None and 0.1 < c1["useful_frac"] < 0.25             # no counters were collected for C1: only the counter-free fraction
+    # ... and agree with the same workloads benched on their own
+    for name, f in (("atrium_1920x1080_64spp_d8", "r04_bench_c3_atrium.json"), ("mixed_1920x1080_128spp_d8", "r04_bench_c5_mixed.json")):
+        alone = _line(f)
+        assert abs(alone["roofline"]["kernel_ms"] - w[name]["kernel_ms"]) / w[name]["kernel_ms"] < 0.02
+        assert alone["config"]["rays_per_frame"] == w[name]["rays_per_frame"]
 
 
 def test_stale_counters_are_withheld(monkeypatch):
@@ -42,3 +92,16 @@ def test_stale_counters_are_withheld(monkeypatch):
     r = bench.roofline_block("cornell_1920x1080_64spp_d8", {"lds_resident": True, "lds_bytes": 1000, "workgroups": 1792}, c, "k_render_paths", 27.4, 1, 256)
     assert r["pmc_stale"] is True and r["frac"] is None and r["traffic"] is None and "issue_model" not in r and "lane_util" not in r
     assert r["useful_frac"] is not None                                        # needs no profile
+
+
+def test_a_scene_file_becomes_a_workload(tmp_path):
+    """--scene <file>: the asset goes through createScene's rules (scenes.create_scene) and names the workload (VERDICT r3 missing 4)"""
+    import jtx_pathtracer_amd as jtx
+    p = os.path.join(tmp_path, "room.obj")
+    jtx.scenes.write_obj(jtx.scenes.cornell(), p)
+    name, data, dims = bench.load_workload(jtx, "atrium_1920x1080_64spp_d8", scene_file=p, camera="inside")
+    assert name == "file:room_1920x1080_64spp_d8" and dims == (1920, 1080, 8, 8, 8) and data.num_triangles == 32
+    c = data.camera
+    assert c["yfov"] == 60.0 and 0 < c["center"][1] < 548.9                     # inside the bounds, looking down the longest axis
+    name2, data2, _ = bench.load_workload(jtx, "cornell_1920x1080_64spp_d8")
+    assert name2 == "cornell_1920x1080_64spp_d8" and data2.num_triangles == 32
