@@ -96,9 +96,13 @@ JD void classify(BNode &n, Counters *cnt) {
     if (n.count > SMALL) n.aux = atomicAdd(&cnt->large, 1);
 }
 
+// cnt[1] (never a level's counters): .nodes = capacity of the node array, .large = why the build must be declined (1: a split left one side
+// empty -- every SAH cost inf / NaN, where the reference's buildTree recurses for ever, bvh.cpp:96-111, 126-127; 2: node array full)
 JD void makeChildren(BNode *nodes, int id, int best, int leftCount, const Box &lb, const Box &lc, const Box &rb, const Box &rc, Counters *cnt) {
     BNode &n = nodes[id];
+    if (leftCount <= 0 || leftCount >= n.count) { atomicMax(&cnt[1].large, 1); n.child = -1; return; }
     const int c = atomicAdd(&cnt->nodes, 2);
+    if (c + 2 > cnt[1].nodes) { atomicMax(&cnt[1].large, 2); atomicSub(&cnt->nodes, 2); n.child = -1; return; }
     n.child = c; n.best = best; n.leftCount = leftCount;
     for (int s = 0; s < 2; ++s) {
         BNode &ch = nodes[c + s];
@@ -138,9 +142,9 @@ __global__ void __launch_bounds__(256) k_prim_boxes(const float4 *prim_src, cons
     __syncthreads();
     if (threadIdx.x < 12) { if ((threadIdx.x % 6) < 3) atomicMin(&rootKeys[threadIdx.x], red[threadIdx.x]); else atomicMax(&rootKeys[threadIdx.x], red[threadIdx.x]); }
 }
-__global__ void k_root_keys_init(int *rootKeys, Counters *cnt) {
+__global__ void k_root_keys_init(int *rootKeys, Counters *cnt, int maxNodes) {
     if (threadIdx.x < 12) rootKeys[threadIdx.x] = (threadIdx.x % 6) < 3 ? fkey(FLT_MAX) : fkey(-FLT_MAX);
-    if (threadIdx.x == 0) { cnt[0].nodes = 1; cnt[0].large = 0; cnt[1].nodes = 0; cnt[1].large = 0; }
+    if (threadIdx.x == 0) { cnt[0].nodes = 1; cnt[0].large = 0; cnt[1].nodes = maxNodes; cnt[1].large = 0; }
 }
 __global__ void k_root_init(BNode *nodes, const int *rootKeys, int np, Counters *cnt, const int *orig, int *order, int *prim_node) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -642,7 +646,7 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildArena &arenaMem, D
     if (arena.used > arena.cap) return hipErrorOutOfMemory;
 
     BCHK(hipMemsetAsync(small, 0, 512 * sizeof(int), st));
-    LAUNCH(k_root_keys_init, dim3(1), dim3(64), rootKeys, cnt);
+    LAUNCH(k_root_keys_init, dim3(1), dim3(64), rootKeys, cnt, (int) maxNodes);
     LAUNCH(k_prim_boxes, dim3(blocks(np, 256)), dim3(256), B.prim_src, B.mesh_xf, np, blo, bhi, rootKeys);
     LAUNCH(k_root_init, dim3(blocks(np, 256)), dim3(256), nodes, rootKeys, np, cnt, B.orig, order[0], pnode[0]);
     LAUNCH(k_advance_level, dim3(1), dim3(1), cnt, lv);                                   // level 0 = the root
@@ -666,9 +670,13 @@ hipError_t jtx_device_build(const DevBuildBuffers &B, DevBuildArena &arenaMem, D
             cur ^= 1;
             LAUNCH(k_advance_level, dim3(1), dim3(1), cnt, lv);
         }
+        Counters guard{};
         BCHK(hipMemcpyAsync(&h, lv, sizeof h, hipMemcpyDeviceToHost, st));
+        BCHK(hipMemcpyAsync(&guard, cnt + 1, sizeof guard, hipMemcpyDeviceToHost, st));
         BCHK(hipStreamSynchronize(st));
-        if ((size_t) h.le > maxNodes) return hipErrorUnknown;
+        if (guard.large == 1) { R.declined = "buildTree does not terminate on this geometry: the SAH costs of a node are all inf / NaN (box areas overflow fp32), "
+                                             "the partition leaves one side empty (bvh.cpp:96-111, 126-127)"; return hipSuccess; }
+        if (guard.large == 2 || (size_t) h.le > maxNodes) { R.declined = "more nodes than a binary tree over these primitives can have"; return hipSuccess; }
         if (h.le == h.ls) break;                                                           // the last round opened nothing: the tree stands
         if (rounds > 120) { R.declined = "the tree is deeper than 120 levels (the reference's traversal stack holds 64, scene.cpp:13)"; return hipSuccess; }
     }

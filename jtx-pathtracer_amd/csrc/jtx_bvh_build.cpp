@@ -127,6 +127,12 @@ struct Builder {
             if ((int) n > maxPrims || bestCost < leafCost) {                            // bvh.cpp:105-112
                 Prim *m = std::partition(p, p + n, [&](const Prim &q) { return bucketOf(cb, q, dim) <= best; });
                 mid = (size_t) (m - p);
+                // Where every split cost is inf or NaN (boxes whose surface area overflows fp32) no cost is < INF, minBucket stays -1
+                // (bvh.cpp:96-101), the partition puts everything on one side and the reference's buildTree recurses on the same span for
+                // ever (bvh.cpp:126-127).  There is no tree to reproduce: say so instead of running out of memory.
+                if (mid == 0 || mid == n)
+                    throw std::runtime_error("buildTree does not terminate on this geometry: the SAH costs of a node are all inf / NaN (box areas "
+                                             "overflow fp32), std::partition leaves one side empty (bvh.cpp:96-111, 126-127)");
             } else {
                 return emitLeaf(t, slot, p, n);
             }

@@ -1316,6 +1316,27 @@ def test_device_rebuild_is_failure_atomic(gpu, monkeypatch):
         sc.destroy()
 
 
+def test_device_rebuild_declines_what_the_reference_cannot_build(gpu):
+    """the device builder says WHY it does not build (it used to return hipErrorUnknown) -- here an edit that scales a mesh
+    until its boxes' surface areas overflow fp32: every SAH cost is inf, the reference's buildTree would recurse for ever (bvh.cpp:96-111,
+    126-127) -- and the scene stays as it was."""
+    data = gpu.scenes.atrium(target_tris=4000)
+    sc = gpu.Scene(data); sc.buildBVH()
+    try:
+        n0, r0 = sc.bvh()
+        sc.setTransform(0, np.diag([1e25, 1e25, 1e25, 1.0]).astype(np.float32))
+        with pytest.raises(gpu._capi.JtxMiError, match="declined.*does not terminate"):
+            sc.rebuildBVHOnDevice()
+        n1, r1 = sc.bvh()
+        _same_tree(n0, r0, n1, r1, "after the declined rebuild")
+        sc.setTransform(0, np.eye(4, dtype=np.float32))
+        sc.rebuildBVHOnDevice()
+        n2, r2 = sc.bvh()
+        _same_tree(n0, r0, n2, r2, "rebuild after the edit was taken back")
+    finally:
+        sc.destroy()
+
+
 def test_device_rebuild_edge_cases(gpu):
     """the corners of buildTree (bvh.cpp:18-57) through jtx_mi_scene_rebuild: one primitive (a leaf root), a quad whose halves
     share their centroid (degenerate centroid bounds: one leaf of two), two separate triangles in either input order

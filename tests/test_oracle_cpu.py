@@ -480,3 +480,20 @@ def test_oracle_alternate_integrators_basic_properties():
     assert b2.sum() < 0.7 * a2.sum()                                   # what is left is the sky seen directly and by bounces
     # the camera ray counts as a specular bounce: pixels that look straight at the emissive quad are lit under integrate
     assert a1.max() > 0 and np.isfinite(a1).all() and np.isfinite(a2).all()
+
+
+def test_host_bvh_build_says_when_the_reference_would_not_terminate():
+    """boxes whose surface area overflows fp32 make every SAH cost inf / NaN: no cost is < INF, minBucket stays -1 (bvh.cpp:96-101),
+    std::partition leaves one side empty and the reference's buildTree recurses on the same span for ever (bvh.cpp:126-127).  The host
+    builder used to follow it until std::bad_alloc; it names the situation now."""
+    from jtx_pathtracer_amd import api, scenes as sc_
+    s = sc_.SceneData("overflow")
+    s.materials = [sc_.material(sc_.DIFFUSE, (0.7, 0.6, 0.5))]
+    v = []
+    for k in range(140):
+        e = np.float32(1.5) ** k * np.float32(0.01)
+        v += [(0, 0, -k * 1e-3), (e, 0, -k * 1e-3), (0, e, -k * 1e-3)]
+    v = np.array(v, np.float32)
+    s.add_mesh(np.arange(len(v), dtype=np.int32).reshape(-1, 3), v, np.tile(np.array([[0, 0, 1]], np.float32), (len(v), 1)), 0)
+    with pytest.raises(Exception, match="does not terminate"):
+        api.bvh_build_host(s)
