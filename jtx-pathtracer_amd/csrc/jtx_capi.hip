@@ -1408,6 +1408,13 @@ int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
     return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 #endif
+#ifdef JTX_PROFILE_FUSE
+int jtx_mi_debug_fuse(jtx_mi_scene *s, unsigned long long *out3) {   // diagnostic builds only: sum of max(c) + max(a), sum of max(a_prev + c), bounces
+    if (!s || !s->counters.p) return 1;
+    (void) hipDeviceSynchronize();
+    return hipMemcpy(out3, s->counters.p + 56, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef JTX_PROFILE_TIMELINE
 int jtx_mi_debug_timeline(jtx_mi_scene *s, unsigned long long *out, int n) {   // diagnostic builds only: (start, end) wall clocks per wave
     if (!s || !s->counters.p) return 1;

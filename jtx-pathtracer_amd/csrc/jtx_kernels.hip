@@ -75,6 +75,9 @@ struct PathState {
     f3 o, d, beta, radiance;
     Rng rng;
     int depth;
+#ifdef JTX_PROFILE_FUSE
+    unsigned fuse_c, fuse_a, fuse_aprev;   // diagnostic: steps of this bounce's extension / shadow ray, of the previous bounce's shadow ray
+#endif
 #if JTX_SLIP_K > 0
     bool slip;                   // its extension ray is under way across bounces, state parked in memory (k_render_paths over the 8-ary nodes)
 #endif
@@ -128,7 +131,13 @@ JD BounceResult pathBounce(const DevScene &sc, const Src &src, int maxDepth, Pat
     } else hit = traverseNoStack<false, COUNT>(src, sc.num_nodes, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
 #else
     (void) slipBase;
+#ifdef JTX_PROFILE_FUSE
+    const unsigned fuse0 = cnt.w_node_steps + cnt.w_leaf_steps;
+#endif
     const bool hit = traverseNoStack<false, COUNT>(src, sc.num_nodes, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
+#ifdef JTX_PROFILE_FUSE
+    ps.fuse_c = cnt.w_node_steps + cnt.w_leaf_steps - fuse0;
+#endif
 #endif
     PH(0)
     if (!hit) {                                                       // integrator.cpp:183-187
@@ -150,7 +159,13 @@ JD BounceResult pathBounce(const DevScene &sc, const Src &src, int maxDepth, Pat
             const float lDist = len(sf.point - ls.p);
             HitRec dummy;
             PH(1)
+#ifdef JTX_PROFILE_FUSE
+            const unsigned fuse1 = cnt.w_node_steps + cnt.w_leaf_steps;
+#endif
             const bool occluded = traverseNoStack<true, COUNT>(src, sc.num_nodes, sOrigin, ls.wi, 0.0f, lDist - RAY_EPSILON, dummy, cnt);
+#ifdef JTX_PROFILE_FUSE
+            ps.fuse_a = cnt.w_node_steps + cnt.w_leaf_steps - fuse1;
+#endif
             PH(2)
             if (!occluded) {
                 f3 f; float pb;
@@ -352,6 +367,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     for (int i = 0; i < 6; ++i) ps.ph[i] = 0;
     const long long k0 = clock64();
 #endif
+#ifdef JTX_PROFILE_FUSE
+    unsigned long long fuseSep = 0, fuseSum = 0, fuseCalls = 0; ps.fuse_c = ps.fuse_a = ps.fuse_aprev = 0;
+#endif
     // the wave's current chunk (all wave-uniform)
     int next = 0, nunits = 0;                      // paths handed out / in the chunk
     int row0 = 0, col0 = 0, slot0 = 0, sBegin = 0;
@@ -415,6 +433,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
 #ifdef JTX_PROFILE_TIMELINE
         tl_iters++; tl_active += alive ? 1 : 0;
 #endif
+#ifdef JTX_PROFILE_FUSE
+        ps.fuse_c = 0; ps.fuse_a = 0;
+#endif
         // ---- one bounce of every live path ----
         if (alive) {
             bool done;
@@ -449,9 +470,20 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                 alive = false; need = true;
             }
         }
+#ifdef JTX_PROFILE_FUSE
+        {   // wave maxima (all lanes take part): separate calls cost max(c) + max(a); one fused call per bounce would cost max(a_prev + c)
+            unsigned mc = ps.fuse_c, ma = ps.fuse_a, mf = ps.fuse_c + ps.fuse_aprev;
+            for (int off = 32; off > 0; off >>= 1) { mc = max(mc, __shfl_xor(mc, off, 64)); ma = max(ma, __shfl_xor(ma, off, 64)); mf = max(mf, __shfl_xor(mf, off, 64)); }
+            fuseSep += mc + ma; fuseSum += mf; fuseCalls += 1;
+            ps.fuse_aprev = alive ? ps.fuse_a : 0u;          // (a finished path's last shadow ray is charged to nobody: a slight favour to the fused figure)
+        }
+#endif
     }
 #ifdef JTX_PROFILE_WIDE
     if (SRC == SRC_WIDE) exportWideStats(p, cnt);
+#endif
+#ifdef JTX_PROFILE_FUSE
+    if (p.counters && lane == 0) { atomicAdd(&p.counters[56], fuseSep); atomicAdd(&p.counters[57], fuseSum); atomicAdd(&p.counters[58], fuseCalls); }
 #endif
 #ifdef JTX_PROFILE_PHASES
     if (p.counters && lane == 0) {         // diagnostic build: per-phase wave clocks as lane 0 sees them (tools/tools_phases.py --timed)
