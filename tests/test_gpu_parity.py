@@ -7,6 +7,8 @@ DESIGN.md), so radiance, accumulation buffer, RGB8 image and ray counters must b
 import numpy as np
 import pytest
 
+import os
+
 import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
@@ -1536,3 +1538,22 @@ def test_cpp_host_loads_an_asset_and_renders_it(gpu, tmp_path):
     assert kv["crc"] == "%08x" % zlib.crc32(np.ascontiguousarray(cam.img_).tobytes())
     assert np.array_equal(gltf.decode_png(open(png, "rb").read()), np.asarray(cam.img_).reshape(72, 96, 3)[::-1])
     assert len(np.unique(np.asarray(cam.img_).reshape(-1, 3), axis=0)) > 8          # (every glTF material is metal-rough white: mostly mirrored sky)
+
+
+def test_bench_times_a_scene_file_and_the_extra_workload_path(gpu, tmp_path):
+    """bench.py --scene (VERDICT r3 missing 4) and the per-workload timing the default run adds to its line (next 2), on the device: an OBJ
+    of the Cornell geometry goes through createScene's rules, renders at the headline's frame size and reports rays, kernel time and the
+    counter-free roofline fraction (an OBJ brings no lights: extension rays only, 0.43 G per frame)."""
+    import torch
+    import bench
+    p = os.path.join(tmp_path, "room.obj")
+    gpu.scenes.write_obj(gpu.scenes.cornell(), p)
+    name, data, dims = bench.load_workload(gpu, "cornell_1920x1080_64spp_d8", scene_file=p, camera="278,273,-800,278,273,0,39.3077")
+    assert name == "file:room_1920x1080_64spp_d8" and dims == (1920, 1080, 8, 8, 8)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        e = bench.time_workload(gpu, torch, dev, st, name, data, dims, steps=2, warmup=1)
+    assert e["rays_per_frame"] > 3e8 and e["scene_triangles"] == 32 and e["kernel_ms"] > 1.0 and e["kernel_ms"] <= e["ms_per_step"]
+    assert abs(e["value"] - e["rays_per_frame"] / (e["ms_per_step"] * 1e-3) / 1e6) / e["value"] < 1e-3
+    assert 0.05 < e["useful_frac"] < 0.4 and e["frac"] is None             # a file scene has no recorded counters: only the counter-free fraction
