@@ -1557,3 +1557,20 @@ def test_bench_times_a_scene_file_and_the_extra_workload_path(gpu, tmp_path):
     assert e["rays_per_frame"] > 3e8 and e["scene_triangles"] == 32 and e["kernel_ms"] > 1.0 and e["kernel_ms"] <= e["ms_per_step"]
     assert abs(e["value"] - e["rays_per_frame"] / (e["ms_per_step"] * 1e-3) / 1e6) / e["value"] < 1e-3
     assert 0.05 < e["useful_frac"] < 0.4 and e["frac"] is None             # a file scene has no recorded counters: only the counter-free fraction
+
+
+def test_rccl_takes_the_exchange_of_the_sharded_frame(gpu):
+    """The N > 1 path's collectives on REAL RCCL (the gloo rehearsals cannot touch it): a one-GPU box offers one rank, so
+    the group has one member and the gather / reduce degenerate to self-copies -- through RCCL's communicator set-up and torch's c10d
+    checks for exactly the slab shapes, dtypes and views `distributed.FrameGather` / `reduce_frame` / bench.py use.  In a child
+    process (tools/rccl_selfcheck.py) with a time limit, so that a communicator that cannot come up costs a failure, not the session."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selfcheck.py"), "--width", "640", "--height", "360"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["rccl_selfcheck"] == "ok" and line["gather"] and line["reduce"] and line["slab_bytes"] == 640 * 360 * 15
