@@ -255,6 +255,16 @@ class MultiScene:
             pass
 
 
+def _film_array(shape, dtype):
+    """A zeroed array in an anonymous mapping of its own.  The cameras page-lock img_ / acc_ (jtx_mi_pin_host = hipHostRegister) so
+    that the frame is DMA-written into them; page-locking works on whole pages, and an array from numpy's allocator shares its first
+    and last page with whatever else malloc put there and hands them back to a heap that is trimmed and re-grown under the
+    registration's feet.  A private mapping is page-aligned, shares nothing and stays mapped until the array is gone."""
+    import mmap
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    return np.frombuffer(mmap.mmap(-1, max(n, 1)), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class StaticCamera:
     """StaticCamera (src/camera.hpp:179-188) -- one blocking render per call."""
 
@@ -265,8 +275,8 @@ class StaticCamera:
         self.maxDepth_ = int(maxDepth)
         self.samplesPerPass_ = 1
         self.currentSample_ = 0
-        self.img_ = np.zeros((self.height_, self.width_, 3), np.uint8)      # RGB8Image, row 0 = bottom
-        self.acc_ = np.zeros((self.height_, self.width_, 3), np.float32)    # AccumulationBuffer
+        self.img_ = _film_array((self.height_, self.width_, 3), np.uint8)      # RGB8Image, row 0 = bottom
+        self.acc_ = _film_array((self.height_, self.width_, 3), np.float32)    # AccumulationBuffer
         self.stopRender_ = False
         self.counters = None
         self._lib = capi.load()
@@ -284,8 +294,8 @@ class StaticCamera:
     def resize(self, w, h):
         self._unpin()
         self.width_, self.height_ = int(w), int(h)
-        self.img_ = np.zeros((h, w, 3), np.uint8)
-        self.acc_ = np.zeros((h, w, 3), np.float32)
+        self.img_ = _film_array((h, w, 3), np.uint8)
+        self.acc_ = _film_array((h, w, 3), np.float32)
 
     # img_ / acc_ live as long as the camera (image.hpp:60-61,90-91): page-lock them once so that jtx_mi_render DMA-writes
     # them directly (jtx_mi_pin_host); a refusal only costs the library's staging copy

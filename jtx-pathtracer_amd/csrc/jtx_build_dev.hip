@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(64) k_wide_fill(const WItem *in, WItem *out, c
     const int need = (int) jtxq::blockGranules(ni, nl);
     const long long base = (long long) atomicAdd(&o.counters[0], need);
     if (base + need > o.cap || base + need >= (long long) jtxq::kMaxGranules) { atomicExch(&o.counters[2], 1); return; }
-    uint32_t ndw[16], tw[8];
+    uint32_t ndw[16], tw[4 * jtxq::kTails];
     jtxq::encodeGridAndPlanes(ndw, grid, ni, ni + nl, qlo, qhi);
     if (!jtxq::encodeTail(tw, (uint32_t) base, perm, ni + nl)) { atomicExch(&o.counters[2], 1); return; }
     uint4 *nd = o.wide + at;
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(64) k_wide_fill(const WItem *in, WItem *out, c
     if (b == 0) {                                             // the root-peel record: group word, orders, the children's exact boxes
         uint32_t rec[4 * 14];
         for (int i = 0; i < 4 * 14; ++i) rec[i] = 0u;
-        jtxq::encodePeelHeader(rec, (uint32_t) base, ni, ni + nl, tw);
+        jtxq::encodePeelHeader(rec, (uint32_t) base, ni, ni + nl, perm);
         for (int s = 0; s < ni + nl; ++s) { float cmin[3], cmax[3]; cornersOf(nbox, child[s], cmin, cmax); jtxq::encodePeelBox(rec, s, cmin, cmax); }
         for (int g = 0; g < 14; ++g) o.wide[jtxq::kPeelRec + g] = make_uint4(rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
         for (int g = 14; g < (int) jtxq::kRootNode; ++g) o.wide[g] = make_uint4(0u, 0u, 0u, 0u);

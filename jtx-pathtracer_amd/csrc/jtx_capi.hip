@@ -35,12 +35,72 @@ int fail(const std::string &msg) { g_err = msg; return 1; }
         if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Host memory the library does not own (std::vector storage, caller arrays) never reaches a HIP copy directly: bulk transfers go
+// through a page-locked buffer of the library's own, so the GPU only ever touches host pages that this library allocated page-locked
+// and that stay put until it frees them.  (Round 4: an intermittent "Memory access fault by GPU ... on address <a malloc-heap
+// address>" during jtx_mi_scene_create -- twice in ~35 runs of the GPU suite -- while the only GPU work in flight were this file's
+// uploads from vectors; the suite also page-locks camera buffers that live in the malloc heap.  Whatever the runtime does with pageable
+// pointers -- pin them, cache the pin, look them up again after the heap has been trimmed and re-grown -- it now does not get any
+// from here.  The Python mirror's camera buffers moved out of the malloc heap for the same reason: api.py.)
+struct HostStage {
+    std::mutex mu; void *p = nullptr; size_t cap = 0;
+    void *get(size_t bytes) {                       // caller holds mu
+        if (bytes > cap) {
+            if (p) (void) hipHostFree(p);
+            p = nullptr; cap = 0;
+            HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocPortable));
+            cap = bytes;
+        }
+        return p;
+    }
+};
+HostStage &hostStage() { static HostStage *st = new HostStage(); return *st; }       // never freed: it must outlive every scene, and static destructors run after the runtime's
+constexpr size_t kStageChunk = (size_t) 8 << 20, kStageMin = 4096;                   // (copies of a few words stay direct: the runtime embeds / stages them itself)
+
+// host -> device, complete on return.  The destination must not be in use by work in flight.
+void stagedH2D(void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    if (bytes < kStageMin) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return; }
+    HostStage &st = hostStage();
+    std::lock_guard<std::mutex> lk(st.mu);
+    char *stage = (char *) st.get(bytes < kStageChunk ? bytes : kStageChunk);
+    for (size_t off = 0; off < bytes; off += kStageChunk) {
+        const size_t n = bytes - off < kStageChunk ? bytes - off : kStageChunk;
+        std::memcpy(stage, (const char *) src + off, n);
+        HIPCHK(hipMemcpy((char *) dst + off, stage, n, hipMemcpyHostToDevice));
+    }
+}
+// device -> host, complete on return.  The caller has synchronised with whatever wrote the source.
+void stagedD2H(void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    if (bytes < kStageMin) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return; }
+    HostStage &st = hostStage();
+    std::lock_guard<std::mutex> lk(st.mu);
+    char *stage = (char *) st.get(bytes < kStageChunk ? bytes : kStageChunk);
+    for (size_t off = 0; off < bytes; off += kStageChunk) {
+        const size_t n = bytes - off < kStageChunk ? bytes - off : kStageChunk;
+        HIPCHK(hipMemcpy(stage, (const char *) src + off, n, hipMemcpyDeviceToHost));
+        std::memcpy((char *) dst + off, stage, n);
+    }
+}
+
+// a page-locked host buffer owned by a scene (grow-only): the target of its asynchronous read-backs
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    void *ensure(size_t bytes) {
+        if (bytes > cap) { if (p) (void) hipHostFree(p); p = nullptr; cap = 0; HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocPortable)); cap = bytes; }
+        return p;
+    }
+    ~PinBuf() { if (p) (void) hipHostFree(p); }
+    PinBuf() = default; PinBuf(const PinBuf &) = delete; PinBuf &operator=(const PinBuf &) = delete;
+};
+
 template <class T> struct DevBuf {
     T *p = nullptr; size_t n = 0, cap = 0;       // n: elements in use; cap: elements allocated
     void alloc(size_t count) { release(); if (count) HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); n = cap = count; }
     void ensure(size_t count) { if (count <= cap) n = count; else alloc(count); }     // grow-only: an edit loop re-uses its buffers
-    void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
-    void fill(const std::vector<T> &v) { ensure(v.size()); if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    void upload(const std::vector<T> &v) { alloc(v.size()); stagedH2D(p, v.data(), v.size() * sizeof(T)); }
+    void fill(const std::vector<T> &v) { ensure(v.size()); stagedH2D(p, v.data(), v.size() * sizeof(T)); }
     void release() { if (p) (void) hipFree(p); p = nullptr; n = cap = 0; }
     void swap(DevBuf &o) noexcept { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
     ~DevBuf() { release(); }
@@ -74,6 +134,12 @@ bool hostPinned(const void *p) {
 }
 
 int jtx_capi_fail(const std::string &msg) { return fail(msg); }     // for the other translation units of the library
+// device -> caller memory, complete on return: direct when the caller's buffer is page-locked, through the library's staging otherwise (throws)
+void jtx_capi_d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (hostPinned(dst)) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); return; }
+    HIPCHK(hipStreamSynchronize(st));
+    stagedD2H(dst, src, bytes);
+}
 
 namespace {
 // after the stream has drained: did the last persistent launch stop on the cancellation flag (k_render_paths pushes its
@@ -96,6 +162,7 @@ struct jtx_mi_scene {
     DevBuf<float> mesh_xf;
     DevBuf<int> leaf_nodes, level_nodes, rec_node, wide_map, wide_fail;
     std::vector<float> mesh_xf_host;
+    PinBuf pin_nb;                    // page-locked landing buffer of the refit's read-back (node boxes)
     float *mesh_xf_pinned = nullptr;  // page-locked copy the uploads read: the first PAGEABLE host-to-device copy after a render took 8-20 ms (round 4 trace)
     std::vector<int> level_begin;    // per interior depth: offsets into level_nodes
     DevBuf<int> orig_id;             // per BVH-ordered primitive: its index in the scene's own Scene::triangles (input order of a device rebuild)
@@ -109,6 +176,7 @@ struct jtx_mi_scene {
         DevBuf<float4> src, tris, shade, nbox, tnodes, lw_box; DevBuf<int> orig, leaves, levels, rec_node, map; DevBuf<uint4> wide;
         DevBuf<unsigned> lw_tab; DevBuf<DLight> lights;
         DevBuf<int> order, pos, size; DevBuf<jtx_mi_bvh_node> hn;       // scratch
+        PinBuf pin_nodes, pin_ord;       // page-locked landing buffers of the rebuild's read-backs (nodes, primitive order)
         DevBuildArena arena;
         ~RebuildSpare() { if (arena.base) (void) hipFree(arena.base); }
     } spare;
@@ -336,14 +404,14 @@ struct WideBuilder {
         const size_t base = out.size();
         if (base + jtxq::blockGranules(ni, nl) >= jtxq::kMaxGranules) { ok = false; return; }
         out.resize(base + jtxq::blockGranules(ni, nl), make_uint4(0u, 0u, 0u, 0u));
-        uint32_t nd[16], tw[8];
+        uint32_t nd[16], tw[4 * jtxq::kTails];
         jtxq::encodeGridAndPlanes(nd, grid, ni, ni + nl, qlo, qhi);
         if (!jtxq::encodeTail(tw, (uint32_t) base, perm, ni + nl)) { ok = false; return; }
         for (int g = 0; g < 4; ++g) out[at + g] = make_uint4(nd[4 * g], nd[4 * g + 1], nd[4 * g + 2], nd[4 * g + 3]);
         for (uint32_t t = 0; t < jtxq::kTails; ++t) out[at + 4 + t] = make_uint4(tw[4 * t], tw[4 * t + 1], tw[4 * t + 2], tw[4 * t + 3]);
         if (b == 0) {                                                   // the root-peel record: group word, orders, the children's exact boxes
             uint32_t rec[4 * 14] = {};
-            jtxq::encodePeelHeader(rec, (uint32_t) base, ni, ni + nl, tw);
+            jtxq::encodePeelHeader(rec, (uint32_t) base, ni, ni + nl, perm);
             for (int s = 0; s < ni + nl; ++s) jtxq::encodePeelBox(rec, s, nodes[child[s]].pmin, nodes[child[s]].pmax);
             for (int g = 0; g < 14; ++g) out[jtxq::kPeelRec + g] = make_uint4(rec[4 * g], rec[4 * g + 1], rec[4 * g + 2], rec[4 * g + 3]);
         }
@@ -1104,11 +1172,13 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
         HIPCHK(jtx_launch_refit(a, s->level_begin.data(), (int) s->level_begin.size() - 1, s->stream));
         lap("kernels");
         // the host's copy of the nodes, the scene radius (scene.hpp:81-84) and with it the DISTANT lights (scene.cpp:128-134)
-        std::vector<float4> nb(2 * (size_t) s->dev.num_nodes);
-        HIPCHK(hipMemcpyAsync(nb.data(), s->nbox.p, nb.size() * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
-        int wfail = 0;
-        HIPCHK(hipMemcpyAsync(&wfail, s->wide_fail.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        const size_t nbCount = 2 * (size_t) s->dev.num_nodes;
+        float4 *nb = (float4 *) s->pin_nb.ensure((nbCount + 1) * sizeof(float4));       // page-locked, the scene's own: the last granule takes the wide-refit flag
+        int *wfailp = (int *) (nb + nbCount);
+        HIPCHK(hipMemcpyAsync(nb, s->nbox.p, nbCount * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(wfailp, s->wide_fail.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        const int wfail = *wfailp;
         lap("node boxes to the host");
         for (size_t i = 0; i < s->bvh.nodes.size(); ++i) {
             jtx_mi_bvh_node &n = s->bvh.nodes[i];
@@ -1121,10 +1191,10 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
             s->bvh.scene_radius = std::sqrt(dx * dx + dy * dy + dz * dz) / 2;
             if (s->lights.n) {
                 std::vector<DLight> ls(s->lights.n);
-                HIPCHK(hipMemcpy(ls.data(), s->lights.p, ls.size() * sizeof(DLight), hipMemcpyDeviceToHost));
+                stagedD2H(ls.data(), s->lights.p, ls.size() * sizeof(DLight));
                 bool any = false;
                 for (auto &l : ls) if (l.type == 1) { l.scene_radius = s->bvh.scene_radius; any = true; }
-                if (any) HIPCHK(hipMemcpy(s->lights.p, ls.data(), ls.size() * sizeof(DLight), hipMemcpyHostToDevice));
+                if (any) stagedH2D(s->lights.p, ls.data(), ls.size() * sizeof(DLight));
             }
         }
         if (s->dev.lw_leaves) {                                                 // tiny scenes: the flat leaf list follows the refitted nodes
@@ -1135,7 +1205,7 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
                 lb[2 * (size_t) l + 1] = make_float4(n.pmin[2], n.pmax[2], fz, fw);
                 ++l;
             }
-            HIPCHK(hipMemcpy(s->lw_box.p, lb.data(), lb.size() * sizeof(float4), hipMemcpyHostToDevice));
+            stagedH2D(s->lw_box.p, lb.data(), lb.size() * sizeof(float4));
         }
         if (wfail) { s->dev.wide = nullptr; s->dev.wide_depth = 0; }          // a node lost its grid (coordinates out of range): binary records only
         s->refitted = 1; s->xf_dirty = false;
@@ -1160,7 +1230,7 @@ void reserveRebuild(jtx_mi_scene &sc, bool &wantWide, bool &wideOnDevice, size_t
     // the 8-ary nodes come from the host's buildWide, as at scene creation
     static const int sahCut = [] { const char *e = getenv("JTX_WIDE_SAH_CUT"); return e ? atoi(e) : 1; }();
     wideOnDevice = wantWide && sahCut;
-    wideCap = jtxq::kNodeG * (size_t) np + 2 * (size_t) np + 32;     // every interior node its own wide node at worst
+    wideCap = jtxq::kNodeG * (size_t) np + 2 * (size_t) np + jtxq::kFirstBlock;     // every interior node its own wide node at worst
     if (wideOnDevice) { sp.wide.ensure(wideCap); sp.map.ensure(16 * (size_t) np); }
 }
 }
@@ -1227,9 +1297,10 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit) 
         const int nn = R.nn;
         // ---- host copies (locals): nodes, Scene::triangles_ in leaf order ----
         std::vector<jtx_mi_bvh_node> nodes2((size_t) nn);
-        std::vector<int> ord(np);
-        HIPCHK(hipMemcpyAsync(nodes2.data(), sp.hn.p, (size_t) nn * sizeof(jtx_mi_bvh_node), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(ord.data(), sp.order.p, (size_t) np * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        jtx_mi_bvh_node *pinNodes = (jtx_mi_bvh_node *) sp.pin_nodes.ensure(2 * (size_t) np * sizeof(jtx_mi_bvh_node));   // page-locked landing buffers of the
+        const int *ord = (const int *) sp.pin_ord.ensure((size_t) np * sizeof(int));                                     // spare set (sized once: <= 2 np nodes)
+        HIPCHK(hipMemcpyAsync(pinNodes, sp.hn.p, (size_t) nn * sizeof(jtx_mi_bvh_node), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync((void *) ord, sp.order.p, (size_t) np * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         // ---- triangle / shading records recomputed from the re-ordered sources; the 8 threaded orderings ----
         if (s->pbox.cap < 2 * (size_t) np) s->pbox.alloc(2 * (size_t) np);          // (scratch of the refit kernels, not read by any render)
         sp.tnodes.ensure(2 * 8 * (size_t) nn); sp.rec_node.ensure(8 * (size_t) nn);
@@ -1238,6 +1309,7 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit) 
         HIPCHK(jtx_launch_refit_prims(a, s->stream));
         HIPCHK(jtx_launch_build_threaded(sp.nbox.p, sp.pos.p, sp.size.p, nn, sp.tnodes.p, sp.rec_node.p, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        std::memcpy(nodes2.data(), pinNodes, (size_t) nn * sizeof(jtx_mi_bvh_node));
         lap("records, 8 threaded orderings");
         std::vector<jtx_mi_tri_ref> refs(np); std::vector<int32_t> orig(np);
         for (int i = 0; i < np; ++i) { refs[i] = s->bvh.refs[ord[i]]; orig[i] = s->bvh.orig[ord[i]]; }
@@ -1248,7 +1320,7 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit) 
             std::vector<uint4> wh; std::vector<int32_t> wm; int wd = 0;
             if (buildWide(nodes2, wh, wd, &wm) && wd <= kMaxWideDepth) {
                 sp.wide.fill(wh); sp.map.ensure(wm.size());
-                if (!wm.empty()) HIPCHK(hipMemcpy(sp.map.p, wm.data(), wm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                stagedH2D(sp.map.p, wm.data(), wm.size() * sizeof(int32_t));
                 wideOk = true; wideDepth = wd; numWide = (int) (wm.size() / 16); wideGranules = wh.size();
             }
         }
@@ -1259,7 +1331,7 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit) 
             int nl = 0; for (const jtx_mi_bvh_node &n : nodes2) if (n.num_prims) ++nl;
             if (nl > 0 && nl <= 32 && nn > 1) {
                 std::vector<int> hpos(8 * (size_t) nn);
-                HIPCHK(hipMemcpy(hpos.data(), sp.pos.p, hpos.size() * sizeof(int), hipMemcpyDeviceToHost));
+                stagedD2H(hpos.data(), sp.pos.p, hpos.size() * sizeof(int));
                 nleafList = buildLeafTables(nodes2, hpos, sp.lw_box, sp.lw_tab);
             }
         }
@@ -1270,7 +1342,7 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit) 
         bool newLights = false;
         if (s->lights.n) {
             std::vector<DLight> ls(s->lights.n);
-            HIPCHK(hipMemcpy(ls.data(), s->lights.p, ls.size() * sizeof(DLight), hipMemcpyDeviceToHost));
+            stagedD2H(ls.data(), s->lights.p, ls.size() * sizeof(DLight));
             for (auto &l : ls) if (l.type == 1) { l.scene_radius = radius; newLights = true; }
             if (newLights) sp.lights.fill(ls);
         }
@@ -1511,7 +1583,8 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         __atomic_store_n(s->stop_host, 0u, __ATOMIC_RELEASE);                  // stopRender_ = false (camera.cpp:48)
         if (s->film_acc.n != 3 * npix) { s->film_acc.alloc(3 * npix); s->film_img.alloc(3 * npix); }
         if (sb == 0) HIPCHK(hipMemsetAsync(s->film_acc.p, 0, sizeof(float) * 3 * npix, s->stream));
-        else HIPCHK(hipMemcpyAsync(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix, hipMemcpyHostToDevice, s->stream));
+        else if (hostPinned(acc_rgb)) HIPCHK(hipMemcpyAsync(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix, hipMemcpyHostToDevice, s->stream));
+        else { HIPCHK(hipStreamSynchronize(s->stream)); stagedH2D(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix); }      // a pageable caller buffer: through the library's staging
         HIPCHK(hipMemsetAsync(s->film_img.p, 0, 3 * npix, s->stream));
         const int tick = (cb && o.samples_per_tick > 0) ? o.samples_per_tick : (se - sb);
         jtx_mi_counters total{}; const bool count = o.count_rays != 0;
@@ -1632,9 +1705,9 @@ template <class T> struct Tmp {
     T *p = nullptr; size_t n = 0;
     Tmp(size_t count) : n(count) { if (count) HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); }
     Tmp(const T *h, size_t count) : n(count) {
-        if (count) { HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); HIPCHK(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice)); }
+        if (count) { HIPCHK(hipMalloc((void **) &p, count * sizeof(T))); stagedH2D(p, h, count * sizeof(T)); }
     }
-    void down(T *h) { if (h && n) HIPCHK(hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost)); }
+    void down(T *h) { if (h && n) stagedD2H(h, p, n * sizeof(T)); }
     ~Tmp() { if (p) (void) hipFree(p); }
 };
 }

@@ -21,6 +21,7 @@
 
 extern "C" const char *jtx_mi_last_error(void);
 int jtx_capi_fail(const std::string &msg);           // jtx_capi.hip: sets the thread's error text, returns 1
+void jtx_capi_d2h(void *dst, const void *src, size_t bytes, hipStream_t st);   // jtx_capi.hip: device -> caller memory (staged when pageable), complete on return; throws
 
 namespace {
 
@@ -262,7 +263,7 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
                                        r ? s.recv_img : s.slab_img, m->frame_acc, img_rgb ? m->frame_img : nullptr, nslots, r, n, W, H);
                     MHIPCHK(hipGetLastError());
                 }
-                if (img_rgb) MHIPCHK(hipMemcpyAsync(img_rgb, m->frame_img, 3 * npix, hipMemcpyDeviceToHost, root.stream));
+                if (img_rgb) jtx_capi_d2h(img_rgb, m->frame_img, 3 * npix, root.stream);
                 MHIPCHK(hipStreamSynchronize(root.stream));
             }
             done = e;
@@ -270,8 +271,7 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
         }
         {
             SetDev sd(root.device);
-            MHIPCHK(hipMemcpyAsync(acc_rgb, m->frame_acc, sizeof(float) * 3 * npix, hipMemcpyDeviceToHost, root.stream));
-            MHIPCHK(hipStreamSynchronize(root.stream));
+            jtx_capi_d2h(acc_rgb, m->frame_acc, sizeof(float) * 3 * npix, root.stream);
         }
         for (int r = 0; r < n && r < 64; ++r) { float ms = 0; int32_t nl = 0; (void) jtx_mi_kernel_time(m->shards[r].scene, &ms, &nl); m->last_ms[r] = ms; }
         m->last_completed = done;

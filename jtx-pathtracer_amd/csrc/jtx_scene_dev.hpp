@@ -281,6 +281,13 @@ constexpr unsigned WIDE_NODE_G = jtxq::kNodeG;   // granules (16 B) from one int
 #ifndef JTX_WIDE_STEPS
 #define JTX_WIDE_STEPS 1
 #endif
+#ifndef JTX_WIDE_SIGNBYTES
+#define JTX_WIDE_SIGNBYTES 0         // 1: the hit mask of a node from the SIGN BYTES of t1 - t0 (v_perm_b32 / v_bitop3_b32 / v_sad_u8, wideNodePend) instead of
+                                     // compare / select / or
+#endif
+#ifndef JTX_WIDE_PEND_BARRIER
+#define JTX_WIDE_PEND_BARRIER 1
+#endif
 #ifndef JTX_WIDE_ROOT_PEEL
 #define JTX_WIDE_ROOT_PEEL 0         // 1: the first step reads the root's children through scalar loads (measured: C3 +2 %, C5 -2 %; the root's
                                      // vector loads are one coalesced request per wave anyway -- DESIGN.md section 10)
@@ -337,6 +344,55 @@ JD unsigned wideNodeHits(const uint4 n0, const uint4 n2, const uint4 n3, const u
     return hits;
 }
 
+// The same test with the answer in POSITION space of an order list (JTX_WIDE_TAILS=8): ohLo / ohHi hold, per slot byte, the one-hot
+// position of the slot in the ray's visiting order (0: no child).  Per child t1 - t0 instead of a compare (a miss is a NEGATIVE
+// difference: t0, t1 are finite for the rays the wide nodes take, t1 is never -0 -- every far value is b + mu with mu > 0 -- and
+// t0 == t1 gives +0), v_perm_b32's sign selectors turn four sign bits into four bytes 0xff / 0x00, (not miss) AND one-hot, summed
+// over the bytes (distinct bits: a sum is an OR), is the pending mask: 8 v_sub + 4 v_perm + 3 v_bitop3 + 1 v_sad_u8 (48 cycles by
+// tools/micro/rate7.hip) where compare / select / or and the 8-bit permutation took 45 instructions of the 4.4-cycle class (198).
+JD unsigned wideNodePend(const uint4 n0, const uint4 n2, const uint4 n3, const uint4 n4, unsigned ohLo, unsigned ohHi, f3 o, f3 inv, float tmin, float tmax) {
+    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+    const float axx = __uint_as_float((n0.w & 0xffu) << 23) * inv.x, bxx = (__uint_as_float(n0.x) - o.x) * inv.x;
+    const float ayy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * inv.y, byy = (__uint_as_float(n0.y) - o.y) * inv.y;
+    const float azz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * inv.z, bzz = (__uint_as_float(n0.z) - o.z) * inv.z;
+    const float mux = __fmaf_rn(fabsf(bxx), WIDE_MU_B, __fmaf_rn(fabsf(axx), WIDE_MU_A, WIDE_MU_0));
+    const float muy = __fmaf_rn(fabsf(byy), WIDE_MU_B, __fmaf_rn(fabsf(ayy), WIDE_MU_A, WIDE_MU_0));
+    const float muz = __fmaf_rn(fabsf(bzz), WIDE_MU_B, __fmaf_rn(fabsf(azz), WIDE_MU_A, WIDE_MU_0));
+    const float bnx = bxx - mux, bfx = bxx + mux, bny = byy - muy, bfy = byy + muy, bnz = bzz - muz, bfz = bzz + muz;
+    const unsigned nxq[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, fxq[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
+    const unsigned nyq[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, fyq[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
+    const unsigned nzq[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, fzq[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
+    float df[8];
+    unsigned mk[4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int w = s >> 2, b = s & 3;
+        const float t0 = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)),
+                               fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), tmin));
+        const float t1 = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)),
+                               fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), tmax));
+        df[s] = t1 - t0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // v_perm_b32 D, S0, S1, sel: selector 0x0b = 8 x S0[31], 0x09 = 8 x S1[31], 0x0c = 0x00 (checked on the chip: rate7.hip)
+        if (s & 1) {
+            mk[s >> 1] = __builtin_amdgcn_perm(__float_as_uint(df[s - 1]), __float_as_uint(df[s]), (s & 2) ? 0x090b0c0cu : 0x0c0c090bu);
+#if JTX_WIDE_PEND_BARRIER
+            __builtin_amdgcn_sched_barrier(0);                  // two children at a time: eight differences live at once spill INSIDE the node loop
+#endif
+        }
+#endif
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned xl = __builtin_amdgcn_bitop3_b32(mk[0], mk[1], ohLo, 0x02);          // ~a & ~b & c
+    const unsigned xh = __builtin_amdgcn_bitop3_b32(mk[2], mk[3], ohHi, 0x02);
+    return __builtin_amdgcn_sad_u8(__builtin_amdgcn_bitop3_b32(xl, xh, xh, 0xfc), 0u, 0u);   // a | b
+#else
+    unsigned pend = 0u;
+    for (int s = 0; s < 8; ++s) if (!(df[s] < 0.0f) && !(__float_as_uint(df[s]) >> 31)) pend |= ((s < 4 ? ohLo : ohHi) >> (8 * (s & 3))) & 0xffu;
+    return pend;
+#endif
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 JD unsigned wideField3(unsigned v, int at) { return __builtin_amdgcn_ubfe(v, (unsigned) at, 3u); }
 JD unsigned wideBit(unsigned v, unsigned at) { return __builtin_amdgcn_ubfe(v, at, 1u); }
@@ -388,11 +444,23 @@ JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, con
     const unsigned a = base + WIDE_NODE_G * slot;
     if (ws.gbits & 0xffu) { stk[ws.sp * stride + (LANECOL ? wideLaneId() : 0u)] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
     const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
-    const uint4 tl = wide[a + 4 + (jtxq::kTails == 2 && ORDERED ? (unsigned) (r.negmask >> 2) : 0u)];   // [children base | the 24-bit visiting orders of 4 octants]
-    const unsigned hits = wideNodeHits(n0, n2, n3, n4, r.o, r.inv, r.tmin, r.tmax);
-    // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first)
-    const unsigned perm = ORDERED ? wideOrderOf(tl.y, tl.z, tl.w, jtxq::kTails == 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;   // identity: slot k at position k
+    const uint4 tl = wide[a + 4 + (!ORDERED ? 0u : jtxq::kTails == 8 ? (unsigned) r.negmask : jtxq::kTails == 2 ? (unsigned) (r.negmask >> 2) : 0u)];
     const unsigned nchild = n0.w >> 28;
+    if (jtxq::kTails == 8) {        // tail of the ray's octant: [children base | its order | one-hot positions of slots 0-3 | 4-7]
+        const unsigned perm = ORDERED ? tl.y : 0x00fac688u;
+        const unsigned pend = ORDERED ? wideNodePend(n0, n2, n3, n4, tl.z, tl.w, r.o, r.inv, r.tmin, r.tmax)
+                                      : wideNodePend(n0, n2, n3, n4, 0x08040201u, 0x80402010u, r.o, r.inv, r.tmin, r.tmax) & ((1u << nchild) - 1u);
+        ws.gbase = tl.x | (((n0.w >> 24) & 0xfu) << 28);
+        ws.gbits = pend | (perm << 8);
+        return;
+    }
+#if JTX_WIDE_SIGNBYTES
+    const unsigned hits = wideNodePend(n0, n2, n3, n4, 0x08040201u, 0x80402010u, r.o, r.inv, r.tmin, r.tmax);    // identity one-hots: slot space
+#else
+    const unsigned hits = wideNodeHits(n0, n2, n3, n4, r.o, r.inv, r.tmin, r.tmax);
+#endif
+    // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first); tail = [children base | the orders of 4 octants]
+    const unsigned perm = ORDERED ? wideOrderOf(tl.y, tl.z, tl.w, jtxq::kTails == 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;   // identity: slot k at position k
     const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);   // (the identity list leaves the hits where they are)
     ws.gbase = tl.x | (((n0.w >> 24) & 0xfu) << 28);
     ws.gbits = pend | (perm << 8);
@@ -430,8 +498,8 @@ JD void wideRootStep(const uint4 *__restrict__ wide, const WideRay &r, WideState
         if (JTX_PEEL_GROUP < 8) __builtin_amdgcn_sched_barrier(0);
 #endif
     }
-    const bool hiOct = jtxq::kTails == 2 && (r.negmask & 4);
-    const unsigned perm = ORDERED ? wideOrderOf(hiOct ? rec[5] : rec[1], hiOct ? rec[6] : rec[2], hiOct ? rec[7] : rec[3], jtxq::kTails == 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;
+    const bool hiOct = jtxq::kTails >= 2 && (r.negmask & 4);
+    const unsigned perm = ORDERED ? wideOrderOf(hiOct ? rec[5] : rec[1], hiOct ? rec[6] : rec[2], hiOct ? rec[7] : rec[3], jtxq::kTails >= 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;
     const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);
     ws.gbase = grp; ws.gbits = pend | (perm << 8);
     ws.sp = 0; ws.pendLeaf = -1; ws.done = false; ws.hitAnything = false;

@@ -6,16 +6,19 @@
 //   root-peel record   granules 0..13 (kPeelRec): what a peeled first step (JTX_WIDE_ROOT_PEEL=1, off by default) reads with scalar loads:
 //                      [group word | the visiting orders of octants 0-3][#children | orders of octants 4-7][8 children x exact box, 6 floats]
 //   root node          granules 16.. (kRootNode): the root as an ordinary node
-//   children blocks    from granule 24 (kFirstBlock): for a node with ni interior children and nl leaves
+//   children blocks    from granule 32 (kFirstBlock): for a node with ni interior children and nl leaves
 //                          [ni x node, kNodeG granules each][nl x leaf record, 2 granules]
-//   node (96 B)        g0 [origin.xyz (float: the node's min corner) | ex ey ez, ni << 24, (ni + nl) << 28]   plane = origin + q 2^e
+//   node (192 B)       g0 [origin.xyz (float: the node's min corner) | ex ey ez, ni << 24, (ni + nl) << 28]   plane = origin + q 2^e
 //                      g1 [lo.x x8 | lo.y x8]  g2 [lo.z x8 | hi.x x8]  g3 [hi.y x8 | hi.z x8]   (8-bit planes, slot s = byte s)
-//                      g4 [children block granule | the 24-bit visiting orders (3 bits per position) of direction-sign octants 0..3,
-//                          back to back in 3 words]   g5 the same for octants 4..7 (a ray reads the tail of its z sign: base AND order
-//                          in one load)
+//                      g4..g11  ONE TAIL PER DIRECTION-SIGN OCTANT q [children block granule | the octant's 24-bit visiting order (3 bits
+//                          per position) | one-hot position of slots 0-3, a byte each | of slots 4-7]: a ray reads the tail of its
+//                          octant -- base, order and the words that turn its eight pass / miss bytes into the pending mask of the
+//                          order list (wideNodePend: the permutation of the hit bits costs one AND and one byte sum, not 26 instructions)
 //   leaf record (32 B) the exact leaf box + primitivesOffset + numPrimitives  [min.x max.x min.y max.y][min.z max.z offset count]
-// This IS round 3's node.  Four other layouts were built, taken through the whole parity suite and measured this round (DESIGN.md
-// section 10; profiles/r04_wide_layouts.md), each behind the encoders of this file:
+// Rounds 1-3 had TWO tails (octants 0-3 / 4-7: base + four 24-bit orders; 96-byte nodes; JTX_WIDE_TAILS=2 still builds it) and permuted
+// the hit mask in registers.  With the per-octant tails C3 320 -> 305 ms, C5 303 -> 287 (SQ_INSTS_VALU -6.5 %, L2 requests +7 % from the
+// larger nodes); see DESIGN.md section 10.  Other layouts built, taken through the whole parity suite and measured in round 4
+// (profiles/r04_wide_layouts.md), each behind the encoders of this file:
 //   * the children base packed INTO the header beside a 24-bit integer origin (plane = (k + q) 2^e), so that an anyHit step reads four
 //     granules instead of five: (a) 64-byte nodes on 64-byte boundaries, order granules at the end of the block: C3 339 ms against 319;
 //     (b) order granule behind its node: 331 ms.  3.4 % fewer load instructions, but unpacking the header costs 12-16 VALU
@@ -25,7 +28,8 @@
 //     against 321 / 303 -- the per-ray direction flag and class cost two more live registers in kernels that spill 94-161;
 //   * JTX_WIDE_ROOT_PEEL=1: the root's children on their exact boxes through scalar loads: C3 327 (+2 %),
 //     C5 297 (-2 %); the 48 box words take 10 more spilled SGPRs and ~85 v_readlane per bounce, and the five vector loads it
-//     removes were ONE coalesced request per wave each (all 64 lanes read the root), not 64.
+//     removes were ONE coalesced request per wave each (all 64 lanes read the root), not 64;
+//   * children blocks padded to 64 / 128 bytes on top of the per-octant tails: +-0.
 //
 // Quantisation: a node's grid is plane = origin + q * 2^e per axis, q in 0..255, origin = the node's min corner, e the smallest
 // exponent with origin + 255 * 2^e >= max corner.  Child planes are rounded OUTWARD (q_lo = the largest grid plane <= the child's min,
@@ -45,13 +49,13 @@ namespace jtxq {
 constexpr int kWideMinExp = -60, kWideMaxExp = 40;   // cell = 2^e; with |1/d| in [2^-40, 2^40] (WIDE_RANGE) cell / d is exact
 constexpr float kWideCoordMax = 1099511627776.0f;    // 2^40
 
-constexpr uint32_t kPeelRec = 0, kPeelBoxes = 2, kRootNode = 16, kFirstBlock = 24;
 #ifndef JTX_WIDE_TAILS
-#define JTX_WIDE_TAILS 2                             // 2: round 3's two tail granules (octants 0-3 / 4-7); 1: one, octants 4..7 walk the orders of 3..0
-                                                     // backwards: 80-byte nodes, but the per-ray direction flag costs C3 +1.7 %, C5 +4.6 % (measured)
+#define JTX_WIDE_TAILS 8                             // 8: a tail per octant (the product); 2: rounds 1-3's two tail granules (octants 0-3 / 4-7);
+                                                     // 1: one, octants 4..7 walk the orders of 3..0 backwards
 #endif
-constexpr uint32_t kTails = JTX_WIDE_TAILS;
+constexpr uint32_t kTails = JTX_WIDE_TAILS;          // 8: one tail granule PER OCTANT [children base | its 24-bit order | the one-hot POSITION of slots 0-3 | of slots 4-7]
 constexpr uint32_t kNodeG = 4 + kTails;              // granules of a node record
+constexpr uint32_t kPeelRec = 0, kPeelBoxes = 2, kRootNode = 16, kFirstBlock = kTails > 2 ? 32 : 24;
 constexpr uint32_t kMaxGranules = 1u << 28;          // the children base shares its word with a 4-bit count in the kernel's group state
 JTXQ_HD uint32_t blockGranules(int ni, int nl) { return kNodeG * (uint32_t) ni + 2u * (uint32_t) nl; }
 JTXQ_HD uint32_t nodeAt(uint32_t base, int s) { return base + kNodeG * (uint32_t) s; }
@@ -124,6 +128,16 @@ JTXQ_HD bool encodeTail(uint32_t *w, uint32_t base, const uint32_t perm[8], int 
     for (int q = 0; q < 4; ++q)
         for (int p = 0; p < nchild; ++p)
             if (((perm[q] >> (3 * p)) & 7u) != ((perm[7 - q] >> (3 * (nchild - 1 - p))) & 7u)) return false;
+    if (kTails == 8) {
+        // byte s of the two one-hot words = 1 << (position of slot s in this octant's order), 0 for a slot without a child: a per-child
+        // pass / miss byte mask ANDed with them and summed over its bytes IS the pending mask in position space (wideNodePend)
+        for (uint32_t t = 0; t < 8; ++t) {
+            uint32_t oh[2] = {0u, 0u};
+            for (int p = 0; p < nchild; ++p) { const uint32_t sl = (perm[t] >> (3 * p)) & 7u; oh[sl >> 2] |= (1u << p) << (8 * (sl & 3u)); }
+            w[4 * t + 0] = base; w[4 * t + 1] = perm[t] & 0x00ffffffu; w[4 * t + 2] = oh[0]; w[4 * t + 3] = oh[1];
+        }
+        return true;
+    }
     for (uint32_t t = 0; t < kTails; ++t) {
         const uint32_t *pm = perm + 4 * t;
         w[4 * t + 0] = base;
@@ -136,10 +150,12 @@ JTXQ_HD bool encodeTail(uint32_t *w, uint32_t base, const uint32_t perm[8], int 
 
 // the root-peel record (14 granules = 56 words): group word + the orders, #children, then the EXACT boxes of the root's children in slot order
 // [min.x max.x min.y max.y min.z max.z]; unused slots zero (masked by nchild in the kernel)
-JTXQ_HD void encodePeelHeader(uint32_t *rec, uint32_t base, int ni, int nchild, const uint32_t *tail) {
-    rec[0] = groupWord(base, ni); rec[1] = tail[1]; rec[2] = tail[2]; rec[3] = tail[3];
-    rec[4] = (uint32_t) nchild; rec[5] = rec[6] = rec[7] = 0u;
-    if (kTails == 2) { rec[5] = tail[5]; rec[6] = tail[6]; rec[7] = tail[7]; }       // octants 4..7
+JTXQ_HD void encodePeelHeader(uint32_t *rec, uint32_t base, int ni, int nchild, const uint32_t perm[8]) {
+    rec[0] = groupWord(base, ni); rec[4] = (uint32_t) nchild; rec[5] = rec[6] = rec[7] = 0u;
+    for (uint32_t t = 0; t < (kTails == 1 ? 1u : 2u); ++t) {                        // four 24-bit orders back to back; octants 4..7 behind #children
+        const uint32_t *pm = perm + 4 * t;
+        rec[4 * t + 1] = pm[0] | (pm[1] & 0xffu) << 24; rec[4 * t + 2] = pm[1] >> 8 | (pm[2] & 0xffffu) << 16; rec[4 * t + 3] = pm[2] >> 16 | pm[3] << 8;
+    }
 }
 JTXQ_HD void encodePeelBox(uint32_t *rec, int slot, const float cmin[3], const float cmax[3]) {
     union { float f; uint32_t u; } c;

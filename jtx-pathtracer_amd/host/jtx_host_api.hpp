@@ -14,6 +14,7 @@
 #include <thread>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -177,6 +178,23 @@ private:
 };
 
 struct RGB { unsigned char R, G, B; };
+// Film storage the cameras page-lock (jtx_mi_pin_host): whole pages of its own.  Page-locking works on pages; a plain std::vector's
+// block shares its first and last page with whatever else the allocator put there.
+template <class T> struct PageAllocator {
+    typedef T value_type;
+    PageAllocator() = default;
+    template <class U> PageAllocator(const PageAllocator<U> &) {}
+    T *allocate(std::size_t n) {
+        void *p = nullptr;
+        const std::size_t bytes = (n * sizeof(T) + 4095) / 4096 * 4096;
+        if (posix_memalign(&p, 4096, bytes ? bytes : 4096) != 0) throw std::bad_alloc();
+        return (T *) p;
+    }
+    void deallocate(T *p, std::size_t) { std::free(p); }
+    template <class U> bool operator==(const PageAllocator<U> &) const { return true; }
+    template <class U> bool operator!=(const PageAllocator<U> &) const { return false; }
+};
+
 class RGB8Image {                                                     // image.hpp:18-58
 public:
     int w_ = 0, h_ = 0;
@@ -221,7 +239,7 @@ public:
         std::fclose(f);
     }
 private:
-    std::vector<RGB> buffer;
+    std::vector<RGB, PageAllocator<RGB>> buffer;
 };
 class AccumulationBuffer {                                            // image.hpp:64-92
 public:
@@ -232,7 +250,7 @@ public:
     const Vec3 *data() const { return buffer_.data(); }
     Vec3 *data() { return buffer_.data(); }
 private:
-    std::vector<Vec3> buffer_;
+    std::vector<Vec3, PageAllocator<Vec3>> buffer_;
 };
 
 class Camera {                                                        // camera.hpp:20-140

@@ -28,12 +28,13 @@ def slab_q(nd, s, o, inv, tmin, tmax):
     return t0 <= t1
 
 
-ROOT_NODE, ROOT_ORDER, FIRST_BLOCK, PEEL_BOXES, NODE_G = 16, 20, 24, 2, 6      # jtx_wide_quant.hpp: kRootNode (+ 4), kFirstBlock, kPeelBoxes, kNodeG
+ROOT_NODE, ROOT_ORDER, FIRST_BLOCK, PEEL_BOXES, NODE_G = 16, 20, 32, 2, 12     # jtx_wide_quant.hpp: kRootNode (+ 4), kFirstBlock, kPeelBoxes, kNodeG
 
 
 def decode(w, a, oa=None):
-    """wide node at granule a -> dict (layout: jtx_wide_quant.hpp)"""
-    n0, n1, n2, n3, n4, n5 = (w[a + i] for i in range(6))
+    """wide node at granule a -> dict (layout: jtx_wide_quant.hpp, one tail granule per direction-sign octant)"""
+    n0, n1, n2, n3 = (w[a + i] for i in range(4))
+    tails = [w[a + 4 + q] for q in range(8)]
     assert oa is None or oa == a + 4
     origin = n0[:3].view(np.float32)
     cell = [np.array([((int(n0[3]) >> (8 * k)) & 0xff) << 23], np.uint32).view(np.float32)[0] for k in range(3)]
@@ -41,14 +42,17 @@ def decode(w, a, oa=None):
     lo = [byts(n1[0], n1[1]), byts(n1[2], n1[3]), byts(n2[0], n2[1])]
     hi = [byts(n2[2], n2[3]), byts(n3[0], n3[1]), byts(n3[2], n3[3])]
     n = int(n0[3]) >> 28
-    assert int(n5[0]) == int(n4[0])                       # the children base stands in both tail granules
     order = []
-    for half in (n4, n5):                                 # octants 0-3 / 4-7: 4 x 24 bit behind the base
-        bits = int(half[1]) | int(half[2]) << 32 | int(half[3]) << 64
-        order += [[(bits >> (24 * o + 3 * k)) & 7 for k in range(n)] for o in range(4)]
-    for o in range(4):                                    # every sign flipped = the same list backwards (what JTX_WIDE_TAILS=1 builds on)
+    for t in tails:                                       # [children base | 24-bit visiting order | one-hot position of slots 0-3 | of slots 4-7]
+        assert int(t[0]) == int(tails[0][0])              # the children base stands in every tail granule
+        assert int(t[1]) >> 24 == 0
+        od = [(int(t[1]) >> (3 * k)) & 7 for k in range(n)]
+        onehot = byts(t[2], t[3])                         # what wideNodePend ANDs the per-slot pass bytes with: 1 << position, 0 for no child
+        assert onehot == [(1 << od.index(sl)) if sl in od else 0 for sl in range(8)]
+        order.append(od)
+    for o in range(4):                                    # every sign flipped = the same list backwards (the encoder checks it)
         assert order[7 - o] == list(reversed(order[o]))
-    return dict(origin=origin, cell=cell, base=int(n4[0]), ni=(int(n0[3]) >> 24) & 0xf, n=n, lo=lo, hi=hi, order=order)
+    return dict(origin=origin, cell=cell, base=int(tails[0][0]), ni=(int(n0[3]) >> 24) & 0xf, n=n, lo=lo, hi=hi, order=order)
 
 
 def child_addr(nd, slot):
@@ -114,7 +118,9 @@ def wide_leaves_peeled(w, o, inv, neg, tmin, tmax):
     octant = neg[0] | neg[1] << 1 | neg[2] << 2
     root = decode(w, ROOT_NODE, ROOT_ORDER)
     assert int(w[0][0]) == (root["base"] | root["ni"] << 28) and int(w[1][0]) == root["n"]
-    assert [int(x) for x in w[0][1:4]] == [int(x) for x in w[ROOT_ORDER][1:4]] and [int(x) for x in w[1][1:4]] == [int(x) for x in w[ROOT_ORDER + 1][1:4]]
+    for half in (0, 1):                                   # the record's orders: 4 x 24 bit back to back, octants 0-3 behind the group word, 4-7 behind #children
+        bits = int(w[half][1]) | int(w[half][2]) << 32 | int(w[half][3]) << 64
+        assert [[(bits >> (24 * q + 3 * k)) & 7 for k in range(root["n"])] for q in range(4)] == root["order"][4 * half:4 * half + 4]
     boxes = w[PEEL_BOXES:PEEL_BOXES + 12].reshape(-1).view(np.float32).reshape(8, 6)
     out = []
     for s in root["order"][octant]:
