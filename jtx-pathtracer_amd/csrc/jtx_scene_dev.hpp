@@ -253,21 +253,21 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 // leaf's box against the current interval; if it passes, test its triangles.  Any structure that walks
 // the leaves in that order and only skips leaves whose box test would fail gives bit-identical hits.
 // The uncounted kernels use that freedom (the counted ones keep the reference's node visits):
-//   wide node (80 B = 5 x 16 B): a treelet of the binary tree below a node cut into at most 8
+//   wide node (192 B = 12 x 16 B): a treelet of the binary tree below a node cut into at most 8
 //     children (the cut that minimises the summed box area of all wide nodes, jtx_capi.hip); slots = its wide (interior)
 //     children first, then its leaves, each left to right; every child box quantised OUTWARD to 8 bits per plane on the
 //     node's own grid (plane = origin + q 2^e, checked in exact arithmetic by the builder), so a slab test on it can only
 //     pass more often than on any exact box inside it.  Bit layout, children blocks and the root-peel record:
 //     jtx_wide_quant.hpp (the one place that encodes them).
 //       [origin.xyz | ex ey ez, #interior, #children] [lo.x x8 | lo.y x8] [lo.z x8 | hi.x x8] [hi.y x8 | hi.z x8]
-//       [children base | the 24-bit visiting orders of octants 0-3]
+//       8 x [children base | the octant's 24-bit visiting order | one-hot position of slots 0-3 | of slots 4-7]
 //     visiting order of an octant: the slots in the order the reference's near-first rule (dirIsNeg[axis], scene.cpp:40-46)
-//     walks the treelet, 3 bits per position; octant q >= 4 takes the order of octant 7 - q from its END (all three signs
-//     flipped = every near / far decision flipped = the same list backwards): one tail granule instead of round 3's two.
+//     walks the treelet, 3 bits per position.  A ray reads the tail of ITS octant; the one-hot words turn the eight pass / miss
+//     bytes of the box tests (sign bytes of t1 - t0, v_perm_b32) into the pending mask of the order list with one AND and one
+//     byte sum (wideNodePend) -- rounds 1-3 permuted the eight hit bits with 26 instructions (widePending; JTX_WIDE_TAILS=2).
 //   leaf record (32 B): the exact leaf box + primitivesOffset + numPrimitives, tested with slabRegular.
-//   first step (round 4, "root peel"): every lane of a wave enters at the root, so the root's children are tested on their
-//     EXACT boxes read with scalar loads (wave-uniform addresses, SGPR operands: no vector-memory instruction, no byte
-//     conversions) -- 1 of ~10 node steps per ray leaves the vector-memory pipeline.
+//   first step ("root peel", JTX_WIDE_ROOT_PEEL=1, measured and left off): every lane of a wave enters at the root, so the root's
+//     children can be tested on their EXACT boxes read with scalar loads (the record at the head of the array).
 // The per-lane stack holds one 64-bit entry per wide level {header word, visiting order, pending positions} in LDS.
 // A stale hit bit (t.max shrank since the node was tested) only costs a visit.  Irregular rays (a zero / non-finite
 // direction component ...) take the exact binary path.
@@ -276,7 +276,7 @@ constexpr unsigned WIDE_NODE_G = jtxq::kNodeG;   // granules (16 B) from one int
 #define JTX_WIDE_LEAF_VOTE 16
 #endif
 #ifndef JTX_WIDE_FEW_WALKERS
-#define JTX_WIDE_FEW_WALKERS 16
+#define JTX_WIDE_FEW_WALKERS 8          // (re-swept on the per-octant tails: 4 / 8 / 12 / 16 / 24 -> C3 300.8 / 299.8 / 303.0 / 304.5 / 309.0 ms, C5 +-1)
 #endif
 #ifndef JTX_WIDE_STEPS
 #define JTX_WIDE_STEPS 1
