@@ -208,7 +208,7 @@ int  jtx_mi_scene_rebuild(jtx_mi_scene *scene, int32_t max_prims_in_node);
 /* The edit loop's memory, ahead of the first edit (display.cpp:545-588 arms rebuildBVH_, :902-905 rebuilds): jtx_mi_scene_rebuild
  * writes a SECOND set of every structure it replaces and swaps the two when all of it stands (a failed rebuild leaves the scene as it
  * was); that set and the builder's scratch come into being with the first rebuild (~330 MB for 256 k triangles; device memory is
- * mapped at first touch and the builder's code object loaded at its first launch: 26-33 ms against 6.8 ms for every later rebuild)
+ * mapped at first touch and the builder's code object loaded at its first launch: 26-33 ms against 7 ms for every later rebuild)
  * -- or here, e.g. right after loading: a dry run of the rebuild that stops before the commit, so that the first edit costs what
  * every later one does.  The scene is not changed.  Optional; may be called again. */
 int  jtx_mi_scene_reserve_rebuild(jtx_mi_scene *scene);

@@ -1239,7 +1239,7 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit);
 
 // A DRY RUN of the rebuild: everything jtx_mi_scene_rebuild does except its commit section.  hipMalloc alone would not do: device
 // memory is mapped at first touch and a translation unit's code object is loaded at its first launch -- measured on the atrium,
-// allocation 0.9 ms, but the first rebuild still 26 ms against 6.8 for the second.  After the dry run the first rebuild is a second one.
+// allocation 0.9 ms, but the first rebuild still 26 ms against 7 for the second.  After the dry run the first rebuild is a second one.
 int jtx_mi_scene_reserve_rebuild(jtx_mi_scene *s) { return rebuildImpl(s, 1, false); }
 
 namespace {
