@@ -220,6 +220,28 @@ def test_render_resume_and_progress(gpu, cornell_pair):
     assert (stop.img_ == two.img_).all()
 
 
+def test_pageable_caller_buffers_take_the_staged_path(gpu, cornell_pair, monkeypatch):
+    """Film buffers the caller did NOT page-lock (a C++ host's plain vectors; JTX_PIN_CAMERA_BUFFERS=0 here): delivery and the upload of a
+    resumed accumulation go through the library's own page-locked staging (no pageable pointer reaches a HIP copy: DESIGN.md section
+    10, "found by the project's own test runs") -- same film, bit for bit, incl. a frame larger than one 8 MB staging chunk."""
+    data, sc, osc = cornell_pair
+    pinned = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4); pinned.render(sc)
+    assert pinned._pinned and pinned.acc_.ctypes.data % 4096 == 0             # the mirror's own buffers: page-aligned private mappings, page-locked
+    monkeypatch.setenv("JTX_PIN_CAMERA_BUFFERS", "0")
+    plain = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4)
+    plain.render(sc, sample_begin=0, sample_end=3)
+    plain.render(sc, sample_begin=3, sample_end=8)                             # the resumed accumulation is uploaded from pageable memory
+    assert plain._pinned == []
+    assert_same_f32(plain.acc_, pinned.acc_, "film through the staging buffers"); assert (plain.img_ == pinned.img_).all()
+    big_p = gpu.StaticCamera(1200, 800, data.camera, 1, 1, 3)                  # 11.5 MB of accumulation: two staging chunks
+    big_u = gpu.StaticCamera(1200, 800, data.camera, 1, 1, 3)
+    big_u.render(sc)
+    monkeypatch.setenv("JTX_PIN_CAMERA_BUFFERS", "1")
+    big_p.render(sc)
+    assert big_u._pinned == [] and big_p._pinned
+    assert_same_f32(big_u.acc_, big_p.acc_, "large film through the staging buffers"); assert (big_u.img_ == big_p.img_).all()
+
+
 def test_cancel_reaches_the_pass_in_flight(gpu, atrium_full):
     """Camera::terminateRender from another thread (the UI thread, display.cpp:899-910) while ONE long pass is on the
     GPU (the reference polls stopRender_ per pixel, camera.cpp:84-98): the persistent waves stop fetching chunks, the

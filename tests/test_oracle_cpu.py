@@ -497,3 +497,22 @@ def test_host_bvh_build_says_when_the_reference_would_not_terminate():
     s.add_mesh(np.arange(len(v), dtype=np.int32).reshape(-1, 3), v, np.tile(np.array([[0, 0, 1]], np.float32), (len(v), 1)), 0)
     with pytest.raises(Exception, match="does not terminate"):
         api.bvh_build_host(s)
+
+
+def test_film_buffers_of_the_python_mirror_have_pages_of_their_own():
+    """api._film_array: the arrays the cameras page-lock are zeroed, writable, page-aligned private mappings (not numpy-allocator blocks
+    that share their first and last page with other heap objects) and survive the camera object"""
+    import gc
+    import numpy as np
+    from jtx_pathtracer_amd import api
+    a = api._film_array((120, 200, 3), np.float32)
+    assert a.shape == (120, 200, 3) and a.dtype == np.float32 and a.flags.writeable and a.flags.c_contiguous
+    assert a.ctypes.data % 4096 == 0 and not a.any()
+    a[...] = 2.0
+    assert api._film_array((0, 0, 3), np.uint8).shape == (0, 0, 3)
+    cam = api.StaticCamera(64, 48, dict(center=(0, 0, 0), target=(0, 0, 1), up=(0, 1, 0), yfov=40.0, defocus_angle=0.0, focus_distance=1.0), 2, 2, 3)
+    img, acc = cam.img_, cam.acc_
+    assert img.ctypes.data % 4096 == 0 and acc.ctypes.data % 4096 == 0 and img.shape == (48, 64, 3) and acc.dtype == np.float32
+    del cam; gc.collect()
+    acc[...] = 1.0; img[...] = 7                                                  # the mappings live as long as the arrays
+    assert float(acc.sum()) == 48 * 64 * 3 and int(img[0, 0, 0]) == 7 and float(a[5, 5, 1]) == 2.0
