@@ -1076,10 +1076,10 @@ def test_stale_chunk_counter_does_not_cancel_other_launches(gpu, cornell_pair):
     through a launch that owns no counter (count_rays = 1) then read it and returned CANCELLED with an empty film."""
     import threading
     data, sc, osc = cornell_pair
-    cam = gpu.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+    cam = gpu.StaticCamera(1920, 1080, data.camera, 12, 12, 8)        # one 144-spp pass: ~60 ms on the GPU, so that the timer thread is in time
     timer = threading.Timer(0.004, cam.terminateRender)
     timer.start(); cam.render(sc); timer.join()
-    if cam.currentSample_ == 64:
+    if cam.currentSample_ == 144:
         pytest.skip("the frame finished before the cancellation arrived")
     small = gpu.StaticCamera(96, 64, data.camera, 2, 2, 4)
     small.samplesPerPass_ = 2
