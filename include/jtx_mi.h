@@ -229,7 +229,10 @@ int jtx_mi_render(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_
                   float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user);
 int jtx_mi_cancel(jtx_mi_scene *scene);                                     /* Camera::terminateRender(); thread-safe */
 /* Optional: page-lock a caller buffer (Camera::img_ / acc_, image.hpp:60-61,90-91) for as long as it lives, so that
- * jtx_mi_render DMA-writes it directly; pageable buffers work too (one extra host copy from the library's pinned staging). */
+ * jtx_mi_render DMA-writes it directly; pageable buffers work too (one extra host copy from the library's pinned staging).
+ * Page-locking works on whole pages: give such a buffer pages of its own (posix_memalign to 4096 with the size rounded up to pages,
+ * or an anonymous mmap) -- a plain malloc / std::vector block shares its first and last page with other heap objects -- and call
+ * jtx_mi_unpin_host before it is freed.  Host memory the library is handed WITHOUT this call never reaches a GPU copy directly. */
 int jtx_mi_pin_host(void *ptr, uint64_t bytes);
 int jtx_mi_unpin_host(void *ptr);
 int jtx_mi_last_completed_sample(const jtx_mi_scene *scene, int32_t *out);  /* currentSample_ after the last jtx_mi_render */
