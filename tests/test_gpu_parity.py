@@ -863,6 +863,7 @@ def test_cancel_inside_a_split_pass_reports_what_is_in_the_film(gpu, atrium_full
     data, sc, osc = atrium_full
     monkeypatch.setenv("JTX_MAX_RAD_MB", "280")                       # 1920x1080: 8 strata per launch, 8 launches per 64-spp pass
     cam = gpu.StaticCamera(1920, 1080, data.camera, 8, 8, 8)
+    cam._pin()
     timer = threading.Timer(0.17, cam.terminateRender)
     timer.start(); cam.render(sc); timer.join()
     n = cam.currentSample_
@@ -1077,6 +1078,7 @@ def test_stale_chunk_counter_does_not_cancel_other_launches(gpu, cornell_pair):
     import threading
     data, sc, osc = cornell_pair
     cam = gpu.StaticCamera(1920, 1080, data.camera, 12, 12, 8)        # one 144-spp pass: ~60 ms on the GPU, so that the timer thread is in time
+    cam._pin()                                                        # (page-locking 31 MB of fresh pages takes longer than the timer: do it before the clock runs)
     timer = threading.Timer(0.004, cam.terminateRender)
     timer.start(); cam.render(sc); timer.join()
     if cam.currentSample_ == 144:
