@@ -214,6 +214,10 @@ int  jtx_mi_scene_rebuild(jtx_mi_scene *scene, int32_t max_prims_in_node);
 int  jtx_mi_scene_reserve_rebuild(jtx_mi_scene *scene);
 int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
 int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
+/* The scene's 8-ary node set as it stands on the device -- after jtx_mi_scene_create, a device rebuild or a refit -- in the layout of
+ * jtx_mi_wide_build (read back for inspection: tests walk it against the binary tree).  granules_out may be NULL to query the size;
+ * 0 granules when the scene has none.  No counterpart in the reference (whose only acceleration structure is LinearBVHNode, bvh.hpp:7-15). */
+int  jtx_mi_scene_get_wide(jtx_mi_scene *scene, uint32_t *granules_out, int64_t capacity, int64_t *num_granules_out);
 
 /* StaticCamera::render(const Scene&) (camera.cpp:45-128), blocking.  acc_rgb: W*H*3 float sums
  * (AccumulationBuffer), img_rgb: W*H*3 u8 (RGB8Image); both HOST buffers owned by the caller.

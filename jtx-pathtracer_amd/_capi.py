@@ -99,6 +99,7 @@ SYMBOLS = {
     "jtx_mi_scene_destroy": (None, [_scene]),
     "jtx_mi_scene_get_info": (C.c_int, [_scene, P(SceneInfo)]),
     "jtx_mi_scene_get_bvh": (C.c_int, [_scene, P(BvhNode), P(TriRef)]),
+    "jtx_mi_scene_get_wide": (C.c_int, [_scene, _u32, C.c_int64, P(C.c_int64)]),
     "jtx_mi_render": (C.c_int, [_scene, P(CameraDesc), P(RenderOpts), _f, _u8, PROGRESS_CB, C.c_void_p]),
     "jtx_mi_decode_jpeg": (C.c_int, [_u8, C.c_int64, P(C.c_int32), P(C.c_int32), P(C.c_int32), _u8, C.c_int64]),
     "jtx_mi_decode_png": (C.c_int, [_u8, C.c_int64, P(C.c_int32), P(C.c_int32), P(C.c_int32), _u8, C.c_int64]),

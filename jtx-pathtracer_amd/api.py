@@ -101,6 +101,15 @@ class Scene:
         check(self._lib.jtx_mi_scene_get_bvh(self.handle, nodes, refs))
         return nodes_to_numpy(nodes, i["num_nodes"]), refs_to_numpy(refs, i["num_prims"])
 
+    def wide(self):
+        """the scene's 8-ary node set as it stands on the device (uint32 [granules, 4]; layout of wide_build_host)"""
+        ng = C.c_int64()
+        check(self._lib.jtx_mi_scene_get_wide(self.handle, None, 0, C.byref(ng)))
+        out = np.zeros((max(1, ng.value), 4), np.uint32)
+        if ng.value:
+            check(self._lib.jtx_mi_scene_get_wide(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32)), ng.value, C.byref(ng)))
+        return out[: ng.value]
+
     def bounds(self):
         """AABB of the root node (scene.hpp:71-74)."""
         n, _ = self.bvh()

@@ -1386,6 +1386,21 @@ int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     { int bs = 0; out->resident_workgroups = jtx_render_paths_grid(s->dev, s->num_cus, &bs); out->workgroup_size = bs; }
     return 0;
 }
+int jtx_mi_scene_get_wide(jtx_mi_scene *s, uint32_t *granules_out, int64_t capacity, int64_t *num_granules_out) {
+    try {
+        if (!s) throw std::runtime_error("null scene");
+        DeviceGuard dg(s->device);
+        std::lock_guard<std::mutex> lk(s->mu);
+        const size_t n = s->dev.wide ? s->wide.n : 0;
+        if (num_granules_out) *num_granules_out = (int64_t) n;
+        if (granules_out && n) {
+            if ((int64_t) n > capacity) throw std::runtime_error("granules_out too small");
+            HIPCHK(hipStreamSynchronize(s->stream));
+            stagedD2H(granules_out, s->wide.p, n * sizeof(uint4));
+        }
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
 int jtx_mi_scene_get_bvh(const jtx_mi_scene *s, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out) {
     if (!s) return fail("null scene");
     if (nodes_out) std::memcpy(nodes_out, s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(jtx_mi_bvh_node));

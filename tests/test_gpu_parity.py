@@ -1598,3 +1598,49 @@ def test_rccl_takes_the_exchange_of_the_sharded_frame(gpu):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["rccl_selfcheck"] == "ok" and line["gather"] and line["reduce"] and line["slab_bytes"] == 640 * 360 * 15
+
+
+def test_device_built_and_refitted_wide_nodes_walk_like_the_binary_tree(gpu):
+    """The 8-ary node set as it stands ON THE DEVICE (jtx_mi_scene_get_wide) after a device rebuild and after a refit, walked by the
+    CPU test's walker (tests/test_wide_bvh_cpu.py: its decoder asserts, per node and octant, one-hot positions == visiting order and
+    octant 7 - q == octant q reversed): for random rays it reaches the leaves the reference's binary traversal reaches, in the
+    reference's order -- through the quantised nodes and through the root-peel record.  The host builder's array has this test on the
+    CPU; the device builder (k_wide_fill) and the refit kernels write the same layout through the same encoders, and this is where
+    their OUTPUT is read back and checked word by word rather than through a film."""
+    import test_wide_bvh_cpu as W
+    rs = np.random.RandomState(11)
+
+    def check(sc, what, rays=40):
+        nodes, _ = sc.bvh()
+        w = sc.wide()
+        assert len(w) == sc.info()["wide_bytes"] // 16 and len(w) > W.FIRST_BLOCK
+        lo, hi = nodes[0]["pmin"], nodes[0]["pmax"]
+        nonempty = 0
+        for i in range(rays):
+            o = (lo + (hi - lo) * rs.uniform(0.05, 0.95, 3)).astype(np.float32)
+            d = rs.normal(size=3).astype(np.float32)
+            inv = (np.float32(1.0) / d).astype(np.float32)
+            neg = [int(inv[k] < 0) for k in range(3)]
+            tmax = np.float32(np.inf) if i % 3 == 0 else np.float32(rs.uniform(1.0, 60.0))
+            a = W.binary_leaves(nodes, o, inv, neg, np.float32(0.001), tmax)
+            assert W.wide_leaves(w, o, inv, neg, np.float32(0.001), tmax) == a, f"{what}: ray {i}"
+            assert W.wide_leaves_peeled(w, o, inv, neg, np.float32(0.001), tmax) == a, f"{what}: ray {i} (root peel)"
+            nonempty += bool(a)
+        assert nonempty > rays // 3, what
+
+    data = gpu.scenes.atrium(target_tris=3000)
+    sc = gpu.Scene(data); sc.buildBVH()
+    check(sc, "host-built, as uploaded")
+    sc.rebuildBVHOnDevice(1)
+    assert sc.info()["device_built"]
+    check(sc, "device-built")
+    for mi, m in _edit(gpu, data, 3).items():
+        sc.setTransform(mi, m)
+    sc.rebuildBVHOnDevice(1)
+    check(sc, "edited + device-built")
+    for mi, m in _edit(gpu, data, 5).items():
+        sc.setTransform(mi, m)
+    sc.refit()
+    assert sc.info()["refitted"]
+    check(sc, "refitted")
+    sc.destroy()
