@@ -271,7 +271,8 @@ def _film_array(shape, dtype):
     registration's feet.  A private mapping is page-aligned, shares nothing and stays mapped until the array is gone."""
     import mmap
     n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-    return np.frombuffer(mmap.mmap(-1, max(n, 1)), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    m = mmap.mmap(-1, max(n, 1), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)      # (private: the default is a SHARED mapping, i.e. shmem)
+    return np.frombuffer(m, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 class StaticCamera:
