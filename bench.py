@@ -9,6 +9,7 @@ sums the disjoint shards onto rank 0 (strong scaling: the frame is fixed).
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: bench.py starts that torch.distributed.run itself, as a child process)
 
 Prints ONE JSON line on rank 0.  ray = one Scene::closestHit or Scene::anyHit call (SURVEY 8d).
 
@@ -390,6 +391,20 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
     return out
 
 
+def self_launch(n):
+    """start `n` ranks of this script under torch.distributed.run on 127.0.0.1 (a free port) and wait for them"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")                # (what torchrun would set, without its warning on stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -404,6 +419,12 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's peer-to-peer needs on this driver
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference needs no launcher either --
+        # StaticCamera::render just spawns its workers, camera.cpp:81).  This parent has imported neither torch nor the library and
+        # has not touched a GPU: the ranks are a CHILD process (torch.distributed.run), never an exec of a GPU-initialised one; its
+        # stdout (rank 0's one JSON line) and its return code are relayed.
+        raise SystemExit(self_launch(args.gpus))
     import torch
     import torch.distributed as dist
     import jtx_pathtracer_amd as jtx
@@ -412,8 +433,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (see the docstring)")
+        if world == 1 and args.gpus > 1:                    # (WORLD_SIZE=1 set by hand with --gpus N)
+            raise SystemExit("--gpus N > 1 with WORLD_SIZE=1: unset WORLD_SIZE (bench.py then starts its own ranks) or launch with torch.distributed.run")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU fallback)")

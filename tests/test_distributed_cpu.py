@@ -110,3 +110,17 @@ def test_python_and_cpp_tile_maps_agree():
         owner = ((rows // 32) * tiles_x + cols // 32) % world           # pixelToSlot's rank
         for r in range(world):
             assert np.array_equal(D.tile_owner_mask(w, h, r, world), owner == r)
+
+
+def test_bench_self_launch_relays_the_ranks_return_code():
+    """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (as a child process of a parent that has not
+    imported torch).  Without a GPU the two ranks stop with bench.py's "needs an MI355X" (there is no CPU fallback): the parent relays
+    that failure as ITS return code, and the message shows that both ranks got as far as bench.py's main()."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""                          # (were this ever run on a GPU box: still the no-device branch)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr and "launch N>1 with" not in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

