@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JTX_MI_VERSION 4
+#define JTX_MI_VERSION 5
 #define JTX_MI_CANCELLED 2   /* jtx_mi_render: stopped by the callback / jtx_mi_cancel; the film holds the completed passes */
 
 /* LinearBVHNode, src/bvh.hpp:7-15 (32 B) */
@@ -285,6 +285,22 @@ int jtx_mi_closest_hit_batch(jtx_mi_scene *scene, int32_t n, const float *o, con
 /* Scene::anyHit (scene.cpp:57-94) */
 int jtx_mi_any_hit_batch(jtx_mi_scene *scene, int32_t n, const float *o, const float *d, const float *tmin,
                          const float *tmax, int32_t *hit);
+/* The same two calls through a NAMED traversal structure (Scene::closestHit / anyHit, scene.cpp:10-94; same results by construction --
+ * which is what the parity tests check ray by ray, on the code the timed launches run):
+ *   JTX_MI_TRAVERSAL_BINARY      the reference's 32-byte nodes as threaded records (what the two calls above and the counting launches walk)
+ *   JTX_MI_TRAVERSAL_PRODUCTION  what the TIMED launch of this scene walks: the flat leaf list (<= 32 leaves), the LDS copy of the threaded
+ *                                records, the 8-ary quantised nodes (scenes that live in HBM) or the binary records (scenes without wide nodes)
+ *   JTX_MI_TRAVERSAL_SOURCE + s  source s (0 binary records in HBM / 1 their LDS copy / 2 8-ary nodes / 3 leaf list); an error if the
+ *                                scene does not carry it
+ * source_out (may be null): the source that ran (0..3 as above). */
+#define JTX_MI_TRAVERSAL_BINARY 0
+#define JTX_MI_TRAVERSAL_PRODUCTION 1
+#define JTX_MI_TRAVERSAL_SOURCE 2
+int jtx_mi_closest_hit_batch_via(jtx_mi_scene *scene, int32_t traversal, int32_t n, const float *o, const float *d, float tmin, float tmax,
+                                 int32_t *hit, float *t, int32_t *prim, float *b1, float *b2,
+                                 float *point, float *normal, float *uv, int32_t *source_out);
+int jtx_mi_any_hit_batch_via(jtx_mi_scene *scene, int32_t traversal, int32_t n, const float *o, const float *d, const float *tmin,
+                             const float *tmax, int32_t *hit, int32_t *source_out);
 /* sampleBxdf / evalBxdf / pdfBxdf (bsdf/bxdf.cpp:9,79,130) for one material over n inputs */
 int jtx_mi_bxdf_sample_batch(jtx_mi_scene *scene, int32_t material, int32_t n, const float *normal, const float *uv,
                              const float *wo, const float *uc, const float *u2,

@@ -127,6 +127,8 @@ SYMBOLS = {
     "jtx_mi_get_counters": (C.c_int, [_scene, P(Counters)]),
     "jtx_mi_closest_hit_batch": (C.c_int, [_scene, C.c_int32, _f, _f, C.c_float, C.c_float, _i, _f, _i, _f, _f, _f, _f, _f]),
     "jtx_mi_any_hit_batch": (C.c_int, [_scene, C.c_int32, _f, _f, _f, _f, _i]),
+    "jtx_mi_closest_hit_batch_via": (C.c_int, [_scene, C.c_int32, C.c_int32, _f, _f, C.c_float, C.c_float, _i, _f, _i, _f, _f, _f, _f, _f, _i]),
+    "jtx_mi_any_hit_batch_via": (C.c_int, [_scene, C.c_int32, C.c_int32, _f, _f, _f, _f, _i, _i]),
     "jtx_mi_bxdf_sample_batch": (C.c_int, [_scene, C.c_int32, C.c_int32, _f, _f, _f, _f, _f, _i, _f, _f, _f]),
     "jtx_mi_bxdf_eval_batch": (C.c_int, [_scene, C.c_int32, C.c_int32, _f, _f, _f, _f, _f]),
     "jtx_mi_bxdf_pdf_batch": (C.c_int, [_scene, C.c_int32, C.c_int32, _f, _f, _f, _f, _f]),

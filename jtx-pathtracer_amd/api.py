@@ -122,27 +122,36 @@ class Scene:
         return self.data.num_triangles
 
     # -- Scene::closestHit scene.cpp:10-55, batched
-    def closestHit(self, o, d, tmin=0.001, tmax=float("inf")):
+    TRAVERSAL_BINARY, TRAVERSAL_PRODUCTION, TRAVERSAL_SOURCE = 0, 1, 2          # jtx_mi.h: JTX_MI_TRAVERSAL_*
+    SOURCE_NAMES = {0: "binary", 1: "lds", 2: "wide", 3: "leaf"}
+
+    def closestHit(self, o, d, tmin=0.001, tmax=float("inf"), traversal=0):
+        """traversal: 0 the binary records (the reference's node visits), 1 the structure the TIMED launch of this scene walks,
+        2 + s a named source; `self.last_source` = the source that ran (SOURCE_NAMES)"""
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
         n = len(o)
         out = dict(hit=np.zeros(n, np.int32), t=np.zeros(n, np.float32), prim=np.zeros(n, np.int32),
                    b1=np.zeros(n, np.float32), b2=np.zeros(n, np.float32), point=np.zeros((n, 3), np.float32),
                    normal=np.zeros((n, 3), np.float32), uv=np.zeros((n, 2), np.float32))
-        check(self._lib.jtx_mi_closest_hit_batch(self.handle, n, _fp(o), _fp(d), tmin, tmax, _ip(out["hit"]), _fp(out["t"]),
-                                                 _ip(out["prim"]), _fp(out["b1"]), _fp(out["b2"]), _fp(out["point"]),
-                                                 _fp(out["normal"]), _fp(out["uv"])))
+        src = C.c_int32(-1)
+        check(self._lib.jtx_mi_closest_hit_batch_via(self.handle, traversal, n, _fp(o), _fp(d), tmin, tmax, _ip(out["hit"]), _fp(out["t"]),
+                                                     _ip(out["prim"]), _fp(out["b1"]), _fp(out["b2"]), _fp(out["point"]),
+                                                     _fp(out["normal"]), _fp(out["uv"]), C.byref(src)))
+        self.last_source = src.value
         return out
 
     # -- Scene::anyHit scene.cpp:57-94, batched
-    def anyHit(self, o, d, tmin, tmax):
+    def anyHit(self, o, d, tmin, tmax, traversal=0):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
         n = len(o)
         tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, np.float32), (n,)))
         tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)))
         hit = np.zeros(n, np.int32)
-        check(self._lib.jtx_mi_any_hit_batch(self.handle, n, _fp(o), _fp(d), _fp(tmin), _fp(tmax), _ip(hit)))
+        src = C.c_int32(-1)
+        check(self._lib.jtx_mi_any_hit_batch_via(self.handle, traversal, n, _fp(o), _fp(d), _fp(tmin), _fp(tmax), _ip(hit), C.byref(src)))
+        self.last_source = src.value
         return hit
 
     # -- sampleBxdf / evalBxdf / pdfBxdf bsdf/bxdf.cpp:9,79,130, batched per material

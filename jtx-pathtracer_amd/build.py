@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libjtx_mi.so")
 SOURCES = ["jtx_kernels.hip", "jtx_alt.hip", "jtx_wavefront.hip", "jtx_capi.hip", "jtx_multi.hip", "jtx_refit.hip", "jtx_build_dev.hip", "jtx_bvh_build.cpp", "jtx_jpeg.cpp", "jtx_exr.cpp", "jtx_png.cpp"]
-HEADERS = ["jtx_device_math.hpp", "jtx_bxdf.hpp", "jtx_scene_dev.hpp", "jtx_launch.hpp", "jtx_host.hpp", "jtx_tiles.hpp", "jtx_wide_quant.hpp", "jtx_inflate.hpp",
+HEADERS = ["jtx_device_math.hpp", "jtx_bxdf.hpp", "jtx_scene_dev.hpp", "jtx_launch.hpp", "jtx_host.hpp", "jtx_tiles.hpp", "jtx_wide_quant.hpp", "jtx_inflate.hpp", "jtx_profile.hpp", "jtx_profile_readers.hpp",
            os.path.join("..", "..", "include", "jtx_mi.h")]
 # -ffp-contract=off: device results must equal the strict-fp32 CPU oracle bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
@@ -32,14 +32,45 @@ def lib_is_built():
     return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
 
 
+def _compile_one(args):
+    cc, src, obj, flags = args
+    cmd = [cc] + flags + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    return src, cmd, r.returncode, r.stdout + r.stderr
+
+
 def build_all(force=False, verbose=False):
-    """Compile every HIP source into jtx-pathtracer_amd/libjtx_mi.so.  Returns the library path."""
+    """Compile every HIP source into jtx-pathtracer_amd/libjtx_mi.so.  Returns the library path.
+    One object per source under jtx-pathtracer_amd/build/ (compiled in parallel, re-used while neither the source, a header nor
+    the flags changed), then one link; JTX_BUILD_JOBS sets the number of compilers at a time."""
     if not force and lib_is_built():
         return LIB
-    cmd = [_hipcc()] + FLAGS + os.environ.get("JTX_EXTRA_HIPCC_FLAGS", "").split() + ["-o", LIB] + SOURCES
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    cc = _hipcc()
+    cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("JTX_EXTRA_HIPCC_FLAGS", "").split()
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    tag = hashlib.sha1(" ".join(cflags).encode()).hexdigest()[:10]
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, f"{os.path.splitext(src)[0]}.{tag}.o")
+        objs.append(obj)
+        fresh = os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_t, os.path.getmtime(os.path.join(CSRC, src)))
+        if force or not fresh:
+            jobs.append((cc, src, obj, cflags))
+    nj = int(os.environ.get("JTX_BUILD_JOBS", "0")) or min(6, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=max(1, nj)) as ex:
+        for src, cmd, rc, out in ex.map(_compile_one, jobs):
+            if verbose:
+                print(" ".join(cmd))
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n" + out)
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc (link) failed:\n" + r.stdout + r.stderr)
     return LIB

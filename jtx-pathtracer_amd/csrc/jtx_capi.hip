@@ -181,7 +181,6 @@ struct jtx_mi_scene {
         ~RebuildSpare() { if (arena.base) (void) hipFree(arena.base); }
     } spare;
     DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
-    DevBuf<float4> slip_park;        // k_render_paths, JTX_SLIP_K > 0: extension rays parked across bounces
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (kWorkRing, used round-robin)
     unsigned work_slot = 0;
     unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
@@ -888,18 +887,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
     p.acc = d_acc; p.img = d_img;
     p.stop = s.stop_dev;
-    p.slip = nullptr;
-    if (jtx_render_paths_slip_k() > 0 && s.dev.wide && !s.dev.lds_threaded) {        // parked extension rays: 2 float4 per lane of the persistent grid
-        int bs = 0; const size_t lanes = (size_t) jtx_render_paths_grid(s.dev, s.num_cus, &bs) * (size_t) bs;
-        if (s.slip_park.n < 2 * lanes) s.slip_park.alloc(2 * lanes);
-        p.slip = s.slip_park.p;
-    }
     const bool count = o.count_rays != 0;
     if (count) {
         if (!s.counters.p) s.counters.alloc(64);
         HIPCHK(hipMemsetAsync(s.counters.p, 0, 64 * sizeof(unsigned long long), stream));
     }
-#ifdef JTX_PROFILE_TIMELINE
+#ifdef JTX_PROFILE_TIMELINE     /* diagnostic build (jtx_profile.hpp): room for a (start, end) pair per wave */
     if (s.counters.n < 64 + 2 * 65536) { s.counters.alloc(64 + 2 * 65536); HIPCHK(hipMemsetAsync(s.counters.p, 0, (64 + 2 * 65536) * sizeof(unsigned long long), stream)); }
 #endif
     p.counters = s.counters.p;
@@ -1459,68 +1452,7 @@ int jtx_mi_kernel_time(jtx_mi_scene *s, float *ms_total, int32_t *launches) {
     } catch (const std::exception &e) { return fail(e.what()); }
 }
 
-#ifdef JTX_PROFILE_UTIL
-int jtx_mi_debug_util(jtx_mi_scene *s, unsigned long long *out3) {     // diagnostic builds only
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out3, s->counters.p + 20, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-int jtx_mi_debug_util_hist(jtx_mi_scene *s, unsigned long long *out7) {
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out7, s->counters.p + 24, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
-#if defined(JTX_PROFILE_UTIL) && !defined(JTX_PROFILE_WIDE)
-int jtx_mi_debug_wide_idle(jtx_mi_scene *s, unsigned long long *out4) {   // interior iterations parked / done, leaf phases walking / done
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out4, s->counters.p + 48, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
-#ifdef JTX_PROFILE_WIDE
-int jtx_mi_debug_wide(jtx_mi_scene *s, unsigned long long *out8) {     // diagnostic builds only
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out8, s->counters.p + 24, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-int jtx_mi_debug_wide_idle(jtx_mi_scene *s, unsigned long long *out4) {   // node iterations parked / done, leaf iterations walking / done
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out4, s->counters.p + 48, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-int jtx_mi_debug_wide_hist(jtx_mi_scene *s, unsigned long long *out7) {
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out7, s->counters.p + 9, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
-#ifdef JTX_PROFILE_FUSE
-int jtx_mi_debug_fuse(jtx_mi_scene *s, unsigned long long *out3) {   // diagnostic builds only: sum of max(c) + max(a), sum of max(a_prev + c), bounces
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out3, s->counters.p + 56, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
-#ifdef JTX_PROFILE_TIMELINE
-int jtx_mi_debug_timeline(jtx_mi_scene *s, unsigned long long *out, int n) {   // diagnostic builds only: (start, end) wall clocks per wave
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out, s->counters.p + 64, (size_t) 2 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
-#ifdef JTX_PROFILE_PHASES
-int jtx_mi_debug_phases_reset(jtx_mi_scene *s) {       // diagnostic builds only
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemset(s->counters.p + 16, 0, 7 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-int jtx_mi_debug_phases(jtx_mi_scene *s, unsigned long long *out6) {   // diagnostic builds only
-    if (!s || !s->counters.p) return 1;
-    (void) hipDeviceSynchronize();
-    return hipMemcpy(out6, s->counters.p + 16, 7 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;   // [6]: hand-out (timed kernel only)
-}
-#endif
+#include "jtx_profile_readers.hpp"     // jtx_mi_debug_*: diagnostic builds only, nothing in the product
 
 int jtx_mi_kernel_time_by_kind(jtx_mi_scene *s, float *ms5, int32_t *n5) {
     if (!s || !ms5 || !n5) return fail("null argument");
@@ -1730,35 +1662,61 @@ template <class T> struct Tmp {
 
 extern "C" {
 
-int jtx_mi_closest_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const float *d, float tmin, float tmax,
-                             int32_t *hit, float *t, int32_t *prim, float *b1, float *b2, float *point, float *normal,
-                             float *uv) {
+// traversal: JTX_MI_TRAVERSAL_BINARY (0) the binary threaded records -- the reference's node visits, what the counted kernels walk;
+// JTX_MI_TRAVERSAL_PRODUCTION (1) the structure the TIMED launch of this scene walks (flat leaf list / LDS copy / 8-ary nodes / binary
+// records, by the rule of jtx_launch_render_paths); 2 + SRC: that source if the scene carries it, an error otherwise (tests)
+static int batchSource(const jtx_mi_scene &s, int traversal) {
+    if (traversal == 0) return SRC_GLOBAL;
+    if (traversal == 1) return jtx_production_source(s.dev);
+    const int src = traversal - 2;
+    const bool ok = src == SRC_GLOBAL || (src == SRC_LDS && s.dev.lds_threaded) || (src == SRC_LEAF && s.dev.lds_threaded && s.dev.lw_leaves > 0) ||
+                    (src == SRC_WIDE && !s.dev.lds_threaded && s.dev.wide);
+    if (!ok) throw std::runtime_error("traversal " + std::to_string(traversal) + ": this scene does not carry that structure");
+    return src;
+}
+
+int jtx_mi_closest_hit_batch_via(jtx_mi_scene *s, int32_t traversal, int32_t n, const float *o, const float *d, float tmin, float tmax,
+                                 int32_t *hit, float *t, int32_t *prim, float *b1, float *b2, float *point, float *normal,
+                                 float *uv, int32_t *source_out) {
     try {
         if (!s || n < 0 || (n && (!o || !d))) throw std::runtime_error("bad argument");
         DeviceGuard dg(s->device);
+        const int src = batchSource(*s, traversal);
+        if (source_out) *source_out = src;
         if (n == 0) return 0;
         Tmp<float> dO(o, 3 * (size_t) n), dD(d, 3 * (size_t) n), dT(n), dB1(n), dB2(n), dP(3 * (size_t) n), dN(3 * (size_t) n), dUV(2 * (size_t) n);
         Tmp<int> dHit(n), dPrim(n);
-        HIPCHK(jtx_launch_closest_batch(s->dev, n, dO.p, dD.p, tmin, tmax, dHit.p, dT.p, dPrim.p, dB1.p, dB2.p, dP.p, dN.p, dUV.p, s->stream));
+        HIPCHK(jtx_launch_closest_batch(s->dev, src, n, dO.p, dD.p, tmin, tmax, dHit.p, dT.p, dPrim.p, dB1.p, dB2.p, dP.p, dN.p, dUV.p, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         dHit.down(hit); dT.down(t); dPrim.down(prim); dB1.down(b1); dB2.down(b2); dP.down(point); dN.down(normal); dUV.down(uv);
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
 }
+int jtx_mi_closest_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const float *d, float tmin, float tmax,
+                             int32_t *hit, float *t, int32_t *prim, float *b1, float *b2, float *point, float *normal,
+                             float *uv) {
+    return jtx_mi_closest_hit_batch_via(s, 0, n, o, d, tmin, tmax, hit, t, prim, b1, b2, point, normal, uv, nullptr);
+}
 
-int jtx_mi_any_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const float *d, const float *tmin, const float *tmax,
-                         int32_t *hit) {
+int jtx_mi_any_hit_batch_via(jtx_mi_scene *s, int32_t traversal, int32_t n, const float *o, const float *d, const float *tmin, const float *tmax,
+                             int32_t *hit, int32_t *source_out) {
     try {
         if (!s || n < 0 || (n && (!o || !d || !tmin || !tmax || !hit))) throw std::runtime_error("bad argument");
         DeviceGuard dg(s->device);
+        const int src = batchSource(*s, traversal);
+        if (source_out) *source_out = src;
         if (n == 0) return 0;
         Tmp<float> dO(o, 3 * (size_t) n), dD(d, 3 * (size_t) n), dA(tmin, n), dB(tmax, n);
         Tmp<int> dHit(n);
-        HIPCHK(jtx_launch_any_batch(s->dev, n, dO.p, dD.p, dA.p, dB.p, dHit.p, s->stream));
+        HIPCHK(jtx_launch_any_batch(s->dev, src, n, dO.p, dD.p, dA.p, dB.p, dHit.p, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         dHit.down(hit);
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
+}
+int jtx_mi_any_hit_batch(jtx_mi_scene *s, int32_t n, const float *o, const float *d, const float *tmin, const float *tmax,
+                         int32_t *hit) {
+    return jtx_mi_any_hit_batch_via(s, 0, n, o, d, tmin, tmax, hit, nullptr);
 }
 
 static int bxdfBatch(jtx_mi_scene *s, int mode, int32_t material, int32_t n, const float *normal, const float *uv, const float *wo,

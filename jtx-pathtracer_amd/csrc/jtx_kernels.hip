@@ -31,10 +31,6 @@ namespace jtx {
 #ifndef JTX_WIDE_OCC
 #define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
 #endif
-#ifndef JTX_LANE_COLUMN
-#define JTX_LANE_COLUMN 0       // 1: k_render_paths over the 8-ary nodes recomputes the LDS stack column from the lane id instead of keeping a pointer live
-                                // (what the slip kernel needs to stay free of scratch reloads inside its node loop; by itself C3 +1.1 %)
-#endif
 #ifndef JTX_NUM_SGPR
 #define JTX_NUM_SGPR 0          // > 0: amdgpu_num_sgpr on k_render_paths (the compiler budgets 80 SGPRs by itself and spills 60-80 into VGPR lanes)
 #endif
@@ -75,70 +71,16 @@ struct PathState {
     f3 o, d, beta, radiance;
     Rng rng;
     int depth;
-#ifdef JTX_PROFILE_FUSE
-    unsigned fuse_c, fuse_a, fuse_aprev;   // diagnostic: steps of this bounce's extension / shadow ray, of the previous bounce's shadow ray
-#endif
-#if JTX_SLIP_K > 0
-    bool slip;                   // its extension ray is under way across bounces, state parked in memory (k_render_paths over the 8-ary nodes)
-#endif
-#ifdef JTX_PROFILE_PHASES
-    long long ph[6];
-#endif
+    JTX_PROF_PATH_FIELDS         // diagnostic builds only (jtx_profile.hpp)
 };
 
-#ifdef JTX_PROFILE_PHASES
-#define PH_DECL long long ph_t = clock64();
-#define PH(i) { long long n_ = clock64(); ps.ph[i] += n_ - ph_t; ph_t = n_; }
-#else
-#define PH_DECL
-#define PH(i)
-#endif
-
-#ifdef JTX_PROFILE_WIDE
-// diagnostic build: lane sums of the steps, wave maxima of the iterations (tools/tools_wide_stats.py)
-JD void exportWideStats(const RenderParams &p, const Counters9 &cnt) {
-    if (!p.counters) return;
-    const unsigned v[12] = {cnt.w_calls, cnt.w_node_iters, cnt.w_node_steps, cnt.w_leaf_iters, cnt.w_leaf_steps, cnt.w_tris, cnt.w_pops, cnt.w_fetch,
-                            cnt.w_np, cnt.w_nd, cnt.w_lw, cnt.w_ld};
-    for (int i = 0; i < 12; ++i) {
-        const bool perWave = (i == 0 || i == 1 || i == 3);
-        unsigned long long sv = v[i];
-        if (perWave) { for (int off = 32; off > 0; off >>= 1) { unsigned long long o2 = __shfl_down(sv, off, 64); sv = sv > o2 ? sv : o2; } }
-        else for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
-        if ((threadIdx.x & 63) == 0 && sv) atomicAdd(&p.counters[i < 8 ? 24 + i : 40 + i], sv);
-    }
-    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[9 + i], (unsigned long long) cnt.w_hist[i]);
-}
-#endif
-
-// -> BOUNCE_NEXT: the path goes on with its next extension ray; BOUNCE_DONE: finished (radiance final); BOUNCE_PENDING (slip
-// builds only, -DJTX_SLIP_K=n): its extension ray is still under way -- call again
-#if JTX_SLIP_K > 0
-typedef int BounceResult;
-enum { BOUNCE_NEXT = 0, BOUNCE_DONE = 1, BOUNCE_PENDING = 2 };
-#else
-typedef bool BounceResult;
+// -> false: the path goes on with its next extension ray; true: finished (radiance final)
 constexpr bool BOUNCE_NEXT = false, BOUNCE_DONE = true;
-#endif
-template <bool COUNT, int MASK, class Src, bool SLIP = false>
-JD BounceResult pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &ps, Counters9 &cnt, float4 *slipBase = nullptr) {
+template <bool COUNT, int MASK, class Src>
+JD bool pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &ps, Counters9 &cnt) {
     HitRec h;
     PH_DECL
-#if JTX_SLIP_K > 0
-    bool hit;
-    if constexpr (SLIP) {
-        if (traverseWideSlip(src, sc.num_nodes, ps.o, ps.d, 0.001f, slipBase, ps.slip, h, hit, cnt)) { PH(0) return BOUNCE_PENDING; }
-    } else hit = traverseNoStack<false, COUNT>(src, sc.num_nodes, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
-#else
-    (void) slipBase;
-#ifdef JTX_PROFILE_FUSE
-    const unsigned fuse0 = cnt.w_node_steps + cnt.w_leaf_steps;
-#endif
     const bool hit = traverseNoStack<false, COUNT>(src, sc.num_nodes, ps.o, ps.d, 0.001f, __builtin_inff(), h, cnt);
-#ifdef JTX_PROFILE_FUSE
-    ps.fuse_c = cnt.w_node_steps + cnt.w_leaf_steps - fuse0;
-#endif
-#endif
     PH(0)
     if (!hit) {                                                       // integrator.cpp:183-187
         ps.radiance = ps.radiance + ps.beta * a3(sc.sky);
@@ -159,13 +101,7 @@ JD BounceResult pathBounce(const DevScene &sc, const Src &src, int maxDepth, Pat
             const float lDist = len(sf.point - ls.p);
             HitRec dummy;
             PH(1)
-#ifdef JTX_PROFILE_FUSE
-            const unsigned fuse1 = cnt.w_node_steps + cnt.w_leaf_steps;
-#endif
             const bool occluded = traverseNoStack<true, COUNT>(src, sc.num_nodes, sOrigin, ls.wi, 0.0f, lDist - RAY_EPSILON, dummy, cnt);
-#ifdef JTX_PROFILE_FUSE
-            ps.fuse_a = cnt.w_node_steps + cnt.w_leaf_steps - fuse1;
-#endif
             PH(2)
             if (!occluded) {
                 f3 f; float pb;
@@ -198,9 +134,6 @@ JD void startPath(const DCam &cam, uint32_t row, uint32_t col, uint32_t s, PathS
     ps.rng.seed(row, col, s + 1u);                                     // camera.cpp:101
     cameraRay(cam, col, row, s, ps.rng, ps.o, ps.d);
     ps.beta = mk3(1.0f); ps.radiance = mk3(0.0f); ps.depth = 0;
-#if JTX_SLIP_K > 0
-    ps.slip = false;
-#endif
 }
 
 JD unsigned char toByte(float v) {                                     // image.hpp:9-16,47-52
@@ -228,9 +161,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
     const int owned = bid / BLOCKS_PER_TILE;                           // index into this rank's tiles
     const int tile = p.tile_rank + owned * p.tile_world;               // global 32x32 tile id, row-major (camera.cpp:55-64)
     const int sub = (bid % BLOCKS_PER_TILE) * WAVES_PER_BLOCK + wave;  // 0..15 sub-block inside the tile
-#ifdef JTX_PROFILE_TIMELINE
-    const long long tl0 = wall_clock64();
-#endif
+    JTX_PROF_TIMELINE_BEGIN
     const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
     const int row = trow * 32 + (sub >> 2) * 8 + (lane >> 3);
     const int col = tcol * 32 + (sub & 3) * 8 + (lane & 7);
@@ -246,10 +177,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         if (!SPLIT && p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
         int s = sBegin;
         PathState ps;
-#ifdef JTX_PROFILE_PHASES
-        for (int i = 0; i < 6; ++i) ps.ph[i] = 0;
-        long long k0 = clock64();
-#endif
+        JTX_PROF_PHASES_BEGIN(ps)
         bool alive = s < sEnd;
         if (alive) { startPath(p.cam, row, col, s, ps); if (COUNT) cnt.n_camera++; }
         while (alive) {
@@ -273,12 +201,7 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
                 else alive = false;
             }
         }
-#ifdef JTX_PROFILE_PHASES
-        if (p.counters && lane == 0) {     // diagnostic build: per-phase wave cycles of lane 0's view
-            for (int i = 0; i < 5; ++i) atomicAdd(&p.counters[16 + i], (unsigned long long) ps.ph[i]);
-            atomicAdd(&p.counters[16 + 5], (unsigned long long) (clock64() - k0));
-        }
-#endif
+        JTX_PROF_PHASES_END(p, ps, lane, false)
         if (!SPLIT) {
         p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
         if (p.img) {
@@ -290,28 +213,14 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
         }
     }
 #ifdef JTX_PROFILE_TIMELINE
-    if (!COUNT && p.counters && lane == 0 && p.sample_end - p.sample_begin > 1) {      // diagnostic: wave life span, indexed by pixel block
+    if (!COUNT && p.counters && lane == 0 && p.sample_end - p.sample_begin > 1) {      // wave life span, indexed by pixel block
         const int wid = ((int) blockIdx.y * (int) gridDim.x + bid) * WAVES_PER_BLOCK + wave;
-        if (wid < 65536) { p.counters[64 + 2 * wid] = (unsigned long long) tl0; p.counters[64 + 2 * wid + 1] = (unsigned long long) wall_clock64(); }
+        JTX_PROF_TIMELINE_WAVE(p, wid)
     }
 #endif
     if (COUNT) waveAddCounters(p.counters, cnt);
-#ifdef JTX_PROFILE_WIDE
-    if (SRC == SRC_WIDE) exportWideStats(p, cnt);
-#endif
-#ifdef JTX_PROFILE_UTIL
-    if (COUNT) {
-        // every lane of a wave sits through the same traversal-loop iterations, but lanes that left the
-        // pixel loop early stop counting: take the wave maximum
-        unsigned a = cnt.it_interior, b = cnt.it_leaf, c = cnt.it_calls;
-        for (int off = 32; off > 0; off >>= 1) { a = max(a, __shfl_down(a, off, 64)); b = max(b, __shfl_down(b, off, 64)); c = max(c, __shfl_down(c, off, 64)); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&p.counters[20], (unsigned long long) a); atomicAdd(&p.counters[21], (unsigned long long) b); atomicAdd(&p.counters[22], (unsigned long long) c);
-                                       for (int i = 0; i < 7; ++i) atomicAdd(&p.counters[24 + i], (unsigned long long) cnt.it_hist[i]); }
-        unsigned long long id[4] = {cnt.it_np, cnt.it_nd, cnt.it_lw, cnt.it_ld};
-        for (int i = 0; i < 4; ++i) { for (int off = 32; off > 0; off >>= 1) id[i] += __shfl_down(id[i], off, 64);
-                                      if ((threadIdx.x & 63) == 0) atomicAdd(&p.counters[48 + i], id[i]); }
-    }
-#endif
+    if (SRC == SRC_WIDE) { JTX_PROF_WIDE_EXPORT(p, cnt) }
+    if (COUNT) { JTX_PROF_UTIL_EXPORT(p, cnt) }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -353,23 +262,11 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int nchunks = p.num_subblocks * p.num_groups;
-#ifdef JTX_PROFILE_TIMELINE
-    const long long tl0 = wall_clock64();
-    unsigned tl_iters = 0, tl_active = 0;
-#endif
+    JTX_PROF_TIMELINE_BEGIN
 
     Counters9 cnt = {};
     PathState ps;
-#if JTX_SLIP_K > 0
-    ps.slip = false;
-#endif
-#ifdef JTX_PROFILE_PHASES
-    for (int i = 0; i < 6; ++i) ps.ph[i] = 0;
-    const long long k0 = clock64();
-#endif
-#ifdef JTX_PROFILE_FUSE
-    unsigned long long fuseSep = 0, fuseSum = 0, fuseCalls = 0; ps.fuse_c = ps.fuse_a = ps.fuse_aprev = 0;
-#endif
+    JTX_PROF_PHASES_BEGIN(ps)
     // the wave's current chunk (all wave-uniform)
     int next = 0, nunits = 0;                      // paths handed out / in the chunk
     int row0 = 0, col0 = 0, slot0 = 0, sBegin = 0;
@@ -377,9 +274,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     int s = 0, slot = 0;                           // this lane's current path: stratum, pixel slot in the rank's frame
     bool alive = false, need = true;
     while (true) {
-#ifdef JTX_PROFILE_PHASES
-        const long long h0 = clock64();
-#endif
+        JTX_PROF_HANDOUT_BEGIN
         // ---- hand out paths to the lanes that need one ----
         while (true) {
             const unsigned long long mask = __ballot(need);
@@ -426,16 +321,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             }
         }
         need = false;
-#ifdef JTX_PROFILE_PHASES
-        ps.ph[5] += clock64() - h0;                                      // the hand-out (chunk fetches, camera rays)
-#endif
+        JTX_PROF_HANDOUT_END(ps)
         if (__ballot(alive) == 0ull) break;
-#ifdef JTX_PROFILE_TIMELINE
-        tl_iters++; tl_active += alive ? 1 : 0;
-#endif
-#ifdef JTX_PROFILE_FUSE
-        ps.fuse_c = 0; ps.fuse_a = 0;
-#endif
+        JTX_PROF_TIMELINE_ITER(alive)
         // ---- one bounce of every live path ----
         if (alive) {
             bool done;
@@ -444,13 +332,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
                                   src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
-            else if constexpr (SRC == SRC_WIDE) {
-                                  // single-wave workgroups: the stack column is found from the lane id at every push / pop (JTX_LANE_COLUMN)
-                                  constexpr bool LC = BS == 64 && JTX_LANE_COLUMN;
-                                  WideSrcT<LC> src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
-                                  src.stk = (uint2 *) smem + (LC ? 0 : threadIdx.x); src.stride = BS;
-                                  // (a pending extension ray -- JTX_SLIP_K > 0 -- is neither done nor in need of a path: the lane calls again)
-                                  done = pathBounce<false, MASK, WideSrcT<LC>, (JTX_SLIP_K > 0)>(sc, src, p.max_depth, ps, cnt, JTX_SLIP_K > 0 ? p.slip : nullptr) == BOUNCE_DONE; }
+            else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                                  src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS;
+                                  done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             if (done) {
@@ -470,74 +354,80 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                 alive = false; need = true;
             }
         }
-#ifdef JTX_PROFILE_FUSE
-        {   // wave maxima (all lanes take part): separate calls cost max(c) + max(a); one fused call per bounce would cost max(a_prev + c)
-            unsigned mc = ps.fuse_c, ma = ps.fuse_a, mf = ps.fuse_c + ps.fuse_aprev;
-            for (int off = 32; off > 0; off >>= 1) { mc = max(mc, __shfl_xor(mc, off, 64)); ma = max(ma, __shfl_xor(ma, off, 64)); mf = max(mf, __shfl_xor(mf, off, 64)); }
-            fuseSep += mc + ma; fuseSum += mf; fuseCalls += 1;
-            ps.fuse_aprev = alive ? ps.fuse_a : 0u;          // (a finished path's last shadow ray is charged to nobody: a slight favour to the fused figure)
-        }
-#endif
     }
-#ifdef JTX_PROFILE_WIDE
-    if (SRC == SRC_WIDE) exportWideStats(p, cnt);
-#endif
-#ifdef JTX_PROFILE_FUSE
-    if (p.counters && lane == 0) { atomicAdd(&p.counters[56], fuseSep); atomicAdd(&p.counters[57], fuseSum); atomicAdd(&p.counters[58], fuseCalls); }
-#endif
-#ifdef JTX_PROFILE_PHASES
-    if (p.counters && lane == 0) {         // diagnostic build: per-phase wave clocks as lane 0 sees them (tools/tools_phases.py --timed)
-        for (int i = 0; i < 5; ++i) atomicAdd(&p.counters[16 + i], (unsigned long long) ps.ph[i]);
-        atomicAdd(&p.counters[16 + 5], (unsigned long long) (clock64() - k0));
-        atomicAdd(&p.counters[16 + 6], (unsigned long long) ps.ph[5]);
-    }
-#endif
-#ifdef JTX_PROFILE_TIMELINE
-    if (p.counters) {
-        unsigned long long a = tl_active;
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-        if (lane == 0) {
-            const int wid = (int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6);
-            if (wid < 65536) { p.counters[64 + 2 * wid] = (unsigned long long) tl0; p.counters[64 + 2 * wid + 1] = (unsigned long long) wall_clock64(); }
-            atomicAdd(&p.counters[40], (unsigned long long) tl_iters); atomicAdd(&p.counters[41], a);
-        }
-    }
-#endif
+    if (SRC == SRC_WIDE) { JTX_PROF_WIDE_EXPORT(p, cnt) }
+    JTX_PROF_PHASES_END(p, ps, lane, true)
+    JTX_PROF_TIMELINE_END(p, lane, (int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6))
 }
 
 // ------------------------------------------------------------------------------------------------
 // parity-test kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_closest_batch(DevScene sc, int n, const float *o, const float *d, float tmin,
-                                                         float tmax, int *hit, float *t, int *prim, float *b1, float *b2,
-                                                         float *point, float *normal, float *uv) {
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Counters9 cnt = {};
-    HitRec h; h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f;
-    GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
-    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    const bool r = traverseNoStack<false, false>(src, sc.num_nodes, ro, rd, tmin, tmax, h, cnt);
-    hit[i] = r ? 1 : 0;
-    Surface sf; sf.point = sf.normal = mk3(0.0f); sf.uv = mk2(0.0f, 0.0f);
-    if (r) sf = makeSurface(sc.shade, h, ro, rd); else { h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f; }
-    t[i] = h.t; prim[i] = h.prim; b1[i] = h.b1; b2[i] = h.b2;
-    point[3 * i] = sf.point.x; point[3 * i + 1] = sf.point.y; point[3 * i + 2] = sf.point.z;
-    normal[3 * i] = sf.normal.x; normal[3 * i + 1] = sf.normal.y; normal[3 * i + 2] = sf.normal.z;
-    uv[2 * i] = sf.uv.x; uv[2 * i + 1] = sf.uv.y;
+// Per-ray entry points, instantiated for every BVH source the render kernels walk (jtx_mi_closest_hit_batch_via / any_hit_batch_via):
+// SRC_GLOBAL the binary threaded records in HBM (what the counted kernels walk), SRC_LDS the same staged in LDS, SRC_LEAF the flat leaf
+// list (traverseLeaves: scalar-operand boxes, candidates from the LDS copy), SRC_WIDE the 8-ary quantised nodes with the per-lane LDS
+// stack (traverseWide) -- the SAME Src objects, built the same way, as k_render_paths builds them, so a ray through these kernels runs
+// the code a path's ray runs in the timed launch (incl. the wave-wide vote that sends a wave with an irregular ray to the binary records).
+template <int SRC, int BS, class F>
+JD void withBatchSrc(const DevScene &sc, int *smem, F &&body) {
+    static_assert((SRC != SRC_LDS && SRC != SRC_LEAF) || BS == BLOCK, "stageScene strides by BLOCK");
+    constexpr bool LDS_SCENE = SRC == SRC_LDS || SRC == SRC_LEAF;
+    float4 *lds_tnodes = (float4 *) smem;
+    float4 *lds_tris = lds_tnodes + 2 * 8 * sc.num_nodes;
+    float4 *lds_lbox = lds_tris + 3 * sc.num_prims;                     // SRC_LEAF: [leaf list][order / position tables]
+    const int lwPad = (sc.lw_leaves + 3) & ~3;
+    unsigned *lds_tab = (unsigned *) (lds_lbox + 2 * lwPad);
+    if (SRC == SRC_LEAF) {
+#if JTX_LDS_PLANES
+        for (int i = threadIdx.x; i < 2 * lwPad; i += BS) lds_lbox[(i & 1) * lwPad + (i >> 1)] = sc.lw_box[i];   // halves apart
+#else
+        for (int i = threadIdx.x; i < 2 * lwPad; i += BS) lds_lbox[i] = sc.lw_box[i];
+#endif
+        for (int i = threadIdx.x; i < 128; i += BS) lds_tab[i] = sc.lw_tab[i];
+    }
+    if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);                // (every thread of the workgroup: before any lane leaves)
+    if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes; src.np = sc.num_prims; body(src); }
+    else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
+                          src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad; body(src); }
+    else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
+                          src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS; body(src); }
+    else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris; body(src); }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_any_batch(DevScene sc, int n, const float *o, const float *d, const float *tmin,
-                                                     const float *tmax, int *hit) {
+template <int SRC, int BS>
+__global__ void __launch_bounds__(BS) k_closest_batch(DevScene sc, int n, const float *o, const float *d, float tmin,
+                                                      float tmax, int *hit, float *t, int *prim, float *b1, float *b2,
+                                                      float *point, float *normal, float *uv) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    Counters9 cnt = {};
-    HitRec h;
-    GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
-    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    hit[i] = traverseNoStack<true, false>(src, sc.num_nodes, ro, rd, tmin[i], tmax[i], h, cnt) ? 1 : 0;
+    withBatchSrc<SRC, BS>(sc, smem, [&](const auto &src) {
+        const int i = blockIdx.x * BS + threadIdx.x;
+        if (i >= n) return;
+        Counters9 cnt = {};
+        HitRec h; h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f;
+        const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        const bool r = traverseNoStack<false, false>(src, sc.num_nodes, ro, rd, tmin, tmax, h, cnt);
+        hit[i] = r ? 1 : 0;
+        Surface sf; sf.point = sf.normal = mk3(0.0f); sf.uv = mk2(0.0f, 0.0f);
+        if (r) sf = makeSurface(sc.shade, h, ro, rd); else { h.t = 0.0f; h.prim = -1; h.b1 = h.b2 = 0.0f; }
+        t[i] = h.t; prim[i] = h.prim; b1[i] = h.b1; b2[i] = h.b2;
+        point[3 * i] = sf.point.x; point[3 * i + 1] = sf.point.y; point[3 * i + 2] = sf.point.z;
+        normal[3 * i] = sf.normal.x; normal[3 * i + 1] = sf.normal.y; normal[3 * i + 2] = sf.normal.z;
+        uv[2 * i] = sf.uv.x; uv[2 * i + 1] = sf.uv.y;
+    });
+}
+
+template <int SRC, int BS>
+__global__ void __launch_bounds__(BS) k_any_batch(DevScene sc, int n, const float *o, const float *d, const float *tmin,
+                                                  const float *tmax, int *hit) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    withBatchSrc<SRC, BS>(sc, smem, [&](const auto &src) {
+        const int i = blockIdx.x * BS + threadIdx.x;
+        if (i >= n) return;
+        Counters9 cnt = {};
+        HitRec h;
+        const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        hit[i] = traverseNoStack<true, false>(src, sc.num_nodes, ro, rd, tmin[i], tmax[i], h, cnt) ? 1 : 0;
+    });
 }
 
 __global__ void __launch_bounds__(BLOCK) k_bxdf_batch(DevScene sc, int mode, int material, int n, const float *normal,
@@ -674,8 +564,6 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
 }
 } // namespace jtx
 
-int jtx_render_paths_slip_k() { return JTX_SLIP_K; }     // > 0: RenderParams::slip must hold 2 float4 per lane of the persistent grid
-
 int jtx_render_paths_grid(const DevScene &sc, int num_cus, int *block_size) {
     const bool lds = sc.lds_threaded != 0, wide = !lds && sc.wide != nullptr;
     const int bs = lds ? BLOCK : 64;
@@ -716,18 +604,44 @@ hipError_t jtx_launch_resolve_samples(const RenderParams &p, int num_owned_tiles
 
 static inline unsigned blocksFor(int n) { return (unsigned) ((n + BLOCK - 1) / BLOCK); }
 
-hipError_t jtx_launch_closest_batch(const DevScene &sc, int n, const float *o, const float *d, float tmin, float tmax,
+// The BVH source the TIMED launch of this scene walks (jtx_launch_render_paths' choice): what traversal = 1 of the per-ray entry points runs
+int jtx_production_source(const DevScene &sc) {
+    const bool lds = sc.lds_threaded != 0;
+    static const int leafWalk = [] { const char *e = getenv("JTX_LEAF_WALK"); return e ? atoi(e) : 1; }();
+    if (lds) return (sc.lw_leaves > 0 && leafWalk) ? SRC_LEAF : SRC_LDS;
+    return sc.wide != nullptr ? SRC_WIDE : SRC_GLOBAL;
+}
+
+static size_t batchShmem(const DevScene &sc, int src, int bs) {
+    if (src == SRC_WIDE) return (size_t) sc.wide_depth * bs * sizeof(uint2);
+    if (src == SRC_LDS) return ldsBytes(sc, true);
+    if (src == SRC_LEAF) return ldsBytes(sc, true) + (size_t) 2 * ((sc.lw_leaves + 3) & ~3) * sizeof(float4) + 128 * sizeof(unsigned);
+    return 0;
+}
+
+// src: SRC_GLOBAL / SRC_LDS / SRC_LEAF / SRC_WIDE (the caller has checked that the scene carries that structure).  The 8-ary instance
+// runs single-wave workgroups like the timed kernel (stack stride 64), the LDS-staged ones its 256-lane workgroups.
+hipError_t jtx_launch_closest_batch(const DevScene &sc, int src, int n, const float *o, const float *d, float tmin, float tmax,
                                     int *hit, float *t, int *prim, float *b1, float *b2, float *point, float *normal,
                                     float *uv, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_closest_batch, dim3(blocksFor(n)), dim3(BLOCK), ldsBytes(sc, false), stream, sc, n, o, d, tmin, tmax,
-                       hit, t, prim, b1, b2, point, normal, uv);
+    const int bs = src == SRC_WIDE ? 64 : BLOCK;
+    const dim3 grid((unsigned) ((n + bs - 1) / bs)), block(bs);
+    const size_t shmem = batchShmem(sc, src, bs);
+#define LAUNCH_CB(S, B) hipLaunchKernelGGL((k_closest_batch<S, B>), grid, block, shmem, stream, sc, n, o, d, tmin, tmax, hit, t, prim, b1, b2, point, normal, uv)
+    if (src == SRC_WIDE) LAUNCH_CB(SRC_WIDE, 64); else if (src == SRC_LEAF) LAUNCH_CB(SRC_LEAF, BLOCK); else if (src == SRC_LDS) LAUNCH_CB(SRC_LDS, BLOCK); else LAUNCH_CB(SRC_GLOBAL, BLOCK);
+#undef LAUNCH_CB
     return hipGetLastError();
 }
-hipError_t jtx_launch_any_batch(const DevScene &sc, int n, const float *o, const float *d, const float *tmin,
+hipError_t jtx_launch_any_batch(const DevScene &sc, int src, int n, const float *o, const float *d, const float *tmin,
                                 const float *tmax, int *hit, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_any_batch, dim3(blocksFor(n)), dim3(BLOCK), ldsBytes(sc, false), stream, sc, n, o, d, tmin, tmax, hit);
+    const int bs = src == SRC_WIDE ? 64 : BLOCK;
+    const dim3 grid((unsigned) ((n + bs - 1) / bs)), block(bs);
+    const size_t shmem = batchShmem(sc, src, bs);
+#define LAUNCH_AB(S, B) hipLaunchKernelGGL((k_any_batch<S, B>), grid, block, shmem, stream, sc, n, o, d, tmin, tmax, hit)
+    if (src == SRC_WIDE) LAUNCH_AB(SRC_WIDE, 64); else if (src == SRC_LEAF) LAUNCH_AB(SRC_LEAF, BLOCK); else if (src == SRC_LDS) LAUNCH_AB(SRC_LDS, BLOCK); else LAUNCH_AB(SRC_GLOBAL, BLOCK);
+#undef LAUNCH_AB
     return hipGetLastError();
 }
 hipError_t jtx_launch_bxdf_batch(const DevScene &sc, int mode, int material, int n, const float *normal, const float *uv,

@@ -29,8 +29,6 @@ struct RenderParams {
     // word; persistent waves read it whenever they fetch a chunk and stop handing out paths, k_resolve_samples then leaves
     // the film as the last completed pass left it
     const unsigned *stop;
-    // k_render_paths over the 8-ary nodes with JTX_SLIP_K > 0: two float4 per lane of the persistent grid (an extension ray parked across bounces)
-    float4 *slip;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
@@ -114,15 +112,15 @@ hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
 int jtx_render_paths_grid(const jtx::DevScene &sc, int num_cus, int *block_size);   // workgroups the persistent grid holds (host only)
-int jtx_render_paths_slip_k();                                                      // JTX_SLIP_K the kernels were compiled with
 hipError_t jtx_launch_render_alt(const jtx::RenderParams &p, int num_owned_tiles, bool count, int li, hipStream_t stream);
 hipError_t jtx_launch_radiance_samples_alt(const jtx::DevScene &sc, const jtx::DCam &cam, int maxDepth, int li, int n, const int *row,
                                            const int *col, const int *sample, float *rgb, hipStream_t stream);
 hipError_t jtx_launch_resolve_samples(const jtx::RenderParams &p, int num_owned_tiles, hipStream_t stream);
-hipError_t jtx_launch_closest_batch(const jtx::DevScene &sc, int n, const float *o, const float *d, float tmin, float tmax,
+int jtx_production_source(const jtx::DevScene &sc);      // SRC_* the timed launch of this scene walks
+hipError_t jtx_launch_closest_batch(const jtx::DevScene &sc, int src, int n, const float *o, const float *d, float tmin, float tmax,
                                     int *hit, float *t, int *prim, float *b1, float *b2, float *point, float *normal,
                                     float *uv, hipStream_t stream);
-hipError_t jtx_launch_any_batch(const jtx::DevScene &sc, int n, const float *o, const float *d, const float *tmin,
+hipError_t jtx_launch_any_batch(const jtx::DevScene &sc, int src, int n, const float *o, const float *d, const float *tmin,
                                 const float *tmax, int *hit, hipStream_t stream);
 hipError_t jtx_launch_bxdf_batch(const jtx::DevScene &sc, int mode, int material, int n, const float *normal, const float *uv,
                                  const float *wo, const float *wi_in, const float *uc, const float *u2, int *ok, float *f,

@@ -16,6 +16,7 @@
 #pragma once
 #include "jtx_bxdf.hpp"
 #include "jtx_wide_quant.hpp"
+#include "jtx_profile.hpp"
 
 namespace jtx {
 
@@ -43,27 +44,9 @@ struct DevScene {
 
 struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode only)
     unsigned n_camera, n_closest, n_any, n_nodes_closest, n_tri_closest, n_accept, n_nodes_any, n_tri_any, n_shade;
-#ifdef JTX_PROFILE_UTIL
-    unsigned it_interior, it_leaf, it_calls;   // diagnostic: loop iterations this lane sat through (= wave iterations)
-    unsigned it_hist[7];   // interior iterations by number of walking lanes: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
-    unsigned it_np, it_nd, it_lw, it_ld;   // lane-iterations idle: interior iterations spent parked / done, leaf phases spent walking / done
-#endif
-#ifdef JTX_PROFILE_WIDE
-    unsigned w_calls, w_node_iters, w_node_steps, w_leaf_iters, w_leaf_steps, w_tris, w_pops, w_fetch;   // diagnostic: wide traversal
-    unsigned w_hist[7];    // node iterations by number of walking lanes: 1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64
-    unsigned w_np, w_nd, w_lw, w_ld;   // lane-iterations idle: node iterations spent parked / done, leaf iterations spent walking / done
-#endif
+    JTX_PROF_UTIL_FIELDS         // diagnostic builds only (jtx_profile.hpp); nothing in the product
+    JTX_PROF_WIDE_FIELDS
 };
-#ifdef JTX_PROFILE_UTIL
-#define UTIL(x) x
-#else
-#define UTIL(x)
-#endif
-#ifdef JTX_PROFILE_WIDE
-#define WSTAT(x) x
-#else
-#define WSTAT(x)
-#endif
 
 enum { SRC_GLOBAL = 0, SRC_LDS = 1, SRC_WIDE = 2, SRC_LEAF = 3 };
 
@@ -264,10 +247,11 @@ JD bool traverseThreaded(const Src &src, int num_nodes, f3 o, f3 d, f3 inv, int 
 //     visiting order of an octant: the slots in the order the reference's near-first rule (dirIsNeg[axis], scene.cpp:40-46)
 //     walks the treelet, 3 bits per position.  A ray reads the tail of ITS octant; the one-hot words turn the eight pass / miss
 //     bytes of the box tests (sign bytes of t1 - t0, v_perm_b32) into the pending mask of the order list with one AND and one
-//     byte sum (wideNodePend) -- rounds 1-3 permuted the eight hit bits with 26 instructions (widePending; JTX_WIDE_TAILS=2).
+//     byte sum (wideNodePend) -- rounds 1-3 permuted the eight hit bits with 26 instructions.
 //   leaf record (32 B): the exact leaf box + primitivesOffset + numPrimitives, tested with slabRegular.
-//   first step ("root peel", JTX_WIDE_ROOT_PEEL=1, measured and left off): every lane of a wave enters at the root, so the root's
-//     children can be tested on their EXACT boxes read with scalar loads (the record at the head of the array).
+//   (The head of the array holds the exact boxes of the root's children -- the "root-peel" record of a first step through scalar
+//    loads that was measured and dropped; tests walk it.  That step, the one- and two-tail node formats, the straggler-slip kernel and
+//    the lane-column stack addressing live as patches under tools/experiments/, not here.)
 // The per-lane stack holds one 64-bit entry per wide level {header word, visiting order, pending positions} in LDS.
 // A stale hit bit (t.max shrank since the node was tested) only costs a visit.  Irregular rays (a zero / non-finite
 // direction component ...) take the exact binary path.
@@ -281,19 +265,11 @@ constexpr unsigned WIDE_NODE_G = jtxq::kNodeG;   // granules (16 B) from one int
 #ifndef JTX_WIDE_STEPS
 #define JTX_WIDE_STEPS 1
 #endif
-#ifndef JTX_WIDE_SIGNBYTES
-#define JTX_WIDE_SIGNBYTES 0         // 1: the hit mask of a node from the SIGN BYTES of t1 - t0 (v_perm_b32 / v_bitop3_b32 / v_sad_u8, wideNodePend) instead of
-                                     // compare / select / or
-#endif
 #ifndef JTX_WIDE_PEND_BARRIER
 #define JTX_WIDE_PEND_BARRIER 1
 #endif
-#ifndef JTX_WIDE_ROOT_PEEL
-#define JTX_WIDE_ROOT_PEEL 0         // 1: the first step reads the root's children through scalar loads (measured: C3 +2 %, C5 -2 %; the root's
-                                     // vector loads are one coalesced request per wave anyway -- DESIGN.md section 10)
-#endif
-#ifndef JTX_PEEL_GROUP
-#define JTX_PEEL_GROUP 8             // children of the root tested between two scheduling barriers (8: no barriers; 2 / 4 spill MORE SGPRs)
+#ifndef JTX_FP_TOLERANCE
+#define JTX_FP_TOLERANCE 0           // 1: the measurement build of round 5 (what north_star's "stated per-pixel tolerance" would buy in the traversal)
 #endif
 
 // outward slack of the wide-node slab test: mu = 2^-23 (4 |b| + 512 |a|) + 2^-100 per axis (error budget in DESIGN.md)
@@ -304,8 +280,7 @@ constexpr float WIDE_RANGE = 1099511627776.0f;   // 2^40: |1/d|, 1/|1/d| and |o|
 
 JD float ubyteToFloat(unsigned v, int k) { return (float) ((v >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
 
-// ocls: the octant whose stored order this ray walks (negmask, or 7 - negmask when the z sign is set), rev: from the end
-struct WideRay { f3 o, d, inv; float tmin, tmax; int negmask, ocls; bool rev; };
+struct WideRay { f3 o, d, inv; float tmin, tmax; int negmask; };
 struct WideState {
     unsigned gbase, gbits;       // current group: children base (28 bits) | interior children (4) ; order list (24) | pending (8)
     int sp, pendLeaf;            // stack entries in use; granule of the leaf record the lane is parked on (-1: none)
@@ -315,36 +290,8 @@ struct WideState {
     JD bool walking() const { return pendLeaf < 0 && !done; }
 };
 
-// The 8 child boxes of a wide node against a ray: bit s = slot s may be hit (never misses a box AABB::hit would pass).
-JD unsigned wideNodeHits(const uint4 n0, const uint4 n2, const uint4 n3, const uint4 n4, f3 o, f3 inv, float tmin, float tmax) {
-    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-    // per axis: t(q) = q * a + b with a = cell / d (exact: a power-of-two scaling), b = (origin - o) / d,
-    // pushed outward by mu >= every rounding difference to AABB::hit on a contained box
-    const float axx = __uint_as_float((n0.w & 0xffu) << 23) * inv.x, bxx = (__uint_as_float(n0.x) - o.x) * inv.x;
-    const float ayy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23) * inv.y, byy = (__uint_as_float(n0.y) - o.y) * inv.y;
-    const float azz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23) * inv.z, bzz = (__uint_as_float(n0.z) - o.z) * inv.z;
-    const float mux = __fmaf_rn(fabsf(bxx), WIDE_MU_B, __fmaf_rn(fabsf(axx), WIDE_MU_A, WIDE_MU_0));
-    const float muy = __fmaf_rn(fabsf(byy), WIDE_MU_B, __fmaf_rn(fabsf(ayy), WIDE_MU_A, WIDE_MU_0));
-    const float muz = __fmaf_rn(fabsf(bzz), WIDE_MU_B, __fmaf_rn(fabsf(azz), WIDE_MU_A, WIDE_MU_0));
-    const float bnx = bxx - mux, bfx = bxx + mux, bny = byy - muy, bfy = byy + muy, bnz = bzz - muz, bfz = bzz + muz;
-    // near / far plane bytes of each axis by the direction sign (== min/max of the pair for a regular ray)
-    const unsigned nxq[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, fxq[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
-    const unsigned nyq[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, fyq[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
-    const unsigned nzq[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, fzq[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
-    unsigned hits = 0u;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int w = s >> 2, b = s & 3;
-        const float t0 = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)),
-                               fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), tmin));
-        const float t1 = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)),
-                               fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), tmax));
-        hits |= (t0 <= t1 ? 1u : 0u) << s;
-    }
-    return hits;
-}
-
-// The same test with the answer in POSITION space of an order list (JTX_WIDE_TAILS=8): ohLo / ohHi hold, per slot byte, the one-hot
+// The 8 child boxes of a wide node against a ray (never misses a box AABB::hit would pass), with the answer in POSITION space of the
+// ray's order list: ohLo / ohHi hold, per slot byte, the one-hot
 // position of the slot in the ray's visiting order (0: no child).  Per child t1 - t0 instead of a compare (a miss is a NEGATIVE
 // difference: t0, t1 are finite for the rays the wide nodes take, t1 is never -0 -- every far value is b + mu with mu > 0 -- and
 // t0 == t1 gives +0), v_perm_b32's sign selectors turn four sign bits into four bytes 0xff / 0x00, (not miss) AND one-hot, summed
@@ -393,116 +340,33 @@ JD unsigned wideNodePend(const uint4 n0, const uint4 n2, const uint4 n3, const u
 #endif
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-JD unsigned wideField3(unsigned v, int at) { return __builtin_amdgcn_ubfe(v, (unsigned) at, 3u); }
-JD unsigned wideBit(unsigned v, unsigned at) { return __builtin_amdgcn_ubfe(v, at, 1u); }
-#else
-JD unsigned wideField3(unsigned v, int at) { return (v >> at) & 7u; }
-JD unsigned wideBit(unsigned v, unsigned at) { return (v >> at) & 1u; }
-#endif
-// the visiting order of octant class q (0..3) out of the three order words (4 x 24 bits back to back)
-JD unsigned wideOrderOf(unsigned wy, unsigned wz, unsigned ww, int q) {
-    const unsigned lo = q < 2 ? wy : (q == 2 ? wz : ww), hi = q < 2 ? wz : ww;
-    return __funnelshift_r(lo, hi, (24 * q) & 31) & 0x00ffffffu;
-}
-// hit mask in slot space -> pending mask in the position space of an order list
-JD unsigned widePending(unsigned hits, unsigned perm) {
-    unsigned pend = 0u;
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) pend |= wideBit(hits, wideField3(perm, 3 * k2)) << k2;     // 2 v_bfe_u32 + v_lshl_or_b32 per position
-    return pend;
-}
-
 // One interior step of a walking lane: take the next child of the current group (popping the stack when the
 // group is empty); an interior child is fetched and tested (its hits become the new group), a leaf child parks the lane.
 // ORD = 0 (anyHit: the answer does not depend on the order): children are taken in slot order, leaves first; 1: the octant's visiting order.
-// LANECOL (single-wave workgroups): `stk` is the wave's stack BASE and the lane's column is recomputed from the lane id at every push /
-// pop (two v_mbcnt) -- a per-lane column pointer kept across the traversal is one more live register, and the allocator's answer to
-// that in the slip kernel was a scratch reload inside the node loop.
-#if defined(__HIP_DEVICE_COMPILE__)
-JD unsigned wideLaneId() {      // volatile: the builtins are loop-invariant, get hoisted out of the node loop -- and then spilled and reloaded in it
-    unsigned x;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
-    return x;
-}
-#else
-JD unsigned wideLaneId() { return 0u; }
-#endif
-template <int ORD, bool LANECOL = false>
+template <int ORD>
 JD void wideNodeStep(const uint4 *__restrict__ wide, uint2 *stk, int stride, const WideRay &r, WideState &ws) {
     constexpr bool ORDERED = ORD == 1;
     if ((ws.gbits & 0xffu) == 0u) {                          // group exhausted: pop
         if (ws.sp == 0) { ws.done = true; return; }
-        --ws.sp; const uint2 e = stk[ws.sp * stride + (LANECOL ? wideLaneId() : 0u)]; ws.gbase = e.x; ws.gbits = e.y;
+        --ws.sp; const uint2 e = stk[ws.sp * stride]; ws.gbase = e.x; ws.gbits = e.y;
     }
-    // next position in visiting order (a reversed list is walked from its end; anyHit: leaves first)
-    const int k = (ORDERED && !(jtxq::kTails == 1 && r.rev)) ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);
+    // next position in visiting order (anyHit: from the end of the slot list -- leaves first)
+    const int k = ORDERED ? __builtin_ctz(ws.gbits & 0xffu) : 31 - __builtin_clz(ws.gbits & 0xffu);
     ws.gbits &= ~(1u << k);
     const unsigned slot = (ws.gbits >> (8 + 3 * k)) & 7u;
     const unsigned ni = ws.gbase >> 28, base = ws.gbase & 0x0fffffffu;
     if (slot >= ni) { ws.pendLeaf = (int) (base + WIDE_NODE_G * ni + 2u * (slot - ni)); return; }
     const unsigned a = base + WIDE_NODE_G * slot;
-    if (ws.gbits & 0xffu) { stk[ws.sp * stride + (LANECOL ? wideLaneId() : 0u)] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
+    if (ws.gbits & 0xffu) { stk[ws.sp * stride] = make_uint2(ws.gbase, ws.gbits); ++ws.sp; }
     const uint4 n0 = wide[a], n2 = wide[a + 1], n3 = wide[a + 2], n4 = wide[a + 3];
-    const uint4 tl = wide[a + 4 + (!ORDERED ? 0u : jtxq::kTails == 8 ? (unsigned) r.negmask : jtxq::kTails == 2 ? (unsigned) (r.negmask >> 2) : 0u)];
+    // tail of the ray's octant: [children base | its order | one-hot positions of slots 0-3 | 4-7]
+    const uint4 tl = wide[a + 4 + (ORDERED ? (unsigned) r.negmask : 0u)];
     const unsigned nchild = n0.w >> 28;
-    if (jtxq::kTails == 8) {        // tail of the ray's octant: [children base | its order | one-hot positions of slots 0-3 | 4-7]
-        const unsigned perm = ORDERED ? tl.y : 0x00fac688u;
-        const unsigned pend = ORDERED ? wideNodePend(n0, n2, n3, n4, tl.z, tl.w, r.o, r.inv, r.tmin, r.tmax)
-                                      : wideNodePend(n0, n2, n3, n4, 0x08040201u, 0x80402010u, r.o, r.inv, r.tmin, r.tmax) & ((1u << nchild) - 1u);
-        ws.gbase = tl.x | (((n0.w >> 24) & 0xfu) << 28);
-        ws.gbits = pend | (perm << 8);
-        return;
-    }
-#if JTX_WIDE_SIGNBYTES
-    const unsigned hits = wideNodePend(n0, n2, n3, n4, 0x08040201u, 0x80402010u, r.o, r.inv, r.tmin, r.tmax);    // identity one-hots: slot space
-#else
-    const unsigned hits = wideNodeHits(n0, n2, n3, n4, r.o, r.inv, r.tmin, r.tmax);
-#endif
-    // slot space -> visiting order of this ray's octant (24-bit list of slots, first visited first); tail = [children base | the orders of 4 octants]
-    const unsigned perm = ORDERED ? wideOrderOf(tl.y, tl.z, tl.w, jtxq::kTails == 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;   // identity: slot k at position k
-    const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);   // (the identity list leaves the hits where they are)
+    const unsigned perm = ORDERED ? tl.y : 0x00fac688u;            // (anyHit: the identity list, slot k at position k)
+    const unsigned pend = ORDERED ? wideNodePend(n0, n2, n3, n4, tl.z, tl.w, r.o, r.inv, r.tmin, r.tmax)
+                                  : wideNodePend(n0, n2, n3, n4, 0x08040201u, 0x80402010u, r.o, r.inv, r.tmin, r.tmax) & ((1u << nchild) - 1u);
     ws.gbase = tl.x | (((n0.w >> 24) & 0xfu) << 28);
     ws.gbits = pend | (perm << 8);
-}
-
-// The first step of a traversal: all lanes stand at the root, so its children come through scalar loads (the root-peel record:
-// group word, the four orders, #children, the children's EXACT boxes -- a slab test on an exact child box passes whenever a leaf below would)
-template <int ORD>
-JD void wideRootStep(const uint4 *__restrict__ wide, const WideRay &r, WideState &ws) {
-    constexpr bool ORDERED = ORD == 1;
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef const __attribute__((address_space(4))) unsigned *CW;
-    typedef const __attribute__((address_space(4))) float *CF;
-#else
-    typedef const unsigned *CW;
-    typedef const float *CF;
-#endif
-    const CW rec = (CW) (const void *) wide;
-    const CF box = (CF) (const void *) (wide + jtxq::kPeelBoxes);
-    const unsigned grp = rec[0], nchild = rec[4];
-    const bool openEnd = r.tmax == __builtin_inff();          // closestHit's interval (integrator.cpp:181): see slabRegularOpen
-    unsigned hits = 0u;
-    // JTX_PEEL_GROUP children at a time, the groups kept apart by scheduling barriers: all 48 box words at once cost the kernel
-    // 10 more spilled SGPRs and ~85 more v_readlane per bounce than the step saves (measured: C3 +2 %)
-#pragma unroll
-    for (int g = 0; g < 8; g += JTX_PEEL_GROUP) {
-#pragma unroll
-        for (int s = g; s < g + JTX_PEEL_GROUP; ++s) {
-            const float4 na = make_float4(box[6 * s], box[6 * s + 1], box[6 * s + 2], box[6 * s + 3]);
-            const float4 nb = make_float4(box[6 * s + 4], box[6 * s + 5], 0.0f, 0.0f);
-            const bool pass = openEnd ? slabRegularOpen(na, nb, r.o, r.inv, r.tmin) : slabRegular(na, nb, r.o, r.inv, r.tmin, r.tmax);
-            hits |= (pass ? 1u : 0u) << s;
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (JTX_PEEL_GROUP < 8) __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-    const bool hiOct = jtxq::kTails >= 2 && (r.negmask & 4);
-    const unsigned perm = ORDERED ? wideOrderOf(hiOct ? rec[5] : rec[1], hiOct ? rec[6] : rec[2], hiOct ? rec[7] : rec[3], jtxq::kTails >= 2 ? (r.negmask & 3) : r.ocls) : 0x00fac688u;
-    const unsigned pend = (ORDERED ? widePending(hits, perm) : hits) & ((1u << nchild) - 1u);
-    ws.gbase = grp; ws.gbits = pend | (perm << 8);
-    ws.sp = 0; ws.pendLeaf = -1; ws.done = false; ws.hitAnything = false;
 }
 
 // The leaf a lane is parked on: AABB::hit on the exact box, then the leaf's triangles (mesh.hpp:106-192)
@@ -511,7 +375,14 @@ JD void wideLeafStep(const uint4 *__restrict__ wide, const Src &src, bool any, W
     const uint4 ua = wide[ws.pendLeaf], ub = wide[ws.pendLeaf + 1];
     const float4 la = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
     const float4 lb = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), 0.0f, 0.0f);
+#if JTX_FP_TOLERANCE
+    // tolerance build (DESIGN.md "tolerance mode"; NOT the product): the leaf's exact box is not re-tested -- its triangles are, so a hit
+    // can only differ from the reference's where AABB::hit's rounding rejects a box whose triangle test would pass (grazing hits)
+    (void) la; (void) lb;
+    {
+#else
     if (slabRegular(la, lb, r.o, r.inv, r.tmin, r.tmax)) {
+#endif
         const int n = (int) ub.w, off = (int) ub.z;
         for (int i = 0; i < n; ++i) {
             const int prim = off + i;
@@ -529,20 +400,14 @@ JD void wideLeafStep(const uint4 *__restrict__ wide, const Src &src, bool any, W
 
 JD void wideRaySetup(WideRay &r, f3 o, f3 d, f3 inv, int negmask, float tmin, float tmax) {
     r.o = o; r.d = d; r.inv = inv; r.tmin = tmin; r.tmax = tmax; r.negmask = negmask;
-    if (jtxq::kTails == 1) { r.rev = (negmask & 4) != 0; r.ocls = (r.rev ? ~negmask : negmask) & 3; }
-    else { r.rev = false; r.ocls = 0; }                    // (two tails: the octant's own order, negmask & 3 inside the tail of its z sign)
 }
 
-template <bool ANY, bool LANECOL = false, class Src>
+template <bool ANY, class Src>
 JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk, int stride, f3 o, f3 d, f3 inv,
                      int negmask, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     WideRay r; wideRaySetup(r, o, d, inv, negmask, tmin, tmax);
     WideState ws;
-#if JTX_WIDE_ROOT_PEEL
-    wideRootStep<ANY ? 0 : 1>(wide, r, ws);
-#else
     ws.start();
-#endif
     WSTAT(cnt.w_calls++;)
     while (true) {
         while (true) {
@@ -554,7 +419,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
                 WSTAT(if (ws.pendLeaf >= 0) cnt.w_np++; else if (ws.done) cnt.w_nd++;)
                 if (ws.walking()) {
                     WSTAT(cnt.w_node_steps++; const int leafBefore = ws.pendLeaf; const bool doneBefore = ws.done;)
-                    wideNodeStep<ANY ? 0 : 1, LANECOL>(wide, stk, stride, r, ws);
+                    wideNodeStep<ANY ? 0 : 1>(wide, stk, stride, r, ws);
                     WSTAT(if (ws.pendLeaf < 0 && !ws.done) cnt.w_fetch++; (void) leafBefore; (void) doneBefore;)
                 }
             }
@@ -585,107 +450,24 @@ JD bool wideRayOk(f3 o, f3 inv, float tmin, float tmax) {
            fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= WIDE_RANGE;
 }
 
-// ---- closestHit that lets its stragglers slip (round 4) ---------------------------------------------------------------------
-// A wave leaves traverseWide when its LAST ray is through: on the atrium 22 % of the node iterations of a frame run with one or two
-// walking lanes, 37 % with at most eight (tools/tools_wide_stats.py) -- while half of the lanes of the NEXT traversal idle in turn.
-// Here the wave leaves the loop when at most JTX_SLIP_K rays are still under way (and at least JTX_SLIP_MIN_DONE came through in
-// this call): the stragglers keep their traversal state -- group, pending children, stack depth, t.max, the hit so far; the stack
-// itself stays where it is, in the lane's LDS column -- sit out the rest of the bounce, and walk on in the wave's next closestHit,
-// beside 60 fresh rays.  Nothing about a ray's own walk changes (same nodes, same order, same shrinking t.max): bit-identical.
-#ifndef JTX_SLIP_K
-#define JTX_SLIP_K 0                 // 0: off (every ray finishes in the call that started it).  Measured with 4: node iterations of the C3 frame
-                                     // -8.8 %, traversal calls +3.6 %, frame +1.6 %
-#endif
-#ifndef JTX_SLIP_MIN_DONE
-#define JTX_SLIP_MIN_DONE 24
-#endif
-#if JTX_SLIP_K > 0
-// The interrupted state is PARKED IN MEMORY (two float4 per lane of the persistent grid, written by the few lanes that slip, read by
-// the few that resume), not carried in registers: eight more values live across the whole bounce made the compiler spill inside the
-// node loops (first version: C3 364 ms against 320).
-
-// -> true: this lane's ray is UNFINISHED (state in park[0..1], `on` set); false: finished, `hit` / `rec` as traverseNoStack<false> gives them
-template <class Src>
-JD bool traverseWideSlip(const Src &src, int num_nodes, f3 o, f3 d, float tmin, float4 *parkBase, bool &on, HitRec &rec, bool &hit, Counters9 &cnt) {
-    hit = false;
-    if (num_nodes == 0) return false;
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-    const float tmax0 = __builtin_inff();
-    if (__builtin_expect(__ballot(!on && !wideRayOk(o, inv, tmin, tmax0)) != 0ull, 0)) {
-        // an irregular ray among the fresh ones: they walk the exact binary records together; resumed rays wait for the next call
-        if (on) return true;
-        hit = traverseThreaded<false, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax0, rec, cnt);
-        return false;
-    }
-    const uint4 *__restrict__ wide = src.wide;
-    uint2 *stk = src.stk; const int stride = src.stride;
-    WideRay r; wideRaySetup(r, o, d, inv, negmask, tmin, tmax0);
-    WideState ws; ws.start();
-    if (on) {
-        const float4 *park = parkBase + 2 * ((size_t) blockIdx.x * blockDim.x + threadIdx.x);
-        const float4 s0 = park[0], s1 = park[1];
-        ws.gbase = __float_as_uint(s0.x); ws.gbits = __float_as_uint(s0.y); ws.sp = __float_as_int(s0.z);
-        rec.prim = __float_as_int(s0.w); ws.hitAnything = rec.prim >= 0;
-        r.tmax = s1.x; rec.t = s1.x; rec.b1 = s1.y; rec.b2 = s1.z;
-    }
-    bool slipped = false;
-    WSTAT(cnt.w_calls++; if (on) cnt.w_pops++;)
-    while (true) {
-        while (true) {
-            WSTAT(cnt.w_node_iters++;
-                  { const int na = __popcll(__ballot(ws.walking()));
-                    cnt.w_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++; })
-            WSTAT(if (ws.pendLeaf >= 0) cnt.w_np++; else if (ws.done) cnt.w_nd++;)
-            WSTAT(if (ws.walking()) cnt.w_node_steps++;)
-            if (ws.walking()) wideNodeStep<1, Src::LANE_COLUMN>(wide, stk, stride, r, ws);
-            const unsigned long long walking = __ballot(ws.walking());
-            const unsigned long long parked = __ballot(ws.pendLeaf >= 0);
-            if (walking == 0ull || __popcll(parked) >= JTX_WIDE_LEAF_VOTE) break;
-            if (parked != 0ull && __popcll(walking) <= JTX_WIDE_FEW_WALKERS) break;
-            if (__popcll(walking | parked) <= JTX_SLIP_K && __popcll(__ballot(ws.done)) >= JTX_SLIP_MIN_DONE) break;
-        }
-        WSTAT(if (__ballot(ws.pendLeaf >= 0)) { cnt.w_leaf_iters++; if (ws.pendLeaf < 0) { if (ws.done) cnt.w_ld++; else cnt.w_lw++; } else cnt.w_leaf_steps++; })
-        if (ws.pendLeaf >= 0) wideLeafStep(wide, src, false, r, ws, rec);
-        const unsigned long long busy = __ballot(!ws.done);
-        if (busy == 0ull) break;
-        if (__popcll(busy) <= JTX_SLIP_K && __popcll(__ballot(ws.done)) >= JTX_SLIP_MIN_DONE) { slipped = true; break; }
-    }
-    if (slipped && !ws.done) {
-        float4 *park = parkBase + 2 * ((size_t) blockIdx.x * blockDim.x + threadIdx.x);
-        park[0] = make_float4(__uint_as_float(ws.gbase), __uint_as_float(ws.gbits), __int_as_float(ws.sp), __int_as_float(ws.hitAnything ? rec.prim : -1));
-        park[1] = make_float4(r.tmax, rec.b1, rec.b2, 0.0f);
-        on = true;
-        return true;
-    }
-    on = false;
-    hit = ws.hitAnything;
-    return false;
-}
-
-#endif
-
 // HBM-resident scene, uncounted kernels: wide traversal; a wave with an irregular ray walks the binary records
-template <bool LANECOL>
-struct WideSrcT {
-    static constexpr bool LANE_COLUMN = LANECOL;
+struct WideSrc {
     const uint4 *wide;
     const float4 *tnodes, *tris;
-    uint2 *stk;               // LANECOL: the workgroup's (= wave's) stack base; else this lane's LDS stack column
+    uint2 *stk;               // this lane's LDS stack column
     int stride;               // entries between two levels (= workgroup size)
     JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
 };
-typedef WideSrcT<false> WideSrc;
 
-template <bool ANY, bool COUNT, bool LANECOL>
-JD bool traverseNoStack(const WideSrcT<LANECOL> &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
+template <bool ANY, bool COUNT>
+JD bool traverseNoStack(const WideSrc &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     static_assert(!COUNT, "the counted kernels reproduce the reference's node visits: binary records only");
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
     if (__builtin_expect(__ballot(!wideRayOk(o, inv, tmin, tmax)) == 0ull, 1))
-        return traverseWide<ANY, LANECOL>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
+        return traverseWide<ANY>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
     return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
 }
 

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(WBLOCK, WIDE ? JTX_WF_WIDE_OCC : 1) k_wf_trace
                                  fabsf(o.x) < __builtin_inff() && fabsf(o.y) < __builtin_inff() && fabsf(o.z) < __builtin_inff() &&
                                  tmax == tmax;
             cur = negmask * sc.num_nodes; leafN = 0; hitAny = false; rec.prim = -1; rec.t = 0.0f; rec.b1 = rec.b2 = 0.0f;
-            if (WIDE) { wideRaySetup(wr, o, d, inv, negmask, tmin, tmax); if (JTX_WIDE_ROOT_PEEL) wideRootStep<ANY == 0>(sc.wide, wr, ws); else ws.start(); }
+            if (WIDE) { wideRaySetup(wr, o, d, inv, negmask, tmin, tmax); ws.start(); }
             if (!regular || (WIDE && !wideRayOk(o, inv, tmin, tmax))) {
                 // axis-parallel / non-finite rays: the exact slab test, traced to the end right here
                 // (rare; keeps the main loop on the min/max form only)

@@ -3,7 +3,8 @@
 // ONE piece of code decides every bit of a node, whoever writes it.
 //
 // Layout, round 4 (16-byte granules):
-//   root-peel record   granules 0..13 (kPeelRec): what a peeled first step (JTX_WIDE_ROOT_PEEL=1, off by default) reads with scalar loads:
+//   root-peel record   granules 0..13 (kPeelRec): the root's children with their EXACT boxes, what a first step through scalar loads reads
+//                      (measured and dropped: tools/experiments/r04_slip_rootpeel_tails.patch; the record stays in the layout, tests walk it):
 //                      [group word | the visiting orders of octants 0-3][#children | orders of octants 4-7][8 children x exact box, 6 floats]
 //   root node          granules 16.. (kRootNode): the root as an ordinary node
 //   children blocks    from granule 32 (kFirstBlock): for a node with ni interior children and nl leaves
@@ -15,7 +16,7 @@
 //                          octant -- base, order and the words that turn its eight pass / miss bytes into the pending mask of the
 //                          order list (wideNodePend: the permutation of the hit bits costs one AND and one byte sum, not 26 instructions)
 //   leaf record (32 B) the exact leaf box + primitivesOffset + numPrimitives  [min.x max.x min.y max.y][min.z max.z offset count]
-// Rounds 1-3 had TWO tails (octants 0-3 / 4-7: base + four 24-bit orders; 96-byte nodes; JTX_WIDE_TAILS=2 still builds it) and permuted
+// Rounds 1-3 had TWO tails (octants 0-3 / 4-7: base + four 24-bit orders; 96-byte nodes) and permuted
 // the hit mask in registers.  With the per-octant tails C3 320 -> 305 ms, C5 303 -> 287 (SQ_INSTS_VALU -6.5 %, L2 requests +7 % from the
 // larger nodes); see DESIGN.md section 10.  Other layouts built, taken through the whole parity suite and measured in round 4
 // (profiles/r04_wide_layouts.md), each behind the encoders of this file:
@@ -23,10 +24,10 @@
 //     granules instead of five: (a) 64-byte nodes on 64-byte boundaries, order granules at the end of the block: C3 339 ms against 319;
 //     (b) order granule behind its node: 331 ms.  3.4 % fewer load instructions, but unpacking the header costs 12-16 VALU
 //     instructions per node step (+4.0 % SQ_INSTS_VALU), and the kernel is short of issue slots first;
-//   * JTX_WIDE_TAILS=1: ONE tail granule (80-byte nodes), octant q >= 4 walking the order of octant 7 - q backwards (all three signs
+//   * ONE tail granule (80-byte nodes), octant q >= 4 walking the order of octant 7 - q backwards (all three signs
 //     flipped = every near / far decision of the treelet flipped): same instruction count in the node loop, C3 326 / C5 317 ms
 //     against 321 / 303 -- the per-ray direction flag and class cost two more live registers in kernels that spill 94-161;
-//   * JTX_WIDE_ROOT_PEEL=1: the root's children on their exact boxes through scalar loads: C3 327 (+2 %),
+//   * root peel: the root's children on their exact boxes through scalar loads: C3 327 (+2 %),
 //     C5 297 (-2 %); the 48 box words take 10 more spilled SGPRs and ~85 v_readlane per bounce, and the five vector loads it
 //     removes were ONE coalesced request per wave each (all 64 lanes read the root), not 64;
 //   * children blocks padded to 64 / 128 bytes on top of the per-octant tails: +-0.
@@ -49,13 +50,9 @@ namespace jtxq {
 constexpr int kWideMinExp = -60, kWideMaxExp = 40;   // cell = 2^e; with |1/d| in [2^-40, 2^40] (WIDE_RANGE) cell / d is exact
 constexpr float kWideCoordMax = 1099511627776.0f;    // 2^40
 
-#ifndef JTX_WIDE_TAILS
-#define JTX_WIDE_TAILS 8                             // 8: a tail per octant (the product); 2: rounds 1-3's two tail granules (octants 0-3 / 4-7);
-                                                     // 1: one, octants 4..7 walk the orders of 3..0 backwards
-#endif
-constexpr uint32_t kTails = JTX_WIDE_TAILS;          // 8: one tail granule PER OCTANT [children base | its 24-bit order | the one-hot POSITION of slots 0-3 | of slots 4-7]
+constexpr uint32_t kTails = 8;                       // one tail granule PER OCTANT [children base | its 24-bit order | the one-hot POSITION of slots 0-3 | of slots 4-7]
 constexpr uint32_t kNodeG = 4 + kTails;              // granules of a node record
-constexpr uint32_t kPeelRec = 0, kPeelBoxes = 2, kRootNode = 16, kFirstBlock = kTails > 2 ? 32 : 24;
+constexpr uint32_t kPeelRec = 0, kPeelBoxes = 2, kRootNode = 16, kFirstBlock = 32;
 constexpr uint32_t kMaxGranules = 1u << 28;          // the children base shares its word with a 4-bit count in the kernel's group state
 JTXQ_HD uint32_t blockGranules(int ni, int nl) { return kNodeG * (uint32_t) ni + 2u * (uint32_t) nl; }
 JTXQ_HD uint32_t nodeAt(uint32_t base, int s) { return base + kNodeG * (uint32_t) s; }
@@ -128,22 +125,12 @@ JTXQ_HD bool encodeTail(uint32_t *w, uint32_t base, const uint32_t perm[8], int 
     for (int q = 0; q < 4; ++q)
         for (int p = 0; p < nchild; ++p)
             if (((perm[q] >> (3 * p)) & 7u) != ((perm[7 - q] >> (3 * (nchild - 1 - p))) & 7u)) return false;
-    if (kTails == 8) {
-        // byte s of the two one-hot words = 1 << (position of slot s in this octant's order), 0 for a slot without a child: a per-child
-        // pass / miss byte mask ANDed with them and summed over its bytes IS the pending mask in position space (wideNodePend)
-        for (uint32_t t = 0; t < 8; ++t) {
-            uint32_t oh[2] = {0u, 0u};
-            for (int p = 0; p < nchild; ++p) { const uint32_t sl = (perm[t] >> (3 * p)) & 7u; oh[sl >> 2] |= (1u << p) << (8 * (sl & 3u)); }
-            w[4 * t + 0] = base; w[4 * t + 1] = perm[t] & 0x00ffffffu; w[4 * t + 2] = oh[0]; w[4 * t + 3] = oh[1];
-        }
-        return true;
-    }
+    // byte s of the two one-hot words = 1 << (position of slot s in this octant's order), 0 for a slot without a child: a per-child
+    // pass / miss byte mask ANDed with them and summed over its bytes IS the pending mask in position space (wideNodePend)
     for (uint32_t t = 0; t < kTails; ++t) {
-        const uint32_t *pm = perm + 4 * t;
-        w[4 * t + 0] = base;
-        w[4 * t + 1] = pm[0] | (pm[1] & 0xffu) << 24;
-        w[4 * t + 2] = pm[1] >> 8 | (pm[2] & 0xffffu) << 16;
-        w[4 * t + 3] = pm[2] >> 16 | pm[3] << 8;
+        uint32_t oh[2] = {0u, 0u};
+        for (int p = 0; p < nchild; ++p) { const uint32_t sl = (perm[t] >> (3 * p)) & 7u; oh[sl >> 2] |= (1u << p) << (8 * (sl & 3u)); }
+        w[4 * t + 0] = base; w[4 * t + 1] = perm[t] & 0x00ffffffu; w[4 * t + 2] = oh[0]; w[4 * t + 3] = oh[1];
     }
     return true;
 }
@@ -152,7 +139,7 @@ JTXQ_HD bool encodeTail(uint32_t *w, uint32_t base, const uint32_t perm[8], int 
 // [min.x max.x min.y max.y min.z max.z]; unused slots zero (masked by nchild in the kernel)
 JTXQ_HD void encodePeelHeader(uint32_t *rec, uint32_t base, int ni, int nchild, const uint32_t perm[8]) {
     rec[0] = groupWord(base, ni); rec[4] = (uint32_t) nchild; rec[5] = rec[6] = rec[7] = 0u;
-    for (uint32_t t = 0; t < (kTails == 1 ? 1u : 2u); ++t) {                        // four 24-bit orders back to back; octants 4..7 behind #children
+    for (uint32_t t = 0; t < 2u; ++t) {                                             // four 24-bit orders back to back; octants 4..7 behind #children
         const uint32_t *pm = perm + 4 * t;
         rec[4 * t + 1] = pm[0] | (pm[1] & 0xffu) << 24; rec[4 * t + 2] = pm[1] >> 8 | (pm[2] & 0xffffu) << 16; rec[4 * t + 3] = pm[2] >> 16 | pm[3] << 8;
     }

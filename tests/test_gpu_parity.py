@@ -1665,3 +1665,115 @@ def test_bench_starts_its_own_ranks(gpu):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks"]["nranks_seen"] == 2 and "REHEARSAL" in line["config"]["parallelism"]
     assert sum(x["shard_rays"] for x in line["ranks"]["ranks"]) == line["config"]["rays_per_frame"] == 727984390
+
+
+# ---- per-ray parity THROUGH THE TRAVERSALS THAT SHIP (VERDICT r4 missing 4 / weak 2): jtx_mi_closest_hit_batch_via / any_hit_batch_via
+# with JTX_MI_TRAVERSAL_PRODUCTION run traverseLeaves (Cornell: the flat leaf list, scalar-operand boxes), the LDS copy (scenes that
+# are LDS-resident but have more than 32 leaves) or traverseWide (HBM-resident scenes: the 8-ary quantised nodes, wideNodePend, the
+# per-lane LDS stack) -- the Src objects k_render_paths builds -- and every ray is compared with the oracle: a frame test says THAT a
+# ray went wrong, this one says WHICH.
+
+def _production_rays(data, osc, n, seed):
+    """n camera rays, n secondary-like rays from their hit points (origins ON surfaces, random directions: the rays a path's bounces
+    and shadow tests cast), n/8 nearly axis-parallel rays (|1/d| up to 1e9: inside the range the wide nodes take, b = (origin - o)/d
+    huge), and -- LAST, so that only the final waves of the launch fall back to the binary records by the wave-wide vote -- 128 exactly
+    axis-parallel rays."""
+    cam = data.camera_desc(512, 384, 2, 2, 4)
+    row, col, smp = _grid_samples(512, 384, 4, n, seed)
+    o, d = ol.camera_rays(cam, row, col, smp)
+    h = osc.closestHit(o, d)
+    rs = np.random.RandomState(seed + 1)
+    dirs = rs.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    o2 = np.where(h["hit"][:, None] > 0, h["point"] + np.float32(1e-3) * dirs, o).astype(np.float32)
+    m = n // 8
+    near = rs.normal(size=(m, 3)).astype(np.float32)
+    ax = rs.randint(0, 3, m)
+    near *= np.float32(1e-9) * (10.0 ** rs.uniform(0, 6, (m, 1))).astype(np.float32)
+    near[np.arange(m), ax] = np.where(rs.rand(m) < 0.5, 1.0, -1.0)
+    o3 = o2[rs.randint(0, n, m)]
+    axis = np.zeros((128, 3), np.float32)
+    axis[np.arange(128), np.arange(128) % 3] = np.where(np.arange(128) % 2, 1.0, -1.0)
+    o4 = o2[rs.randint(0, n, 128)]
+    return np.concatenate([o, o2, o3, o4]), np.concatenate([d, dirs, near, axis])
+
+
+def _check_closest(sc, osc, o, d, traversal, want_source, what):
+    g = sc.closestHit(o, d, traversal=traversal)
+    assert sc.SOURCE_NAMES[sc.last_source] == want_source, f"{what}: ran {sc.SOURCE_NAMES[sc.last_source]}"
+    r = osc.closestHit(o, d)
+    bad = np.flatnonzero((g["hit"] != r["hit"]) | (g["prim"] != r["prim"]))
+    assert len(bad) == 0, f"{what}: {len(bad)} rays hit another primitive; first ray {bad[0]}: o={o[bad[0]]} d={d[bad[0]]} gpu prim {g['prim'][bad[0]]} oracle {r['prim'][bad[0]]}"
+    for k in ("t", "b1", "b2", "point", "normal", "uv"):
+        assert_same_f32(g[k], r[k], f"{what}: {k}")
+    return g
+
+
+def _check_any(sc, osc, o, d, tmax, traversal, want_source, what):
+    g = sc.anyHit(o, d, 0.0, tmax, traversal=traversal)
+    assert sc.SOURCE_NAMES[sc.last_source] == want_source, f"{what}: ran {sc.SOURCE_NAMES[sc.last_source]}"
+    r = osc.anyHit(o, d, 0.0, tmax)
+    bad = np.flatnonzero(g != r)
+    assert len(bad) == 0, f"{what}: {len(bad)} rays differ; first ray {bad[0]}: o={o[bad[0]]} d={d[bad[0]]} tmax={tmax[bad[0]]} gpu {g[bad[0]]} oracle {r[bad[0]]}"
+    return g
+
+
+@pytest.mark.parametrize("which", ["cornell", "mixed", "atrium_full"])
+def test_per_ray_parity_through_the_shipped_traversals(which, request, gpu):
+    """>= 100 k rays per scene and mode, closestHit AND anyHit: hit / prim / t / b1 / b2 / point / normal / uv bitwise equal to the oracle
+    through the binary records (mode 0) and through the scene's production structure (mode 1): Cornell = the flat leaf list, the mixed
+    scene and the 262 k-triangle atrium = the 8-ary quantised nodes."""
+    if which == "atrium_full":
+        data, sc, osc = request.getfixturevalue("atrium_full")
+    else:
+        data, sc, osc = request.getfixturevalue(which + "_pair")
+    want = {"cornell": "leaf", "mixed": "wide", "atrium_full": "wide"}[which]
+    info = sc.info()
+    assert (want == "leaf") == bool(info["lds_resident"]) and (want != "wide" or info["wide_depth"] >= 2)
+    o, d = _production_rays(data, osc, 48000, 21)
+    assert len(o) >= 100000
+    rs = np.random.RandomState(5)
+    diag = float(np.linalg.norm(np.asarray(sc.bounds()[1]) - np.asarray(sc.bounds()[0])))
+    tmax = rs.uniform(0.002 * diag, 0.8 * diag, len(o)).astype(np.float32)
+    for traversal, src in ((sc.TRAVERSAL_BINARY, "binary"), (sc.TRAVERSAL_PRODUCTION, want)):
+        g = _check_closest(sc, osc, o, d, traversal, src, f"{which} closestHit via {src}")
+        assert g["hit"].mean() > 0.5
+        a = _check_any(sc, osc, o, d, tmax, traversal, src, f"{which} anyHit via {src}")
+        assert 0.05 < a.mean() < 0.95
+    # finite intervals on closestHit too (the leaf list's phase A takes the open-ended form only for t.max = +inf)
+    for traversal, src in ((sc.TRAVERSAL_PRODUCTION, want),):
+        g = sc.closestHit(o[:20000], d[:20000], 0.001, 0.3 * diag, traversal=traversal)
+        r = osc.closestHit(o[:20000], d[:20000], 0.001, 0.3 * diag)
+        assert (g["hit"] == r["hit"]).all() and (g["prim"] == r["prim"]).all()
+        assert_same_f32(g["t"], r["t"], f"{which} closestHit, finite interval, via {src}")
+
+
+def test_per_ray_parity_on_equal_t_ties_and_lds_copies(gpu, cornell_pair):
+    """(i) the equal-t tie scene (rays through grid vertices and along grid edges: several triangles at exactly the same distance, the
+    first found in the reference's visiting order wins) through the 8-ary nodes, one- and four-primitive leaves; (ii) the LDS copy of
+    the threaded records (source 1: what LDS-resident scenes with more than 32 leaves walk, and every LDS-resident scene under
+    JTX_LEAF_WALK=0) on the Cornell box, named explicitly; (iii) asking for a structure the scene does not carry is an error."""
+    for max_prims in (1, 4):
+        data = _tie_scene(gpu)
+        data.max_prims_in_node = max_prims
+        sc = gpu.Scene(data); sc.buildBVH(max_prims)
+        osc = ol.OracleScene(data)
+        rs = np.random.RandomState(3)
+        n = 60000
+        gx = -4 + 8 * rs.randint(0, 25, n) / 24.0
+        gy = 6 * rs.randint(0, 25, n) / 24.0
+        target = np.stack([gx, gy, np.full(n, -3.0)], 1).astype(np.float32)
+        o = np.tile(np.array([[0.0, 3.0, 9.0]], np.float32), (n, 1))
+        o[: n // 3] += rs.uniform(-2, 2, (n // 3, 3)).astype(np.float32)         # a third from scattered origins (all regular rays)
+        d = (target - o).astype(np.float32)
+        g = _check_closest(sc, osc, o, d, sc.TRAVERSAL_PRODUCTION, "wide", f"ties, {max_prims} per leaf")
+        assert g["hit"].mean() > 0.9
+        tmax = rs.uniform(0.5, 1.5, n).astype(np.float32)                        # d is un-normalised: t = 1 is the grid plane
+        _check_any(sc, osc, o, d, tmax, sc.TRAVERSAL_PRODUCTION, "wide", f"ties anyHit, {max_prims} per leaf")
+        sc.destroy()
+    data, sc, osc = cornell_pair
+    o, d = _production_rays(data, osc, 16000, 33)
+    _check_closest(sc, osc, o, d, sc.TRAVERSAL_SOURCE + 1, "lds", "cornell closestHit via the LDS copy")
+    _check_any(sc, osc, o, d, np.full(len(o), 400.0, np.float32), sc.TRAVERSAL_SOURCE + 1, "lds", "cornell anyHit via the LDS copy")
+    with pytest.raises(gpu.JtxMiError):
+        sc.closestHit(o[:4], d[:4], traversal=sc.TRAVERSAL_SOURCE + 2)           # Cornell has no 8-ary nodes

@@ -318,7 +318,7 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(jtx._capi.SYMBOLS), declared ^ set(jtx._capi.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.jtx_mi_version() == 4
+    assert lib.jtx_mi_version() == 5
     assert C.sizeof(jtx._capi.BvhNode) == 32 and C.sizeof(jtx._capi.TriRef) == 8
 
 
