@@ -103,8 +103,13 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup):
         img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
         integrator = scene.info()["auto_integrator"]
 
+        pipe = jtx.distributed.ShardPipeline(scene, cam, 0, 1, dev, None, integrator=integrator, frames_in_flight=frames_in_flight())
+
         def frame(count=False):
-            jtx.distributed.render_shard(scene, cam, 0, 1, acc, img, stream=tstream.cuda_stream, count_rays=count, integrator=integrator)
+            if count:
+                jtx.distributed.render_shard(scene, cam, 0, 1, acc, img, stream=tstream.cuda_stream, count_rays=True, integrator=integrator)
+            else:
+                pipe.step()
         frame(count=True)
         torch.cuda.synchronize()
         cnt = jtx._capi.Counters()
@@ -121,16 +126,18 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup):
             frame()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t
-        jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
-        kernel_ms = ms.value / max(1, nl.value)
+        kernel_ms = serial_kernel_ms(jtx, torch, lib, scene, cam, 0, 1, dev, integrator, frames=min(3, steps))
         info = scene.info()
         out = {"ms_per_step": round(elapsed / steps * 1e3, 3), "kernel_ms": round(kernel_ms, 4), "steps": steps, "warmup": warmup,
+               "frames_in_flight": len(pipe.rstreams),
                "value": round(rays * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": rays,
                "scene_triangles": data.num_triangles, "integrator": integrator}
         if integrator == 1:
             sinfo = {"lds_resident": bool(info["lds_resident"]), "lds_bytes": 8 * 32 * info["num_nodes"] + 48 * info["num_prims"],
                      "workgroups": info["resident_workgroups"]}
             roof = roofline_block(name, sinfo, mine, "k_render_paths", kernel_ms, 1, info["num_cus"])
+            if len(pipe.rstreams) > 1:
+                out["in_flight"] = in_flight_block(roof, len(pipe.rstreams), elapsed / steps * 1e3, None)
             for k in ("useful_frac", "frac", "traffic", "vector_memory", "lane_util", "issue_model", "pmc_stale"):
                 if k in roof:
                     out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"], "busy_upper_bound": roof[k]["busy_upper_bound"]}
@@ -140,6 +147,44 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup):
         return out
     finally:
         scene.destroy()
+
+
+def in_flight_block(roof, n, ms_per_frame, kernel_ms_timed):
+    """the fractions of `roof` (measured on launches with one frame in flight) restated on the timed region's steady state: the chip
+    runs nothing but these frames, so a frame's share of it is the wall time per frame (the resolve pass included: a lower bound)"""
+    t = ms_per_frame * 1e-3
+    b = {"frames_in_flight": n, "ms_per_frame": round(ms_per_frame, 3),
+         "useful_frac": round(roof["useful"]["lane_ops_per_launch"] / t / 1e12 / roof["useful"]["peak"], 4),
+         "note": "the same numerators over the wall time per frame of the timed region (frames of the scene overlap: the last chunks of a "
+                 "launch run beside the first chunks of the next, the resolve pass beside the one after; roofline.kernel_ms / frac / "
+                 "useful_frac are measured on launches with ONE frame in flight, as JTX_FRAMES_IN_FLIGHT=1 times them)"}
+    if roof.get("valu_instructions_per_launch"):
+        b["frac"] = round(roof["valu_instructions_per_launch"] / t / 1e9 / roof["peak"], 4)
+    if kernel_ms_timed is not None:
+        b["launch_ms_start_to_end"] = round(kernel_ms_timed, 3)
+    return b
+
+
+def frames_in_flight():
+    """frames of one scene in flight in the timed loops (distributed.ShardPipeline; JTX_FRAMES_IN_FLIGHT=1: round 4's one-stream loop)"""
+    return max(1, min(3, int(os.environ.get("JTX_FRAMES_IN_FLIGHT", "3"))))
+
+
+def serial_kernel_ms(jtx, torch, lib, scene, cam, rank, world, dev, integrator, frames=3):
+    """average duration of the dominant kernel's launch with ONE frame in flight (what `JTX_FRAMES_IN_FLIGHT=1 bench.py` times, and what
+    a rocprofv3 kernel trace of that command shows): the roofline's denominator.  In the timed region several frames of the scene are in
+    flight and consecutive launches share the chip -- a launch then lasts longer than a frame takes (its own start-to-end time counts
+    the lanes it left to its neighbours), so its duration says nothing about the chip time it used."""
+    pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, None, integrator=integrator, frames_in_flight=1)
+    ms = C.c_float(); nl = C.c_int32()
+    pipe.step()
+    torch.cuda.synchronize()
+    jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))     # drop what came before
+    for _ in range(max(1, frames)):
+        pipe.step()
+    torch.cuda.synchronize()
+    jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
+    return ms.value / max(1, nl.value)
 
 
 def algorithmic_bytes(c):
@@ -419,6 +464,11 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL's peer-to-peer needs on this driver
+    # The frames in flight live on three HIP streams; the runtime maps streams onto 4 hardware queues by default, and with torch's, the
+    # library's and the exchange's streams beside them two render streams then share one -- launches of one queue run in order, and the
+    # loop falls back to "one kernel at a time" (C2: 27.2 ms per frame against 26.4; profiles/r05_frames_in_flight.md).  Read by the
+    # runtime when it initialises, so it has to be set before torch is imported.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference needs no launcher either --
         # StaticCamera::render just spawns its workers, camera.cpp:81).  This parent has imported neither torch nor the library and
@@ -481,15 +531,18 @@ def main():
 
     # N > 1: the exchange of frame i runs on a side stream while frame i + 1 renders into the other pair of shard
     # buffers (rank 0 assembles frames in buffers of their own); every frame is complete before the closing fence
+    # ... and, at every N, TWO FRAMES IN FLIGHT: frame i + 1 starts on the other render stream / frame slot while the last chunks and
+    # the resolve pass of frame i still run (JTX_FRAMES_IN_FLIGHT=1: one render stream)
     pipe = None
-    if gatherer is not None and os.environ.get("JTX_PIPELINE_EXCHANGE", "1") != "0":
-        pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, gatherer, integrator=integrator)
+    if (gatherer is not None and os.environ.get("JTX_PIPELINE_EXCHANGE", "1") != "0") or (world == 1 and frames_in_flight() > 1):
+        pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, gatherer, integrator=integrator, timing=world > 1,
+                                             frames_in_flight=frames_in_flight())
 
     xtimed = []                                              # serial exchange: (event before, event after) per frame, on the render stream
 
     def step(count=False, profile=False):
-        if pipe is not None and gatherer is not None and not count and not profile:
-            pipe.step(tstream)
+        if pipe is not None and not count and not profile:
+            pipe.step()
             return
         jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count,
                                      integrator=integrator, profile_kernels=profile)
@@ -561,7 +614,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t
     jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
-    kernel_ms = ms.value / max(1, nl.value)
+    kernel_ms_timed = ms.value / max(1, nl.value)          # launches of the timed region: start-to-end, overlapping when frames are in flight
+    in_flight = len(pipe.rstreams) if pipe is not None else 1
+    # the roofline's kernel duration: launches with ONE frame in flight (integrator 1; the wavefront's dominant stage is timed per kind above)
+    kernel_ms = serial_kernel_ms(jtx, torch, lib, scene, cam, rank, world, dev, integrator, frames=min(3, args.steps)) if (in_flight > 1 and integrator == 1) else kernel_ms_timed
 
     tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -626,6 +682,8 @@ def main():
             kernel_ms = kind_ms[dom][0] / launches_per_frame          # average launch duration of that kernel
         roof = roofline_block(wl_name if world == 1 else wl_name + f"@{world}", sinfo, roof_counters, kernel_name,
                               kernel_ms, launches_per_frame, info["num_cus"])
+        if in_flight > 1 and integrator == 1:
+            roof["in_flight"] = in_flight_block(roof, in_flight, elapsed / args.steps * 1e3, kernel_ms_timed)
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -634,10 +692,12 @@ def main():
             "config": {"workload": wl_name, "scene_triangles": data.num_triangles, "width": W, "height": H,
                        "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
-                       "parallelism": f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu",
+                       "parallelism": (f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu")
+                                      + (f", {len(pipe.rstreams)} frames in flight" if pipe is not None and len(pipe.rstreams) > 1 else ""),
                        "scene_upload_ms": round(t_upload * 1e3, 2), "scene_create_warm_ms": warm_create_ms,
                        "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": info["lds_resident"],
                        "wide_bvh_bytes": info["wide_bytes"],
+                       "frames_in_flight": in_flight,
                        "timed_region": "frames rendered into HBM-resident film buffers (jtx_mi_render_device), incl. the resolve pass"},
             "roofline": roof,
         }

@@ -21,6 +21,7 @@ extern "C" {
 #endif
 
 #define JTX_MI_VERSION 5
+#define JTX_MI_FRAME_SLOTS 3
 #define JTX_MI_CANCELLED 2   /* jtx_mi_render: stopped by the callback / jtx_mi_cancel; the film holds the completed passes */
 
 /* LinearBVHNode, src/bvh.hpp:7-15 (32 B) */
@@ -118,6 +119,14 @@ typedef struct {
     int32_t path_integrator;  /* which Li (camera.cpp:104-106 picks by (un)commenting a line): 0 integrateMIS (integrator.cpp:171-216,
                                * the timed path), 1 integrate (:54-132: NEE without MIS, emission), 2 integrateBasic (:12-52: emission,
                                * no light sampling).  1 and 2 (and scenes with a THIN_DIELECTRIC material) run in k_render_alt. */
+    int32_t frame_slot;       /* 0 .. JTX_MI_FRAME_SLOTS - 1: which of the scene's sets of per-frame working memory (the per-path radiance
+                               * records of the persistent path kernel) this render uses.  Renders of one scene in DIFFERENT slots may be
+                               * in flight at the same time on different streams -- the workers of StaticCamera::render never wait for a
+                               * frame boundary either (camera.cpp:53-64, 81-123): here the last chunks of frame i overlap the first chunks
+                               * of frame i + 1, and the resolve pass of frame i those of frame i + 2.  Renders in the SAME slot are ordered
+                               * by the library (an event per slot), whatever streams they come on; launches that need the scene's
+                               * singletons (count_rays, integrator 2, path_integrator != 0) are ordered against all slots.  jtx_mi_render
+                               * uses slot 0. */
 } jtx_mi_render_opts;
 
 /* ray / traffic counters */
@@ -243,9 +252,10 @@ int jtx_mi_last_completed_sample(const jtx_mi_scene *scene, int32_t *out);  /* c
 
 /* Same, DEVICE buffers, asynchronous on `stream` (a hipStream_t, NULL = the library's own stream).
  * d_acc_rgb must stay valid until the stream is synchronised.  Used by bench.py / multi-GPU.
- * ONE STREAM PER SCENE AT A TIME: the per-path radiance buffer, the chunk counters, the wavefront slot arrays and the
- * ray counters are per-scene singletons -- renders of one scene must all be ordered on one stream (or be separated by a
- * synchronisation); renders of DIFFERENT scenes are independent.  jtx_mi_render uses the library's own stream.
+ * Renders of one scene are ordered per opts.frame_slot (see there): two frames of a scene can be in flight, one per slot, on two
+ * streams, each into film buffers of its own; renders of DIFFERENT scenes are independent.  jtx_mi_render uses the library's own
+ * stream and slot 0.  (jtx_mi_kernel_time pairs are per launch: overlapping launches overlap in time, their durations do not add up
+ * to the wall time.)
  * jtx_mi_cancel() also stops a device render in flight (the film then keeps its previous content). */
 int jtx_mi_render_device(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
                          void *d_acc_rgb, void *d_img_rgb, void *stream);
@@ -253,8 +263,10 @@ int jtx_mi_render_device(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, con
 int jtx_mi_cancel_pending(jtx_mi_scene *scene, int32_t *out);   /* after a sync: 0 none, 1 pending (the last pass completed), 2 pending and the last pass was abandoned */
 int jtx_mi_cancel_reset(jtx_mi_scene *scene);
 int jtx_mi_sync(jtx_mi_scene *scene);
-/* GPU time of the integrator kernel(s) of the last render call(s) since the previous query,
- * from HIP events recorded on the launch stream: sum in ms and number of launches. */
+/* GPU time of the integrator kernel(s) of the last render call(s) since the previous query: sum in ms and number of launches.
+ * Launches of the persistent path kernel report their own clocks (first wave in to last wave out -- what a kernel trace shows; with
+ * several frames of a scene in flight a launch waits for wave slots first, which an event pair on its stream would count in); all
+ * other launches: HIP events recorded on the launch stream. */
 int jtx_mi_kernel_time(jtx_mi_scene *scene, float *ms_total, int32_t *launches);
 /* Wavefront renders with opts.reserved bit 0: summed GPU ms and launch count per kernel kind since the last
  * query: [0] generate, [1] trace closest, [2] shade, [3] trace any (shadow), [4] resolve. */

@@ -180,7 +180,15 @@ struct jtx_mi_scene {
         DevBuildArena arena;
         ~RebuildSpare() { if (arena.base) (void) hipFree(arena.base); }
     } spare;
-    DevBuf<float4> rad;              // per-sample radiance of the strata-split mode
+    // Per-path radiance records of k_render_paths (and of the strata-split mode): JTX_MI_FRAME_SLOTS sets, so that several frames of one
+    // scene can be in flight at once (opts.frame_slot): the last chunks of frame i -- every persistent wave spends its final ~0.4 ms with
+    // ever fewer live lanes -- run beside the first chunks of frame i + 1, launched on another stream into another set, and the resolve
+    // pass of frame i (which finds no free wave slot while frame i + 1 fills the chip) beside the first chunks of frame i + 2.
+    // slot_done[k]: recorded behind the last launch that used set k; a launch waits for it first, so renders of one slot are ordered
+    // by the library whatever streams they come on, and launches that use the scene's singletons (ray counters, wavefront arrays,
+    // strata-split buffers) wait for, and record into, both.
+    DevBuf<float4> rad[JTX_MI_FRAME_SLOTS];
+    hipEvent_t slot_done[JTX_MI_FRAME_SLOTS] = {};
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (kWorkRing, used round-robin)
     unsigned work_slot = 0;
     unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
@@ -202,7 +210,9 @@ struct jtx_mi_scene {
     float ms_by_kind[5] = {0, 0, 0, 0, 0};   // generate, trace-closest, shade, trace-any, resolve (profiled renders)
     int   n_by_kind[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;     // timing pairs of the launches since the last jtx_mi_kernel_time
+    std::vector<unsigned long long *> pending_clock;                         // ... and, for k_render_paths launches, their in-kernel clock pair (else null)
+    DevBuf<unsigned long long> clocks;                                       // 2 per chunk counter of the work ring
     size_t device_bytes = 0;
     int device = 0;
     std::mutex mu;
@@ -214,6 +224,7 @@ struct jtx_mi_scene {
     ~jtx_mi_scene() {
         for (auto &e : pending) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         for (auto &e : free_events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+        for (auto &e : slot_done) if (e) (void) hipEventDestroy(e);
         if (stream) (void) hipStreamDestroy(stream);
         if (stop_host) (void) hipHostFree(stop_host);
         if (mesh_xf_pinned) (void) hipHostFree(mesh_xf_pinned);
@@ -871,6 +882,28 @@ void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_m
 // One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
                   float *d_acc, unsigned char *d_img, hipStream_t stream) {
+    const int slot = o.frame_slot;
+    if (slot < 0 || slot >= JTX_MI_FRAME_SLOTS) throw std::runtime_error("frame_slot: 0 .. " + std::to_string(JTX_MI_FRAME_SLOTS - 1));
+    if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (HBM wavefront)");
+    if (o.path_integrator < 0 || o.path_integrator > 2) throw std::runtime_error("path_integrator: 0 integrateMIS, 1 integrate, 2 integrateBasic");
+    if (o.path_integrator == 1 && s.dev.num_lights == 0)
+        throw std::runtime_error("integrate (integrator.cpp:85) indexes scene.lights without a guard: the scene needs at least one light");
+    const int integ = o.integrator != 0 ? o.integrator : autoIntegrator(s);
+    const bool count = o.count_rays != 0;
+    const bool alt = o.path_integrator != 0 || (s.dev.material_mask & 16) != 0;
+    // uncounted launches: dynamic path assignment (k_render_paths: a wave hands the paths of its pixel block x strata
+    // range to whichever lane is free); JTX_DYNAMIC_PATHS=0 and the counting launches: one lane per pixel
+    static const int dynamicPaths = [] { const char *e = getenv("JTX_DYNAMIC_PATHS"); return e ? atoi(e) : 1; }();
+    for (auto &e : s.slot_done) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // only the persistent path kernel keeps its working memory per slot; everything else uses per-scene singletons
+    const bool slotted = !alt && integ == 1 && dynamicPaths && !count;
+    struct SlotFence {               // wait before, record behind -- also when the launch throws half way (what was enqueued still runs)
+        jtx_mi_scene &s; hipStream_t st; int slot; bool both;
+        SlotFence(jtx_mi_scene &s_, hipStream_t st_, int slot_, bool both_) : s(s_), st(st_), slot(slot_), both(both_) {
+            for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) if (both || k == slot) HIPCHK(hipStreamWaitEvent(st, s.slot_done[k], 0));
+        }
+        ~SlotFence() { for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) if (both || k == slot) (void) hipEventRecord(s.slot_done[k], st); }
+    } fence(s, stream, slot, !slotted);
     RenderParams p{};
     s.last_work = nullptr;            // only a launch that owns a chunk counter arms passAbandoned() (a stale one would void later passes)
     s.pass_parts.clear(); s.pass_resolved_end = se;
@@ -887,7 +920,6 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
     p.acc = d_acc; p.img = d_img;
     p.stop = s.stop_dev;
-    const bool count = o.count_rays != 0;
     if (count) {
         if (!s.counters.p) s.counters.alloc(64);
         HIPCHK(hipMemsetAsync(s.counters.p, 0, 64 * sizeof(unsigned long long), stream));
@@ -896,17 +928,10 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     if (s.counters.n < 64 + 2 * 65536) { s.counters.alloc(64 + 2 * 65536); HIPCHK(hipMemsetAsync(s.counters.p, 0, (64 + 2 * 65536) * sizeof(unsigned long long), stream)); }
 #endif
     p.counters = s.counters.p;
-    if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (HBM wavefront)");
-    int integ = o.integrator;
-    if (integ == 0) integ = autoIntegrator(s);
     // timing pairs are only drained by jtx_mi_kernel_time (bench / tools): a UI that never asks keeps the newest 64
     while (s.pending.size() >= 64 && hipEventQuery(s.pending.front().second) == hipSuccess) {
-        s.free_events.push_back(s.pending.front()); s.pending.erase(s.pending.begin());
+        s.free_events.push_back(s.pending.front()); s.pending.erase(s.pending.begin()); s.pending_clock.erase(s.pending_clock.begin());
     }
-    if (o.path_integrator < 0 || o.path_integrator > 2) throw std::runtime_error("path_integrator: 0 integrateMIS, 1 integrate, 2 integrateBasic");
-    const bool alt = o.path_integrator != 0 || (s.dev.material_mask & 16) != 0;
-    if (o.path_integrator == 1 && s.dev.num_lights == 0)
-        throw std::runtime_error("integrate (integrator.cpp:85) indexes scene.lights without a guard: the scene needs at least one light");
     auto ev = takeEvents(s);
     struct EvReturn { jtx_mi_scene &s; std::pair<hipEvent_t, hipEvent_t> ev; bool armed = true;
                       ~EvReturn() { if (armed) s.free_events.push_back(ev); } } evGuard{s, ev};   // a throw below must not leak the pair
@@ -915,9 +940,10 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     if (owned == 0) {                 // a shard without tiles (more ranks than 32x32 tiles): nothing to launch, an empty timing pair
         HIPCHK(hipEventRecord(ev.second, stream));
         evGuard.armed = false;
-        s.pending.push_back(ev);
+        s.pending.push_back(ev); s.pending_clock.push_back(nullptr);
         return;
     }
+    unsigned long long *launchClock = nullptr;
     if (alt) {
         HIPCHK(jtx_launch_render_alt(p, owned, count, o.path_integrator, stream));
     } else if (integ == 1) {
@@ -929,16 +955,24 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         { const char *e = getenv("JTX_STRATA_GROUPS"); if (e) groups = atoi(e); else if (waves < (long) s.num_cus * 24) groups = 64; else if (waves < (long) s.num_cus * 96) groups = 32; }
         if (groups < 1) groups = 1;
         if (groups > se - sb) groups = se - sb;
-        // uncounted launches: dynamic path assignment (k_render_paths: a wave hands the paths of its pixel block x strata
-        // range to whichever lane is free); JTX_DYNAMIC_PATHS=0 and the counting launches: one lane per pixel
-        static const int dynamicPaths = [] { const char *e = getenv("JTX_DYNAMIC_PATHS"); return e ? atoi(e) : 1; }();
-        if (dynamicPaths && !count) {
+        if (slotted) {
             // chunk = (8x8 pixel block, strata group) = 64 x strata paths, fetched by persistent waves: ~250 k chunks per
             // launch keep the end of the launch short at every shard size (C2: 1 group 44.2 ms, 8 groups 38.1 ms;
-            // 1/8 shard: 64 groups 5.5 ms): the smallest power of two that gives that many, at most one group per stratum
+            // 1/8 shard: 64 groups 5.5 ms): the smallest power of two that gives that many, at most one group per stratum.
+            // With ANOTHER FRAME OF THIS SCENE IN FLIGHT (a launch in another frame slot that has not finished) the end of this launch
+            // is filled by the next one, and the kernels that stage the scene in LDS do better with FEWER, LARGER chunks (fewer
+            // fetches: a fetch stalls the wave for the counter's round trip): ~6 chunks per persistent wave, at least 512 paths each
+            // (profiles/r05_frames_in_flight.md: C2 26.5 against 27.8 ms, a 1/8 shard 3.43 against 4.06 = 1/8 of the frame's kernel time)
             if (!getenv("JTX_STRATA_GROUPS")) {
+                bool pipelined = false;
+                for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) if (k != slot && hipEventQuery(s.slot_done[k]) == hipErrorNotReady) pipelined = true;
+                (void) hipGetLastError();
                 groups = 1;
-                while ((long) groups * waves < 250000 && groups * 2 <= se - sb) groups *= 2;
+                if (pipelined && s.dev.lds_threaded) {
+                    int bs = 0; const long pw = (long) jtx_render_paths_grid(s.dev, s.num_cus, &bs) * (bs / 64);
+                    while ((long) groups * waves < 6 * pw && groups * 2 <= se - sb && (se - sb) / (groups * 2) >= 8) groups *= 2;
+                } else
+                    while ((long) groups * waves < 250000 && groups * 2 <= se - sb) groups *= 2;
             }
             p.rad_stride = owned * 1024;
             // the per-path radiance buffer holds (strata of a pass) x (owned pixels) x 16 B: a frame that would need more
@@ -948,11 +982,12 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             const long perPass = (long) (maxRad / ((size_t) p.rad_stride * sizeof(float4)));
             const int chunk = perPass >= se - sb ? se - sb : (perPass > 1 ? (int) perPass : 1);
             const size_t need = (size_t) p.rad_stride * (size_t) chunk;
-            if (s.rad.n < need || s.rad.n / 4 > need) {                     // grow, and give memory back when the frame shrank a lot
-                if (s.rad.p) HIPCHK(hipStreamSynchronize(stream));           // (a pass in flight may still write the old buffer)
-                s.rad.alloc(need);
+            DevBuf<float4> &rad = s.rad[slot];
+            if (rad.n < need || rad.n / 4 > need) {                         // grow, and give memory back when the frame shrank a lot
+                if (rad.p) HIPCHK(hipStreamSynchronize(stream));             // (a pass in flight may still write the old buffer: this stream waits for slot_done)
+                rad.alloc(need);
             }
-            p.rad = s.rad.p;
+            p.rad = rad.p;
             // one chunk counter per launch: a pass split into several launches (radiance buffer cap) and the pass pipelined behind it
             // must never share one (passAbandoned() reads them per part) -- a ring of kWorkRing, at most half of it per pass
             const int nparts = (se - sb + chunk - 1) / chunk;
@@ -966,9 +1001,13 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.strata_per_group = (q.sample_end - q.sample_begin + g - 1) / g;
                 q.num_groups = (q.sample_end - q.sample_begin + q.strata_per_group - 1) / q.strata_per_group;
                 q.num_subblocks = owned * 16;
-                if (!s.work.p) s.work.alloc(kWorkRing);
-                q.work = s.work.p + (s.work_slot++ & (kWorkRing - 1));    // one counter per launch in flight
+                if (!s.work.p) { s.work.alloc(kWorkRing); s.clocks.alloc(2 * kWorkRing); }
+                const unsigned ring = s.work_slot++ & (kWorkRing - 1);
+                q.work = s.work.p + ring;                                  // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
+                q.clock = s.clocks.p + 2 * ring;                           // (a pass split by the radiance cap: the clock of its last launch)
+                HIPCHK(hipMemsetAsync(q.clock, 0xff, 2 * sizeof(unsigned long long), stream));
+                launchClock = q.clock;
                 s.last_work = q.work;
                 s.pass_parts.push_back({q.work, q.sample_begin, q.sample_end});
                 HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
@@ -979,8 +1018,8 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             p.strata_per_group = (se - sb + groups - 1) / groups;
             p.rad_stride = owned * 1024;
             const size_t need = (size_t) p.rad_stride * (size_t) (se - sb);
-            if (s.rad.n < need) s.rad.alloc(need);
-            p.rad = s.rad.p;
+            if (s.rad[0].n < need) { if (s.rad[0].p) HIPCHK(hipStreamSynchronize(stream)); s.rad[0].alloc(need); }
+            p.rad = s.rad[0].p;
             HIPCHK(jtx_launch_render_pixels(p, owned, count, stream));
             HIPCHK(jtx_launch_resolve_samples(p, owned, stream));
         } else {
@@ -990,7 +1029,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
     if (!evClosed) HIPCHK(hipEventRecord(ev.second, stream));
     evGuard.armed = false;
-    s.pending.push_back(ev);
+    s.pending.push_back(ev); s.pending_clock.push_back(launchClock);
 }
 
 } // namespace
@@ -1439,13 +1478,21 @@ int jtx_mi_kernel_time(jtx_mi_scene *s, float *ms_total, int32_t *launches) {
         std::lock_guard<std::mutex> lk(s->mu);
         DeviceGuard dg(s->device);
         float total = 0; int n = 0;
-        for (auto &e : s->pending) {
+        for (size_t i = 0; i < s->pending.size(); ++i) {
+            auto &e = s->pending[i];
             HIPCHK(hipEventSynchronize(e.second));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+            // a k_render_paths launch carries its own clocks (first wave in, last wave out; wall_clock64 ticks at 100 MHz): with several
+            // frames of the scene in flight the event pair also times the wait for free wave slots, the clocks do not
+            if (s->pending_clock[i]) {
+                unsigned long long c[2] = {~0ull, ~0ull};
+                HIPCHK(hipMemcpy(c, s->pending_clock[i], sizeof c, hipMemcpyDeviceToHost));
+                if (c[0] != ~0ull && c[1] != ~0ull && ~c[1] >= c[0]) ms = (float) ((double) (~c[1] - c[0]) * 1e-5);
+            }
             total += ms; ++n;
             s->free_events.push_back(e);
         }
-        s->pending.clear();
+        s->pending.clear(); s->pending_clock.clear();
         if (ms_total) *ms_total = total;
         if (launches) *launches = n;
         return 0;

@@ -29,6 +29,10 @@ struct RenderParams {
     // word; persistent waves read it whenever they fetch a chunk and stop handing out paths, k_resolve_samples then leaves
     // the film as the last completed pass left it
     const unsigned *stop;
+    // k_render_paths: when and until when the launch really ran -- [0] = min over its waves of wall_clock64() at entry, [1] = min of
+    // ~wall_clock64() at exit (both words start as all ones); or null.  With several frames of a scene in flight an event pair on the
+    // launch stream also times the wait for free wave slots; this does not (it is what rocprofv3's kernel trace shows).
+    unsigned long long *clock;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----

@@ -20,6 +20,7 @@ import numpy as np
 from . import _capi as capi
 
 TILE = 32
+FRAME_SLOTS = 3            # jtx_mi.h: JTX_MI_FRAME_SLOTS
 
 
 def tile_owner_mask(width, height, rank, world):
@@ -36,10 +37,11 @@ def owned_tiles(width, height, rank, world):
 
 
 def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count_rays=False,
-                 sample_begin=0, sample_end=0, integrator=0, profile_kernels=False):
+                 sample_begin=0, sample_end=0, integrator=0, profile_kernels=False, frame_slot=0):
     """Launch this rank's share of the frame into device tensors `acc` (H*W*3 f32) / `img` (H*W*3 u8).
 
-    Asynchronous on `stream` (an int hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).
+    Asynchronous on `stream` (an int hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).  `frame_slot` 0 / 1: two frames of
+    one scene may be in flight, one per slot, on two streams and into two pairs of film buffers (jtx_mi.h: jtx_mi_render_opts).
     """
     lib = capi.load()
     o = capi.RenderOpts()
@@ -48,6 +50,7 @@ def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count
     o.sample_begin, o.sample_end = sample_begin, sample_end
     o.integrator = integrator
     o.reserved = 1 if profile_kernels else 0
+    o.frame_slot = frame_slot
     capi.check(lib.jtx_mi_render_device(scene.handle, C.byref(cam_desc), C.byref(o),
                                         C.c_void_p(acc.data_ptr()),
                                         C.c_void_p(img.data_ptr()) if img is not None else None,
@@ -153,50 +156,84 @@ class FrameGather:
 
 
 class ShardPipeline:
-    """Frame loop of one rank with the exchange overlapped: frame i is gathered on a side stream while frame i + 1
-    renders into the other pair of shard buffers; on `dst` frames are assembled in buffers of their own
-    (`frame_acc`, `frame_img`).  `step()` only enqueues; `torch.cuda.synchronize()` (or the events) completes it."""
+    """Frame loop of one rank with SEVERAL FRAMES IN FLIGHT: frame i + 1 is launched on another render stream, into another pair of
+    shard buffers and another of the scene's frame slots (jtx_mi_render_opts.frame_slot), while frame i's last chunks still run --
+    every persistent wave ends with ever fewer live lanes: ~0.4 ms, 10 % of a 1/8 shard --, and frame i's resolve pass, which finds
+    no free wave slot while frame i + 1 fills the chip, runs beside the first chunks of frame i + 2 (hence three slots); with a
+    `gatherer` (N > 1) frame i is then packed and gathered on a side stream, and on `dst` frames are assembled in buffers of their
+    own (`frame_acc`, `frame_img`).  The workers of StaticCamera::render never wait for a frame boundary either (camera.cpp:53-64, 81-123).
+    `step()` only enqueues; `torch.cuda.synchronize()` (or the events) completes it.  Without a gatherer (one rank) the finished frame
+    of step k is in `accs[k % len(accs)]` / `imgs[k % len(accs)]`.  `timing=True` (or start_timing()) keeps a pair of timing events per frame around
+    the exchange for exchange_ms(); off by default -- a long-running loop must not pile up live events nobody reads."""
 
-    def __init__(self, scene, cam_desc, rank, world, device, gatherer, integrator=0):
+    def __init__(self, scene, cam_desc, rank, world, device, gatherer=None, integrator=0, timing=False, frames_in_flight=FRAME_SLOTS):
         import torch
         self.scene, self.cam, self.rank, self.world, self.integrator = scene, cam_desc, rank, world, integrator
         self.gatherer = gatherer
         n = cam_desc.width * cam_desc.height * 3
-        self.accs = [torch.zeros(n, dtype=torch.float32, device=device) for _ in range(2)]
-        self.imgs = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(2)]
-        on_dst = rank == gatherer.dst
+        nb = max(2, min(FRAME_SLOTS, int(frames_in_flight)))          # buffer sets: one per frame in flight (two also for one stream: the exchange reads one)
+        self.accs = [torch.zeros(n, dtype=torch.float32, device=device) for _ in range(nb)]
+        self.imgs = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(nb)]
+        on_dst = gatherer is not None and rank == gatherer.dst
         self.frame_acc = torch.zeros(n, dtype=torch.float32, device=device) if on_dst else None
         self.frame_img = torch.zeros(n, dtype=torch.uint8, device=device) if on_dst else None
-        self.xstream = torch.cuda.Stream(device=device)
-        self.rendered = [torch.cuda.Event(), torch.cuda.Event()]
-        self.exchanged = [torch.cuda.Event(), torch.cuda.Event()]
+        # frames_in_flight = 1: both buffer pairs on ONE render stream and one frame slot (round 4's loop: only the exchange overlaps)
+        self.rstreams = [torch.cuda.Stream(device=device) for _ in range(nb if frames_in_flight > 1 else 1)]
+        self.xstream = torch.cuda.Stream(device=device) if gatherer is not None else None
+        self.rendered = [torch.cuda.Event() for _ in range(nb)]
+        self.exchanged = [torch.cuda.Event() for _ in range(nb)]
         self.n = 0
-        self.timed = []                  # per frame: (event before, event after) the exchange on the side stream
+        self.timing = bool(timing)
+        self.timed = []                  # (timing only) per frame: (event before, event after) the exchange on the side stream
+        self._ms, self._nms = 0.0, 0
+
+    def start_timing(self):
+        self.timing = True
+        self.reset_timing()
 
     def reset_timing(self):
         self.timed = []
+        self._ms, self._nms = 0.0, 0
+
+    def _fold(self, keep=0):
+        """completed event pairs -> running sum (bounded memory: at most `keep` + the pairs still in flight stay alive)"""
+        while len(self.timed) > keep and self.timed[0][1].query():
+            a, b = self.timed.pop(0)
+            self._ms += a.elapsed_time(b); self._nms += 1
 
     def exchange_ms(self):
-        """average device time of one frame's exchange (pack + gather + scatter on the side stream) since reset_timing();
-        call after torch.cuda.synchronize().  None before the first frame."""
-        if not self.timed:
-            return None
-        return sum(a.elapsed_time(b) for a, b in self.timed) / len(self.timed)
+        """average device time of one frame's exchange (pack + gather + scatter on the side stream) since reset_timing() /
+        start_timing(); call after torch.cuda.synchronize().  None before the first timed frame."""
+        self._fold()
+        return self._ms / self._nms if self._nms else None
 
-    def step(self, render_stream):
-        """`render_stream`: a non-default torch.cuda.Stream the shard kernel is launched on"""
+    def wait(self, stream):
+        """make `stream` wait for everything enqueued so far (both render streams and the exchange)"""
         import torch
-        b = self.n % 2
+        for st in self.rstreams + ([self.xstream] if self.xstream is not None else []):
+            e = torch.cuda.Event(); e.record(st); stream.wait_event(e)
+
+    def step(self, render_stream=None):
+        """enqueue one frame.  (`render_stream`: accepted for round 4's signature; the pipeline renders on streams of its own)"""
+        import torch
+        b = self.n % len(self.accs)
         self.n += 1
-        render_stream.wait_event(self.exchanged[b])          # the exchange two frames back has read this pair
+        rs = self.rstreams[b % len(self.rstreams)]
+        if self.gatherer is not None:
+            rs.wait_event(self.exchanged[b])                 # the exchange two frames back has read this pair
         render_shard(self.scene, self.cam, self.rank, self.world, self.accs[b], self.imgs[b],
-                     stream=render_stream.cuda_stream, integrator=self.integrator)
-        self.rendered[b].record(render_stream)
+                     stream=rs.cuda_stream, integrator=self.integrator, frame_slot=b % len(self.rstreams))
+        self.rendered[b].record(rs)
+        if self.gatherer is None:
+            return
         with torch.cuda.stream(self.xstream):
             self.xstream.wait_event(self.rendered[b])
-            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0.record(self.xstream)
+            if self.timing:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.xstream)
             self.gatherer.collect(self.accs[b], self.imgs[b], self.frame_acc, self.frame_img)
-            t1.record(self.xstream)
+            if self.timing:
+                t1.record(self.xstream)
+                self.timed.append((t0, t1))
+                self._fold(keep=64)
             self.exchanged[b].record(self.xstream)
-            self.timed.append((t0, t1))

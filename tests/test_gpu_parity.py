@@ -758,18 +758,33 @@ def _pipeline_worker(rank, world, port, out_dir):
         data = jtx.scenes.cornell()
         sc = jtx.Scene(data); sc.buildBVH()
         W, H = 200, 136
-        cam = data.camera_desc(W, H, 2, 2, 4)
+        # two views taking turns, so that consecutive frames (in flight together, one per frame slot) differ
+        views = []
+        for yfov in (39.3077, 55.0):
+            c = dict(data.camera); c["yfov"] = yfov
+            data.camera = c
+            views.append((c, data.camera_desc(W, H, 2, 2, 4)))
         fg = jtx.distributed.FrameGather(W, H, rank, world, dev)
-        pipe = jtx.distributed.ShardPipeline(sc, cam, rank, world, dev, fg, integrator=1)
-        st = torch.cuda.Stream(device=dev)
-        for _ in range(5):                                   # odd count: both buffer pairs and the hand-over get used
-            pipe.step(st)
+        pipe = jtx.distributed.ShardPipeline(sc, views[0][1], rank, world, dev, fg, integrator=1, timing=True)
+        assert len(pipe.rstreams) == jtx.distributed.FRAME_SLOTS == 3
+        nframes = 7                                          # odd: both buffer pairs, both slots and the hand-over get used
+        hist_a = [torch.zeros_like(pipe.accs[0]) for _ in range(nframes)] if rank == 0 else None
+        hist_i = [torch.zeros_like(pipe.imgs[0]) for _ in range(nframes)] if rank == 0 else None
+        for k in range(nframes):
+            pipe.cam = views[k % 2][1]
+            pipe.step()
+            if rank == 0:                                    # keep every assembled frame: a copy behind its exchange, on the exchange stream
+                with torch.cuda.stream(pipe.xstream):
+                    hist_a[k].copy_(pipe.frame_acc); hist_i[k].copy_(pipe.frame_img)
         torch.cuda.synchronize()
         dist.barrier()
         if rank == 0:
-            full = jtx.StaticCamera(W, H, data.camera, 2, 2, 4); full.render(sc, integrator=1)
-            a = pipe.frame_acc.cpu().numpy().reshape(H, W, 3); i = pipe.frame_img.cpu().numpy().reshape(H, W, 3)
-            ok = np.array_equal(a.view(np.uint32), full.acc_.view(np.uint32)) and np.array_equal(i, full.img_)
+            ok = pipe.exchange_ms() is not None and len(pipe.timed) == 0
+            for v, (cdict, _) in enumerate(views):
+                full = jtx.StaticCamera(W, H, cdict, 2, 2, 4); full.render(sc, integrator=1)
+                for k in range(v, nframes, 2):
+                    a = hist_a[k].cpu().numpy().reshape(H, W, 3); i = hist_i[k].cpu().numpy().reshape(H, W, 3)
+                    ok = ok and np.array_equal(a.view(np.uint32), full.acc_.view(np.uint32)) and np.array_equal(i, full.img_)
             open(os.path.join(out_dir, "result"), "w").write("ok" if ok else "mismatch")
         dist.barrier()
     finally:
@@ -777,13 +792,62 @@ def _pipeline_worker(rank, world, port, out_dir):
 
 
 def test_shard_pipeline_two_rank_rehearsal(gpu, tmp_path):
-    """ShardPipeline (bench.py's N > 1 frame loop: exchange of frame i on a side stream while frame i + 1 renders into
-    the other buffer pair) with two processes sharing this GPU: rank 0's assembled frame equals the 1-GPU frame."""
+    """ShardPipeline (bench.py's frame loop: two frames in flight -- frame i + 1 launched on the other render stream and frame slot
+    while frame i's tail and resolve run -- and the exchange of frame i on a side stream) with two processes sharing this GPU: EVERY
+    one of rank 0's 7 consecutive assembled frames (two views taking turns) equals the 1-GPU frame of its view, bit for bit."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "result").read() == "ok"
+
+
+@pytest.mark.parametrize("which", ["cornell", "atrium"])
+def test_two_frames_in_flight_on_one_rank(gpu, which):
+    """jtx_mi_render_opts.frame_slot: consecutive frames of ONE scene on three streams, in the scene's three frame slots, each into film
+    buffers of its own (what bench.py times at N = 1) -- 8 frames of four views taking turns, every frame kept by a copy on its own
+    render stream, each bit-identical to the frame of its view rendered alone; then a counting launch (the scene's singletons: ordered
+    against ALL slots by the library) straight behind the frames in flight gives the one-frame counters."""
+    import torch
+    data = gpu.scenes.cornell() if which == "cornell" else gpu.scenes.atrium(target_tris=6000)
+    sc = gpu.Scene(data); sc.buildBVH()
+    W, H = 328, 200
+    views = []
+    for dy in (0.0, 11.0, -7.0, 23.0):
+        c = dict(data.camera); c["center"] = (c["center"][0], c["center"][1] + dy, c["center"][2])
+        data.camera = c
+        views.append((c, data.camera_desc(W, H, 2, 2, 5)))
+    dev = torch.device("cuda", 0)
+    pipe = gpu.distributed.ShardPipeline(sc, views[0][1], 0, 1, dev, None, integrator=1)
+    nb = len(pipe.rstreams)
+    assert nb == gpu.distributed.FRAME_SLOTS == 3 and pipe.xstream is None
+    n = 8
+    hist_a = [torch.zeros_like(pipe.accs[0]) for _ in range(n)]; hist_i = [torch.zeros_like(pipe.imgs[0]) for _ in range(n)]
+    for k in range(n):
+        pipe.cam = views[k % 4][1]
+        pipe.step()
+        with torch.cuda.stream(pipe.rstreams[k % nb]):
+            hist_a[k].copy_(pipe.accs[k % nb]); hist_i[k].copy_(pipe.imgs[k % nb])
+    # a counted frame right behind them, on a third stream: it must wait for both slots (it uses the scene's ray counters)
+    st = torch.cuda.Stream(device=dev)
+    acc = torch.zeros_like(pipe.accs[0]); img = torch.zeros_like(pipe.imgs[0])
+    gpu.distributed.render_shard(sc, views[0][1], 0, 1, acc, img, stream=st.cuda_stream, count_rays=True, integrator=1)
+    torch.cuda.synchronize()
+    import ctypes as C
+    cnt = gpu._capi.Counters(); gpu._capi.check(gpu._capi.load().jtx_mi_get_counters(sc.handle, C.byref(cnt)))
+    for v, (cdict, _) in enumerate(views):
+        full = gpu.StaticCamera(W, H, cdict, 2, 2, 5); full.render(sc, count_rays=(v == 0), integrator=1)
+        if v == 0:
+            assert cnt.as_dict() == full.counters
+            assert np.array_equal(acc.cpu().numpy().view(np.uint32).reshape(H, W, 3), full.acc_.view(np.uint32))
+        for k in range(v, n, 4):
+            a = hist_a[k].cpu().numpy().reshape(H, W, 3); i = hist_i[k].cpu().numpy().reshape(H, W, 3)
+            assert np.array_equal(a.view(np.uint32), full.acc_.view(np.uint32)), f"frame {k} (view {v}) differs"
+            assert np.array_equal(i, full.img_), f"frame {k} (view {v}): RGB8 differs"
+    # frame_slot is validated
+    with pytest.raises(gpu.JtxMiError):
+        gpu.distributed.render_shard(sc, views[0][1], 0, 1, acc, img, stream=st.cuda_stream, frame_slot=gpu.distributed.FRAME_SLOTS)
+    sc.destroy()
 
 
 @pytest.mark.parametrize("lightdir", [(1e-6, -1.0, 3e-7), (-2e-9, -1.0, 1e-10), (0.3, -1e-5, -0.9)])
@@ -1578,7 +1642,9 @@ def test_bench_times_a_scene_file_and_the_extra_workload_path(gpu, tmp_path):
     st = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(st):
         e = bench.time_workload(gpu, torch, dev, st, name, data, dims, steps=2, warmup=1)
-    assert e["rays_per_frame"] > 3e8 and e["scene_triangles"] == 32 and e["kernel_ms"] > 1.0 and e["kernel_ms"] <= e["ms_per_step"]
+    # (kernel_ms: launches with one frame in flight; ms_per_step: the pipelined loop, resolve pass included -- faster per frame than a lone launch + resolve)
+    assert e["rays_per_frame"] > 3e8 and e["scene_triangles"] == 32 and e["kernel_ms"] > 1.0 and e["frames_in_flight"] == 3
+    assert e["ms_per_step"] <= e["kernel_ms"] * 1.03 + 0.5 and e["in_flight"]["useful_frac"] >= e["useful_frac"] * 0.97
     assert abs(e["value"] - e["rays_per_frame"] / (e["ms_per_step"] * 1e-3) / 1e6) / e["value"] < 1e-3
     assert 0.05 < e["useful_frac"] < 0.4 and e["frac"] is None             # a file scene has no recorded counters: only the counter-free fraction
 
