@@ -197,29 +197,100 @@ def algorithmic_bytes(c):
 
 
 # Useful work of the REFERENCE's algorithm, per counted event, in fp32 lane-operations (one add / sub / mul / div / min / max /
-# compare / abs / sqrt = 1; integer RNG / hashing and address arithmetic = 0; derivation from the reference's source in
-# DESIGN.md section 6).  Minimal forms: 1/d once per ray, baked triangle edges, one shading-normal interpolation per path
-# vertex -- what any implementation of the same mathematics must do, NOT what this kernel issues: phase A's box tests of
+# compare / sqrt = 1; abs / negate are operand modifiers = 0; integer RNG / hashing and address arithmetic = 0; derivation from the
+# reference's source in DESIGN.md section 6).  Minimal forms: 1/d once per ray, baked triangle edges, one shading-normal interpolation
+# per path vertex -- what any implementation of the same mathematics must do, NOT what this kernel issues: phase A's box tests of
 # leaves the reference never visits, scheduling ballots, spill code and idle lanes all LOWER the fraction built on it.
-USEFUL_OPS = {
-    "ray": 6,          # 3 divisions 1/d + 3 sign tests (scene.cpp:11-12), per closestHit / anyHit call
-    "node": 25,        # AABB::hit aabb.hpp:66-81: per axis 2 sub, 2 mul, min, max (18); t0 = max of 4, t1 = min of 4 (6); t0 <= t1 (1)
-    "tri": 55,         # Moeller-Trumbore run to the end, mesh.hpp:106-127 / 168-192: cross 9, dot 5, |det| test 2, 1/det 1, tvec 3,
-                       #   b1 6 + 2 tests, cross 9, b2 6 + add + 2 tests, t 6 + 2 interval tests (most tests leave earlier: upper bound per test)
-    "shade": 242,      # one Lambert vertex of integrateMIS (integrator.cpp:171-216) whose light sample is occluded: hit point + normal / uv
-                       #   interpolation + face-forward 42 (mesh.hpp:129-145), Light::sample 26 + shadow-ray set-up 16 + rng floats 10,
-                       #   Frame::fromZ + toLocal 31, cosine-hemisphere sample incl. sin / cos 60, pdf / f / checks 12, toWorld 15,
-                       #   beta update 15, radiance add 6, next ray 6, wo 3.  The unoccluded branch (evalBxdf + pdfBxdf + MIS weight,
-                       #   another 129) and the dearer BxDFs are NOT counted -- the counters do not separate them: a lower bound
-    "camera": 40,      # Camera::getRay camera.hpp:127-139 (stratum offsets 8, viewport point 14, direction 3, rng floats 6) + clamp
-                       #   and accumulate camera.cpp:110-112 / image.hpp:82-86 (9)
+# Every entry is (fast, slow, transcendental): how many of the operations are add / sub / mul (2.4 issue cycles per wave64 instruction
+# on gfx950, profiles/r03_valu_rates.txt), min / max / compare / convert (4.4) and divide / sqrt (8.4, priced as ONE reciprocal-class
+# instruction each) -- the split that `useful_frac_attainable` prices.
+USEFUL_MIX = {
+    "ray": (0, 3, 3),        # 3 divisions 1/d + 3 sign tests (scene.cpp:11-12), per closestHit / anyHit call
+    "node": (12, 13, 0),     # AABB::hit aabb.hpp:66-81: per axis 2 sub, 2 mul (12), min, max (6); t0 = max of 4, t1 = min of 4 (6); t0 <= t1 (1)
+    "tri": (45, 9, 1),       # Moeller-Trumbore run to the end, mesh.hpp:106-127 / 168-192: cross 9, dot 5, |det| test 1, 1/det 1, tvec 3,
+                             #   b1 6 + 2 tests, cross 9, b2 6 + add + 2 tests, t 6 + 2 interval tests (most tests leave earlier: upper bound per test)
+    "camera": (34, 4, 2),    # Camera::getRay camera.hpp:127-139 (stratum offsets 8, viewport point 14, direction 3, rng floats 6) + clamp
+                             #   and accumulate camera.cpp:110-112 / image.hpp:82-86 (9)
+    # one vertex of integrateMIS (integrator.cpp:171-216), whatever its material: hit point + normal / uv interpolation + face-forward 42
+    # (mesh.hpp:129-145), Light::sample 26 + shadow-ray set-up 16 + rng floats 10 (integrator.cpp:134-150), Frame::fromZ + toLocal 31 and
+    # toWorld 15 (bxdf.cpp:10-12, 75), beta update 15, radiance add 6, next ray 6, wo 3
+    "vertex": (142, 10, 18),
+    # ... and what sampleLights adds when the light is NOT occluded, whatever the material (integrator.cpp:151-166): evalBxdf's and pdfBxdf's
+    # own Frame::fromZ + 2 toLocal each (92, bxdf.cpp:80-82, 131-133), f * absdot 9, pl 2, powerHeuristic 6, misWeight * f * L / pl 9, beta * .. + 6
+    "unoccluded": (112, 5, 7),
 }
+# The BxDF's own share of a vertex, by BxDF class (jtx_mi_counters::n_shade_class): its `sample` (sampleBxdf, bxdf.cpp:9-77) ...
+#   0 DIFFUSE diffuse.hpp:15-22: cosine-hemisphere sample incl. sin / cos 60, pdf / f / checks 12
+#   1 DIELECTRIC rough dielectric.hpp:72-108: sampleWm 130 (microfacet.hpp:86-106), Fresnel 29, then reflection (reflect 12, GGX pdf 91, D G 112:
+#     383) or transmission (refract 26, dn 20, pdf 85, f 118: 419) -- the mean
+#   2 CONDUCTOR rough conductor.hpp:40-59: sampleWm 130, reflect 12, GGX pdf 90, the complex Fresnel term per channel 3 x 88 + 6, D G / (4 ci co) 116
+#   3 METALLIC_ROUGHNESS gltf.hpp:36-90: two lerps 20, specular probability 38, then the GGX lobe (sampleWm 130, reflect 15, pdf 90: 240) or the
+#     cosine lobe (82); Schlick 19, diffuse + specular terms 130 -- the mean of the two lobes
+#   4 ThinDielectric dielectric.hpp:170-200: Fresnel 24, the inter-reflection term 8, one lobe 9
+#   5 DIELECTRIC smooth dielectric.hpp:44-70: Fresnel 24, probabilities 3, reflection 4 or refraction 29 -- the mean
+#   6 CONDUCTOR smooth conductor.hpp:33-38: mirror direction, 3 x 88 Fresnel, / cos
+USEFUL_SAMPLE_CLASS = [72, 400, 627, 371, 41, 45, 272, 0]
+# ... and its `evaluate` + `pdf` when the light sample is not occluded (evalBxdf bxdf.cpp:79-128 + pdfBxdf :130-166):
+#   0: same-hemisphere test, R / pi, cos / pi; 1 dielectric.hpp:110-161: half vector + checks 46, Fresnel 29, D G 111; again 46 + 29 for the pdf + GGX pdf 93;
+#   2 conductor.hpp:8-29, 61-73: half vector 22, Fresnel 270, D G 116; pdf 114; 3 gltf.hpp:14-34, 92-122: eval 191, pdf 158; 4: evaluate = {}, pdf = 0;
+#   5, 6: the smooth tests only
+USEFUL_EVAL_CLASS = [5, 356, 524, 349, 2, 6, 4, 0]
+CLASS_MIX = {0: (0.75, 0.18, 0.07)}       # share of (fast, slow, transcendental) operations in a BxDF's own code: Lambert as counted above ...
+GGX_MIX = (0.78, 0.12, 0.10)              # ... the GGX / Fresnel code is richer in divisions and square roots
+ISSUE_CYCLES = (2.4, 4.4, 8.4)            # per wave64 instruction and SIMD (profiles/r03_valu_rates.txt)
+USEFUL_OPS = {k: sum(v) for k, v in USEFUL_MIX.items()}
+USEFUL_OPS["shade"] = USEFUL_OPS["vertex"] + USEFUL_SAMPLE_CLASS[0]      # (= 242: one occluded Lambert vertex, rounds 2-4's price of EVERY vertex)
+
+
+def useful_events(c):
+    """[(events, (fast, slow, transcendental) operations per event)] of one frame's counters"""
+    ev = [(c["n_closest"] + c["n_any"], USEFUL_MIX["ray"]), (c["n_nodes_closest"] + c["n_nodes_any"], USEFUL_MIX["node"]),
+          (c["n_tri_closest"] + c["n_tri_any"], USEFUL_MIX["tri"]), (c["n_camera"], USEFUL_MIX["camera"]), (c["n_shade"], USEFUL_MIX["vertex"])]
+    sc, ec = c.get("n_shade_class"), c.get("n_eval_class")
+    if sc is None:                     # counters of rounds 1-4 (no per-class tallies): every vertex priced as an occluded Lambert one
+        sc, ec = [c["n_shade"]] + [0] * 7, [0] * 8
+    ev.append((sum(ec), USEFUL_MIX["unoccluded"]))
+    for k in range(8):
+        mix = CLASS_MIX.get(k, GGX_MIX)
+        for n, ops in ((sc[k], USEFUL_SAMPLE_CLASS[k]), (ec[k], USEFUL_EVAL_CLASS[k])):
+            if n and ops:
+                ev.append((n, tuple(ops * m for m in mix)))
+    return ev
 
 
 def useful_lane_ops(c):
-    return (USEFUL_OPS["ray"] * (c["n_closest"] + c["n_any"]) + USEFUL_OPS["node"] * (c["n_nodes_closest"] + c["n_nodes_any"])
-            + USEFUL_OPS["tri"] * (c["n_tri_closest"] + c["n_tri_any"]) + USEFUL_OPS["shade"] * c["n_shade"]
-            + USEFUL_OPS["camera"] * c["n_camera"])
+    return sum(n * sum(mix) for n, mix in useful_events(c))
+
+
+def useful_issue_cycles(c):
+    """SIMD cycles the same operations take at the least when every instruction carries 64 lanes of them and issues at its class's rate"""
+    return sum(n * sum(m * cy for m, cy in zip(mix, ISSUE_CYCLES)) for n, mix in useful_events(c)) / 64.0
+
+
+def flat_counters(c):
+    """{"n_camera": .., "n_shade_class": [..]} -> a flat {name: int} (for the all-reduce over ranks) and back"""
+    out = {}
+    for k, v in c.items():
+        if isinstance(v, (list, tuple)):
+            for i, x in enumerate(v):
+                out[f"{k}#{i}"] = int(x)
+        else:
+            out[k] = int(v)
+    return out
+
+
+def unflat_counters(f):
+    out = {}
+    for k, v in f.items():
+        if "#" in k:
+            name, i = k.split("#")
+            out.setdefault(name, [])
+            while len(out[name]) <= int(i):
+                out[name].append(0)
+            out[name][int(i)] = v
+        else:
+            out[k] = v
+    return out
 
 
 def pmc_file():
@@ -340,8 +411,13 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
     # ---- useful-work fraction: needs no profile, only this frame's device counters and the live kernel time ----
     uops = useful_lane_ops(mine)
     out["useful_frac"] = round(uops / t / 1e12 / lane_peak, 4)
+    # ... against what the chip can issue of THAT operation mix with every lane busy: add / sub / mul at 2.4 cycles per wave64 instruction, min /
+    # max / compares at 4.4, divisions and square roots at 8.4 -- how far from ATTAINABLE the kernel is, where useful_frac measures against fma rate
+    ucyc = useful_issue_cycles(mine)
+    out["useful_frac_attainable"] = round(ucyc / (SIMDS * t * CLK), 4)
     out["useful"] = {"lane_ops_per_launch": int(uops), "achieved": round(uops / t / 1e12, 3), "peak": round(lane_peak, 2),
-                     "unit": "T fp32 lane-ops/s", "per_event": USEFUL_OPS,
+                     "unit": "T fp32 lane-ops/s", "per_event": USEFUL_OPS, "sample_by_class": USEFUL_SAMPLE_CLASS, "eval_by_class": USEFUL_EVAL_CLASS,
+                     "issue_cycles_at_least": int(ucyc), "issue_cycles_per_class": list(ISSUE_CYCLES),
                      "note": "reference-algorithm lane-operations (fixed cost per counted event of the untimed counting pass: rays, node visits, "
                              "triangle tests, shading events, camera samples; DESIGN.md section 6) / kernel time / (CUs x 128 lanes x 2.4 GHz)"}
     pmc = None
@@ -584,11 +660,12 @@ def main():
     cnt = jtx._capi.Counters()
     jtx._capi.check(lib.jtx_mi_get_counters(scene.handle, C.byref(cnt)))
     mine = cnt.as_dict()
-    keys = sorted(mine)
-    tot = torch.tensor([mine[k] for k in keys], dtype=torch.int64, device=dev)
+    flat = flat_counters(mine)
+    keys = sorted(flat)
+    tot = torch.tensor([flat[k] for k in keys], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(tot)
-    total = dict(zip(keys, [int(v) for v in tot.tolist()]))
+    total = unflat_counters(dict(zip(keys, [int(v) for v in tot.tolist()])))
     rays_frame = total["n_closest"] + total["n_any"]
 
     # wavefront: one extra untimed frame with a HIP event pair around every kernel, to find the dominant stage

@@ -134,6 +134,12 @@ typedef struct {
     uint64_t n_camera, n_closest, n_any;
     uint64_t n_nodes_closest, n_tri_closest, n_accept;
     uint64_t n_nodes_any, n_tri_any, n_shade;
+    /* by BxDF class = the code path a material's calls take: 0 DIFFUSE, 1 DIELECTRIC rough, 2 CONDUCTOR rough, 3 METALLIC_ROUGHNESS
+     * (material.hpp:5-23), 4 ThinDielectricBxDF (dielectric.hpp:163-207), 5 DIELECTRIC smooth or index-matched (dielectric.hpp:44),
+     * 6 CONDUCTOR smooth (conductor.hpp:33; smooth: max(alpha) < 1e-3, microfacet.hpp:23-25), 7 unused: sampleBxdf calls (they sum to
+     * n_shade) and evalBxdf + pdfBxdf calls -- in integrateMIS the light samples that were not occluded (integrator.cpp:151-166), in
+     * integrate every light sample with pdf > 0 (:94-101) */
+    uint64_t n_shade_class[8], n_eval_class[8];
 } jtx_mi_counters;
 
 typedef struct {

@@ -67,10 +67,11 @@ class RenderOpts(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_camera", "n_closest", "n_any", "n_nodes_closest", "n_tri_closest",
-                                          "n_accept", "n_nodes_any", "n_tri_any", "n_shade")]
+                                          "n_accept", "n_nodes_any", "n_tri_any", "n_shade")] + \
+               [("n_shade_class", C.c_uint64 * 8), ("n_eval_class", C.c_uint64 * 8)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        return {n: (int(getattr(self, n)) if t is C.c_uint64 else [int(x) for x in getattr(self, n)]) for n, t in self._fields_}
 
 
 class SceneInfo(C.Structure):

@@ -45,6 +45,7 @@ JD bool altBounce(const DevScene &sc, const GlobalSrc &src, int maxDepth, AltPat
             const bool occluded = traverseNoStack<true, COUNT>(src, sc.num_nodes, sOrigin, ls.wi, 0.0f, lDist - RAY_EPSILON, dummy, cnt);
             if (!occluded) {
                 f3 f; float pb;
+                if (COUNT) countClass(cnt.n_eval_t, bxdfClass(mat));
                 evalPdfBxdf<MAT_EVERY>(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
                 f = f * absdot(ls.wi, sf.normal);
                 const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
@@ -60,6 +61,7 @@ JD bool altBounce(const DevScene &sc, const GlobalSrc &src, int maxDepth, AltPat
         LightSample ls;
         if (lightSample(light, sf.point, ls) && ls.pdf > 0.0f) {
             f3 f; float pb;
+            if (COUNT) countClass(cnt.n_eval_t, bxdfClass(mat));                  // (integrate evaluates BEFORE its shadow ray: integrator.cpp:94-101)
             evalPdfBxdf<MAT_EVERY>(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
             f = f * absdot(ls.wi, sf.normal);
             const f3 sOrigin = sf.point + sf.normal * RAY_EPSILON;
@@ -74,7 +76,7 @@ JD bool altBounce(const DevScene &sc, const GlobalSrc &src, int maxDepth, AltPat
     const float u = ps.rng.f();
     f2 u2; u2.x = ps.rng.f(); u2.y = ps.rng.f();
     BSample bs;
-    if (COUNT) cnt.n_shade++;
+    if (COUNT) { cnt.n_shade++; countClass(cnt.n_shade_t, bxdfClass(mat)); }
     if (!sampleBxdf<MAT_EVERY>(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) return true;
     if (LI != 0 || bs.pdf > 0.0f) ps.beta = ps.beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);   // unguarded in integrate / integrateBasic
     ps.specularBounce = bs.specular;                                      // integrator.cpp:126
@@ -127,6 +129,13 @@ __global__ void __launch_bounds__(256) k_render_alt(RenderParams p) {
             unsigned long long sv = v[i];
             for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
             if ((threadIdx.x & 63) == 0 && sv) atomicAdd(&p.counters[i], sv);
+        }
+        const unsigned w[14] = {cnt.n_shade_t[0], cnt.n_shade_t[1], cnt.n_shade_t[2], cnt.n_shade_t[3], cnt.n_shade_t[4], cnt.n_shade_t[5], cnt.n_shade_t[6],
+                                cnt.n_eval_t[0], cnt.n_eval_t[1], cnt.n_eval_t[2], cnt.n_eval_t[3], cnt.n_eval_t[4], cnt.n_eval_t[5], cnt.n_eval_t[6]};
+        for (int i = 0; i < 14; ++i) {
+            unsigned long long sv = w[i];
+            for (int off = 32; off > 0; off >>= 1) sv += __shfl_down(sv, off, 64);
+            if ((threadIdx.x & 63) == 0 && sv) atomicAdd(&p.counters[i < 7 ? CNT_SHADE_T + i : CNT_EVAL_T + i - 7], sv);
         }
     }
 }

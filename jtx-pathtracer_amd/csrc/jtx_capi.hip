@@ -1508,6 +1508,18 @@ int jtx_mi_kernel_time_by_kind(jtx_mi_scene *s, float *ms5, int32_t *n5) {
     return 0;
 }
 
+// the scene's 64-word counter block <-> jtx_mi_counters ([0..8] the nine ray counters, [CNT_SHADE_T..] / [CNT_EVAL_T..] the per-class tallies)
+static void countersAddWords(jtx_mi_counters &c, const unsigned long long *h) {
+    c.n_camera += h[0]; c.n_closest += h[1]; c.n_any += h[2]; c.n_nodes_closest += h[3]; c.n_tri_closest += h[4];
+    c.n_accept += h[5]; c.n_nodes_any += h[6]; c.n_tri_any += h[7]; c.n_shade += h[8];
+    for (int i = 0; i < 8; ++i) { c.n_shade_class[i] += h[CNT_SHADE_T + i]; c.n_eval_class[i] += h[CNT_EVAL_T + i]; }
+}
+static void countersToWords(const jtx_mi_counters &c, unsigned long long *h) {
+    h[0] = c.n_camera; h[1] = c.n_closest; h[2] = c.n_any; h[3] = c.n_nodes_closest; h[4] = c.n_tri_closest;
+    h[5] = c.n_accept; h[6] = c.n_nodes_any; h[7] = c.n_tri_any; h[8] = c.n_shade;
+    for (int i = 0; i < 8; ++i) { h[CNT_SHADE_T + i] = c.n_shade_class[i]; h[CNT_EVAL_T + i] = c.n_eval_class[i]; }
+}
+
 int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
     try {
         if (!s || !out) throw std::runtime_error("null argument");
@@ -1515,10 +1527,10 @@ int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
         DeviceGuard dg(s->device);
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipDeviceSynchronize());
-        unsigned long long h[9];
+        unsigned long long h[64];
         HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
-        out->n_camera = h[0]; out->n_closest = h[1]; out->n_any = h[2]; out->n_nodes_closest = h[3]; out->n_tri_closest = h[4];
-        out->n_accept = h[5]; out->n_nodes_any = h[6]; out->n_tri_any = h[7]; out->n_shade = h[8];
+        *out = jtx_mi_counters{};
+        countersAddWords(*out, h);
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
 }
@@ -1626,11 +1638,9 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
             }
             done = inFlightEnd;
             if (count) {
-                unsigned long long h[9];
+                unsigned long long h[64];
                 HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
-                total.n_camera += h[0]; total.n_closest += h[1]; total.n_any += h[2]; total.n_nodes_closest += h[3];
-                total.n_tri_closest += h[4]; total.n_accept += h[5]; total.n_nodes_any += h[6]; total.n_tri_any += h[7];
-                total.n_shade += h[8];
+                countersAddWords(total, h);
             }
             const bool more = done < se;
             if (more && !count) inFlightEnd = enqueue(done);                   // next pass runs while the host copies / the callback looks
@@ -1663,8 +1673,8 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         lap("acc memcpy");
         s->last_completed = done;
         if (count) {   // leave the frame totals on the device for jtx_mi_get_counters
-            unsigned long long h[9] = {total.n_camera, total.n_closest, total.n_any, total.n_nodes_closest, total.n_tri_closest,
-                                       total.n_accept, total.n_nodes_any, total.n_tri_any, total.n_shade};
+            unsigned long long h[64] = {};
+            countersToWords(total, h);
             HIPCHK(hipMemcpy(s->counters.p, h, sizeof h, hipMemcpyHostToDevice));
         }
         return cancelled ? JTX_MI_CANCELLED : 0;

@@ -63,6 +63,13 @@ JD void waveAddCounters(unsigned long long *g, const Counters9 &c) {
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[i], s);
     }
+    const unsigned w[14] = {c.n_shade_t[0], c.n_shade_t[1], c.n_shade_t[2], c.n_shade_t[3], c.n_shade_t[4], c.n_shade_t[5], c.n_shade_t[6],
+                            c.n_eval_t[0], c.n_eval_t[1], c.n_eval_t[2], c.n_eval_t[3], c.n_eval_t[4], c.n_eval_t[5], c.n_eval_t[6]};
+    for (int i = 0; i < 14; ++i) {
+        unsigned long long s = w[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[i < 7 ? CNT_SHADE_T + i : CNT_EVAL_T + i - 7], s);
+    }
 }
 
 // One bounce of integrateMIS (integrator.cpp:171-216) for the lane's current path.  Returns true
@@ -105,6 +112,7 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &
             PH(2)
             if (!occluded) {
                 f3 f; float pb;
+                if (COUNT) countClass(cnt.n_eval_t, bxdfClass(mat));
                 evalPdfBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, ls.wi, f, pb);
                 f = f * absdot(ls.wi, sf.normal);
                 const float pl = 1.0f / (float) sc.num_lights * ls.pdf;
@@ -121,7 +129,7 @@ JD bool pathBounce(const DevScene &sc, const Src &src, int maxDepth, PathState &
     const float u = ps.rng.f();
     f2 u2; u2.x = ps.rng.f(); u2.y = ps.rng.f();
     BSample bs;
-    if (COUNT) cnt.n_shade++;
+    if (COUNT) { cnt.n_shade++; countClass(cnt.n_shade_t, bxdfClass(mat)); }
     if (!sampleBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) return BOUNCE_DONE;
     if (bs.pdf > 0.0f) ps.beta = ps.beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);
     ps.o = sf.point + bs.wi * RAY_EPSILON;                             // integrator.cpp:212

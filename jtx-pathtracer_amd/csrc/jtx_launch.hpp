@@ -39,7 +39,8 @@ struct RenderParams {
 enum { WF_LIVE = 1, WF_TYPE_SHIFT = 8, WF_TYPE_MASK = 0xf00 };   // flags[]: extension ray pending / hit ready;
                                                                 // bits 8-11: 1 + Material::type of the hit (0 = miss)
 enum { WF_SH_PENDING = 1, WF_SH_UNOCCLUDED = 2,         // sflags[]: shadow ray to trace / traced and unoccluded
-       WF_SH_NF_SHIFT = 4, WF_SH_NF_MASK = 0x70 };       //   bits 4-6: components of beta that were inf/NaN at that vertex
+       WF_SH_NF_SHIFT = 4, WF_SH_NF_MASK = 0x70,         //   bits 4-6: components of beta that were inf/NaN at that vertex
+       WF_SH_TYPE_SHIFT = 8, WF_SH_TYPE_MASK = 0x700 };  //   bits 8-10: BxDF class of that vertex (bxdfClass: the per-class tally of evalBxdf calls)
 
 struct WfBuffers {
     int   *flags;                                   // WF_LIVE

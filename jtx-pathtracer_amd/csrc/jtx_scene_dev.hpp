@@ -44,9 +44,23 @@ struct DevScene {
 
 struct Counters9 {        // per-lane tallies, reduced per wave (count_rays mode only)
     unsigned n_camera, n_closest, n_any, n_nodes_closest, n_tri_closest, n_accept, n_nodes_any, n_tri_any, n_shade;
+    unsigned n_shade_t[8], n_eval_t[8];   // sampleBxdf calls / evalBxdf + pdfBxdf calls by BxDF class (bxdfClass; static indices only: registers)
     JTX_PROF_UTIL_FIELDS         // diagnostic builds only (jtx_profile.hpp); nothing in the product
     JTX_PROF_WIDE_FIELDS
 };
+
+// where the per-type tallies live in the scene's 64-word counter block: [0..8] the nine ray counters, [9..53] diagnostics, then these
+constexpr int CNT_SHADE_T = 32, CNT_EVAL_T = 52;
+// BxDF class of a material = the code path its sampleBxdf / evalBxdf / pdfBxdf calls take (jtx_mi.h: jtx_mi_counters):
+// 0 DIFFUSE, 1 DIELECTRIC rough, 2 CONDUCTOR rough, 3 METALLIC_ROUGHNESS, 4 ThinDielectric, 5 DIELECTRIC smooth or index-matched
+// (dielectric.hpp:44: eta == 1 || smooth), 6 CONDUCTOR smooth (conductor.hpp:33; smooth = max(alpha) < 1e-3, microfacet.hpp:23-25)
+JD int bxdfClass(const DMaterial &m) {
+    const bool smooth = fmax2(m.alpha_x, m.alpha_y) < 1e-3f;
+    if (m.type == 1) return (m.ior[0] == 1.0f || smooth) ? 5 : 1;
+    if (m.type == 2) return smooth ? 6 : 2;
+    return m.type;
+}
+JD void countClass(unsigned (&a)[8], int c) { a[0] += c == 0; a[1] += c == 1; a[2] += c == 2; a[3] += c == 3; a[4] += c == 4; a[5] += c == 5; a[6] += c == 6; }
 
 enum { SRC_GLOBAL = 0, SRC_LDS = 1, SRC_WIDE = 2, SRC_LEAF = 3 };
 

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(WBLOCK, WIDE ? JTX_WF_WIDE_OCC : 1) k_wf_trace
                 if (s >= 0) {
                     pslot = s;
                     if (ANY) { pox = p.b.sox[s]; poy = p.b.soy[s]; poz = p.b.soz[s]; pdx = p.b.sdx[s]; pdy = p.b.sdy[s]; pdz = p.b.sdz[s]; ptmax = p.b.stmax[s];
-                               pnf = p.b.sflags[s] & WF_SH_NF_MASK; }
+                               pnf = p.b.sflags[s] & (WF_SH_NF_MASK | WF_SH_TYPE_MASK); }
                     else     { pox = p.b.rox[s]; poy = p.b.roy[s]; poz = p.b.roz[s]; pdx = p.b.rdx[s]; pdy = p.b.rdy[s]; pdz = p.b.rdz[s]; }
                 }
             }
@@ -292,7 +292,8 @@ __global__ void __launch_bounds__(WBLOCK, WIDE ? JTX_WF_WIDE_OCC : 1) k_wf_trace
 
         // ---- E. retire finished rays: one store, nothing to wait for ----
         if (slot >= 0 && cur < 0 && leafN == 0) {
-            if (ANY) p.b.sflags[slot] = hitAny ? nf : WF_SH_UNOCCLUDED;    // shade / resolve add the pending radiance (or poison)
+            if (ANY) { p.b.sflags[slot] = hitAny ? (nf & WF_SH_NF_MASK) : WF_SH_UNOCCLUDED;    // shade / resolve add the pending radiance (or poison)
+                       if (COUNT && !hitAny) countClass(cnt.n_eval_t, (nf & WF_SH_TYPE_MASK) >> WF_SH_TYPE_SHIFT); }   // sampleLights reached evalBxdf (integrator.cpp:151-166)
             else {
                 p.b.hit[slot] = make_float4(rec.t, rec.b1, rec.b2, __int_as_float(hitAny ? rec.prim : -1));
                 if (p.sort_shade) {                                        // shading sorted by the hit material's type
@@ -313,6 +314,11 @@ __global__ void __launch_bounds__(WBLOCK, WIDE ? JTX_WF_WIDE_OCC : 1) k_wf_trace
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if ((threadIdx.x & 63) == 0 && s) atomicAdd(&p.counters[idx[i]], s);
         }
+        if (ANY) for (int i = 0; i < 7; ++i) {
+            unsigned long long s = i == 0 ? cnt.n_eval_t[0] : i == 1 ? cnt.n_eval_t[1] : i == 2 ? cnt.n_eval_t[2] : i == 3 ? cnt.n_eval_t[3] : i == 4 ? cnt.n_eval_t[4] : i == 5 ? cnt.n_eval_t[5] : cnt.n_eval_t[6];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&p.counters[CNT_EVAL_T + i], s);
+        }
     }
 }
 
@@ -326,7 +332,7 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p, int typeCode) {
     const DevScene &sc = p.scene;
     int *scratch = scratchAll + (threadIdx.x & ~63);
     WaveFetch wf; wf.init(p.b.flags, p.num_slots);
-    unsigned nshade = 0;
+    unsigned nshade = 0, nshadeT[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     while (true) {
         const int slot = typeCode < 0 ? waveFetch(wf, true, p.b.flags, WF_LIVE, p.num_slots, scratch)
                                       : waveFetch(wf, true, p.b.flags, WF_LIVE, p.num_slots, scratch, WF_TYPE_MASK,
@@ -381,13 +387,13 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p, int typeCode) {
                         p.b.sdx[slot] = ls.wi.x; p.b.sdy[slot] = ls.wi.y; p.b.sdz[slot] = ls.wi.z;
                         p.b.stmax[slot] = lDist - RAY_EPSILON;
                         p.b.pendx[slot] = pend.x; p.b.pendy[slot] = pend.y; p.b.pendz[slot] = pend.z;
-                        sflag = WF_SH_PENDING | (nonFiniteMask(beta) << WF_SH_NF_SHIFT);
+                        sflag = WF_SH_PENDING | (nonFiniteMask(beta) << WF_SH_NF_SHIFT) | (bxdfClass(mat) << WF_SH_TYPE_SHIFT);
                     }
                 }
                 const float u = rng.f();
                 f2 u2; u2.x = rng.f(); u2.y = rng.f();
                 BSample bs;
-                if (COUNT) nshade++;
+                if (COUNT) { nshade++; countClass(nshadeT, bxdfClass(mat)); }
                 if (sampleBxdf<MASK>(ctx, mat, sf.normal, sf.uv, wo, u, u2, bs)) {
                     if (bs.pdf > 0.0f) beta = beta * (bs.f * absdot(bs.wi, sf.normal) / bs.pdf);
                     const f3 no = sf.point + bs.wi * RAY_EPSILON;         // integrator.cpp:212
@@ -407,6 +413,11 @@ __global__ void __launch_bounds__(WBLOCK) k_wf_shade(WfParams p, int typeCode) {
         unsigned long long s = nshade;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&p.counters[8], s);
+        for (int i = 0; i < 7; ++i) {
+            unsigned long long st = i == 0 ? nshadeT[0] : i == 1 ? nshadeT[1] : i == 2 ? nshadeT[2] : i == 3 ? nshadeT[3] : i == 4 ? nshadeT[4] : i == 5 ? nshadeT[5] : nshadeT[6];
+            for (int off = 32; off > 0; off >>= 1) st += __shfl_down(st, off, 64);
+            if ((threadIdx.x & 63) == 0 && st) atomicAdd(&p.counters[CNT_SHADE_T + i], st);
+        }
     }
 }
 

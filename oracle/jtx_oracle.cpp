@@ -287,7 +287,11 @@ struct Hit {                     // SurfaceIntersection material.hpp:25-40 (tang
 struct Counters {
     uint64_t n_camera = 0, n_closest = 0, n_any = 0, n_nodes_closest = 0, n_tri_closest = 0, n_accept = 0,
              n_nodes_any = 0, n_tri_any = 0, n_shade = 0;
+    uint64_t n_shade_class[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_eval_class[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void shade(int cls) { n_shade++; if (cls >= 0 && cls < 8) n_shade_class[cls]++; }
+    void eval(int cls) { if (cls >= 0 && cls < 8) n_eval_class[cls]++; }
     void add(const Counters &o) {
+        for (int i = 0; i < 8; ++i) { n_shade_class[i] += o.n_shade_class[i]; n_eval_class[i] += o.n_eval_class[i]; }
         n_camera += o.n_camera; n_closest += o.n_closest; n_any += o.n_any;
         n_nodes_closest += o.n_nodes_closest; n_tri_closest += o.n_tri_closest; n_accept += o.n_accept;
         n_nodes_any += o.n_nodes_any; n_tri_any += o.n_tri_any; n_shade += o.n_shade;
@@ -934,6 +938,14 @@ inline void mrParams(const ora_scene &s, const ora_material &m, V2 uv, float &me
     if (m.mr_tex != -1) { V3 mr = getTexel(s.textures[m.mr_tex], uv); roughness = mr.y; metallic = mr.z; }
 }
 
+// the code path a material's sampleBxdf / evalBxdf / pdfBxdf calls take (ora_counters::n_shade_class): dielectric.hpp:44, conductor.hpp:33
+inline int bxdfClass(const ora_material &m) {
+    const bool smooth = GGX{m.alpha_x, m.alpha_y}.smooth();
+    if (m.type == 1) return (m.ior[0] == 1.0f || smooth) ? 5 : 1;
+    if (m.type == 2) return smooth ? 6 : 2;
+    return m.type;
+}
+
 bool sampleBxdf(const ora_scene &s, const ora_material &m, V3 normal, V2 uv, V3 wo, float uc, V2 u, BSample &out) {
     Frame fr = Frame::fromZ(normal);
     V3 wol = fr.toLocal(wo);
@@ -1029,6 +1041,7 @@ V3 sampleLights(const ora_scene &s, V3 rayDir, const Hit &rec, Rng &rng, Counter
         if (!occluded) {
             V3 wo = -rayDir, wi = ls.wi;
             const ora_material &m = s.materials[rec.material];
+            if (cnt) cnt->eval(bxdfClass(m));
             V3 f = evalBxdf(s, m, rec.normal, rec.uv, wo, wi) * absdot(wi, rec.normal);
             float pb = pdfBxdf(s, m, rec.normal, rec.uv, wo, wi);
             float pl = 1.0f / (float) n * ls.pdf;
@@ -1054,7 +1067,7 @@ V3 integrateMIS(const ora_scene &s, V3 o, V3 d, int maxDepth, Rng &rng, Counters
         float u = rng.f();
         V2 u2; u2.x = rng.f(); u2.y = rng.f();
         BSample bs;
-        if (cnt) cnt->n_shade++;
+        if (cnt) cnt->shade(bxdfClass(s.materials[rec.material]));
         if (!sampleBxdf(s, s.materials[rec.material], rec.normal, rec.uv, wo, u, u2, bs)) break;
         if (bs.pdf > 0.0f) beta = beta * (bs.f * absdot(bs.wi, rec.normal) / bs.pdf);
         o = rec.point + bs.wi * RAY_EPSILON;
@@ -1088,6 +1101,7 @@ V3 integrateNEE(const ora_scene &s, V3 o, V3 d, int maxDepth, Rng &rng, Counters
             bool lightSampled = lightSample(light, rec.point, ls);
             if (lightSampled && ls.pdf > 0) {
                 V3 wi = ls.wi;
+                if (cnt) cnt->eval(bxdfClass(m));
                 V3 f = evalBxdf(s, m, rec.normal, rec.uv, wo, wi) * absdot(wi, rec.normal);
                 V3 sOrigin = rec.point + rec.normal * RAY_EPSILON;
                 float lDist = len(rec.point - ls.p);
@@ -1098,7 +1112,7 @@ V3 integrateNEE(const ora_scene &s, V3 o, V3 d, int maxDepth, Rng &rng, Counters
         float u = rng.f();
         V2 u2; u2.x = rng.f(); u2.y = rng.f();
         BSample bs;
-        if (cnt) cnt->n_shade++;
+        if (cnt) cnt->shade(bxdfClass(m));
         if (!sampleBxdf(s, m, rec.normal, rec.uv, wo, u, u2, bs)) break;
         beta = beta * (bs.f * absdot(bs.wi, rec.normal) / bs.pdf);            // unguarded, integrator.cpp:125
         specularBounce = bs.specular;
@@ -1123,7 +1137,7 @@ V3 integrateBasic(const ora_scene &s, V3 o, V3 d, int maxDepth, Rng &rng, Counte
         float u = rng.f();
         V2 u2; u2.x = rng.f(); u2.y = rng.f();
         BSample bs;
-        if (cnt) cnt->n_shade++;
+        if (cnt) cnt->shade(bxdfClass(m));
         if (!sampleBxdf(s, m, rec.normal, rec.uv, wo, u, u2, bs)) break;
         beta = beta * (bs.f * absdot(bs.wi, rec.normal) / bs.pdf);
         o = rec.point + bs.wi * RAY_EPSILON;
@@ -1485,6 +1499,7 @@ void ora_render(const ora_scene *s, const ora_camera_desc *cam, int threads, int
         counters->n_nodes_closest = sum.n_nodes_closest; counters->n_tri_closest = sum.n_tri_closest;
         counters->n_accept = sum.n_accept; counters->n_nodes_any = sum.n_nodes_any; counters->n_tri_any = sum.n_tri_any;
         counters->n_shade = sum.n_shade;
+        for (int i = 0; i < 8; ++i) { counters->n_shade_class[i] = sum.n_shade_class[i]; counters->n_eval_class[i] = sum.n_eval_class[i]; }
     }
 }
 

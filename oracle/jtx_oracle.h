@@ -106,6 +106,9 @@ typedef struct {
     uint64_t n_nodes_any;
     uint64_t n_tri_any;
     uint64_t n_shade;         /* shading events (sampleBxdf calls) */
+    uint64_t n_shade_class[8]; /* ... by BxDF class: 0 DIFFUSE, 1 DIELECTRIC rough, 2 CONDUCTOR rough, 3 METALLIC_ROUGHNESS, 4 thin dielectric,
+                                * 5 DIELECTRIC smooth / index-matched (dielectric.hpp:44), 6 CONDUCTOR smooth (conductor.hpp:33), 7 unused */
+    uint64_t n_eval_class[8];  /* evalBxdf + pdfBxdf calls by BxDF class (integrator.cpp:94-101, 151-166) */
 } ora_counters;
 
 typedef struct ora_scene ora_scene;

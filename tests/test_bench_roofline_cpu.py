@@ -46,9 +46,21 @@ def _check(workload, kernel_ms, cus, lane_ops, useful_frac, frac, busy, busy_ub,
 
 def test_useful_ops_table():
     c = dict(n_camera=2, n_closest=3, n_any=5, n_nodes_closest=7, n_tri_closest=11, n_accept=13, n_nodes_any=17, n_tri_any=19, n_shade=23)
+    # counters without the per-class tallies (rounds 1-4): every vertex an occluded Lambert one, 242 = 170 + 72
     want = 6 * (3 + 5) + 25 * (7 + 17) + 55 * (11 + 19) + 242 * 23 + 40 * 2
     assert bench.useful_lane_ops(c) == want
-    assert bench.USEFUL_OPS == {"ray": 6, "node": 25, "tri": 55, "shade": 242, "camera": 40}
+    assert bench.USEFUL_OPS == {"ray": 6, "node": 25, "tri": 55, "shade": 242, "camera": 40, "vertex": 170, "unoccluded": 124}
+    # with them: the vertex's common part, the BxDF's own sample by class, and evaluate + pdf where the light got through
+    c2 = dict(c, n_shade_class=[10, 3, 2, 5, 0, 2, 1, 0], n_eval_class=[4, 1, 1, 2, 0, 1, 0, 0])
+    S, E = bench.USEFUL_SAMPLE_CLASS, bench.USEFUL_EVAL_CLASS
+    want2 = (6 * 8 + 25 * 24 + 55 * 30 + 40 * 2 + 170 * 23 + sum(n * S[k] for k, n in enumerate(c2["n_shade_class"]))
+             + 124 * 9 + sum(n * E[k] for k, n in enumerate(c2["n_eval_class"])))
+    assert abs(bench.useful_lane_ops(c2) - want2) < 1e-6
+    assert S[2] > S[1] > S[3] > S[6] > S[0] > S[5] and E[2] > E[1] > E[3] > E[0]            # conductor (complex Fresnel x 3) dearest, Lambert cheap
+    # the attainable ceiling prices the same operations by issue class: between fma rate (2.4 cycles) and the transcendental rate (8.4)
+    cyc = bench.useful_issue_cycles(c2) * 64
+    assert 2.4 * want2 < cyc < 4.4 * want2
+    assert bench.unflat_counters(bench.flat_counters(c2)) == c2
 
 
 def test_recorded_bench_line_is_reproducible_from_profiles():

@@ -219,7 +219,8 @@ def test_render_golden(name):
     o = ol.OracleScene(data)
     acc, img, cnt = o.render(data.camera_desc(*g["size"]))
     assert o.info() == pytest.approx(g["bvh"])
-    assert cnt == g["counters"]
+    assert {k: cnt[k] for k in g["counters"]} == g["counters"]          # (the fixture predates the per-class tallies: invariants instead)
+    assert sum(cnt["n_shade_class"]) == cnt["n_shade"] and sum(cnt["n_eval_class"]) <= cnt["n_any"]
     assert crc(acc) == g["acc_crc32"] and crc(img) == g["img_crc32"]
 
 
