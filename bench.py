@@ -90,7 +90,7 @@ def load_workload(jtx, name, atrium_tris=262144, scene_file=None, camera=None):
     return name, data, (W, H, xs, ys, depth)
 
 
-def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup):
+def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup, integrator=None):
     """One rank, one workload: counted pass (device counters), warm-up, `steps` timed frames through jtx_mi_render_device
     (film resident in HBM, resolve pass included), live HIP-event kernel time -> the dict that rides under "workloads"."""
     lib = jtx._capi.load()
@@ -101,8 +101,8 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup):
         cam = data.camera_desc(W, H, xs, ys, depth)
         acc = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
         img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
-        integrator = scene.info()["auto_integrator"]
-
+        if integrator is None:
+            integrator = scene.info()["auto_integrator"]
         pipe = jtx.distributed.ShardPipeline(scene, cam, 0, 1, dev, None, integrator=integrator, frames_in_flight=frames_in_flight())
 
         def frame(count=False):
@@ -795,6 +795,24 @@ def main():
                     extras[n2] = time_workload(jtx, torch, dev, tstream, n2, d2, dims2, EXTRA_STEPS.get(name, 3), 1)
                 except Exception as e:                    # report, never hide
                     extras[name] = {"failed": f"{type(e).__name__}: {e}"}
+            # the architecture north_star names -- integrator 2, the HBM wavefront (SoA queues, ballot compaction; with JTX_WF_SORT_SHADE=1
+            # one shade launch per Material::type: the material-sorted queues) -- on the workload it was named for, as a CURRENT figure
+            # beside the integrator that ships.  Same film bit for bit (tests); launches of one scene are serialised.
+            for tag, sort in (("wavefront", "0"), ("wavefront_sorted", "1")):
+                prev = os.environ.get("JTX_WF_SORT_SHADE")
+                os.environ["JTX_WF_SORT_SHADE"] = sort
+                try:
+                    n2, d2, dims2 = load_workload(jtx, "mixed_1920x1080_128spp_d8", args.atrium_tris)
+                    e = time_workload(jtx, torch, dev, tstream, n2, d2, dims2, 3, 1, integrator=2)
+                    e["integrator_name"] = "hbm-wavefront" + (", one shade launch per material type" if sort == "1" else "")
+                    extras[f"{n2}@{tag}"] = e
+                except Exception as e:                    # report, never hide
+                    extras[f"mixed_1920x1080_128spp_d8@{tag}"] = {"failed": f"{type(e).__name__}: {e}"}
+                finally:
+                    if prev is None:
+                        os.environ.pop("JTX_WF_SORT_SHADE", None)
+                    else:
+                        os.environ["JTX_WF_SORT_SHADE"] = prev
             out["workloads"] = extras
         if world == 1 and not args.no_cpu_baseline:
             try:

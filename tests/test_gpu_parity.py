@@ -214,8 +214,11 @@ def test_render_resume_and_progress(gpu, cornell_pair):
     # cancellation: terminateRender() stops after the current pass
     stop = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4)
     stop.render(sc, progress=lambda c, t: stop.terminateRender() if c == 2 else None)
-    assert stop.currentSample_ == 2
-    two = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4); two.render(sc, sample_begin=0, sample_end=2)
+    # the pass behind the callback's is already in flight (passes are pipelined): on a frame this small it may have run to its end
+    # before the waves look at the flag -- then its stratum IS in the film and counts (jtx_mi.h: jtx_mi_render); never a partial pass
+    n = stop.currentSample_
+    assert n in (2, 3)
+    two = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4); two.render(sc, sample_begin=0, sample_end=n)
     assert_same_f32(stop.acc_, two.acc_, "film after a cancellation = the completed passes, nothing of the abandoned one")
     assert (stop.img_ == two.img_).all()
 
@@ -1843,3 +1846,23 @@ def test_per_ray_parity_on_equal_t_ties_and_lds_copies(gpu, cornell_pair):
     _check_any(sc, osc, o, d, np.full(len(o), 400.0, np.float32), sc.TRAVERSAL_SOURCE + 1, "lds", "cornell anyHit via the LDS copy")
     with pytest.raises(gpu.JtxMiError):
         sc.closestHit(o[:4], d[:4], traversal=sc.TRAVERSAL_SOURCE + 2)           # Cornell has no 8-ary nodes
+
+
+def test_soak_of_the_create_render_rebuild_destroy_path(gpu):
+    """tools/soak.py for a minute (the full 300 iterations are recorded in profiles/r05_soak.txt): scenes created,
+    rendered into page-locked film buffers, edited, rebuilt on the device, rendered again and destroyed, by turns and at changing sizes --
+    every frame bit-identical to the first of its kind, the abort log empty.  In a child process: a GPU fault there is this test's
+    failure, not the session's end."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = os.path.join(root, "gpurun_out", "jtx_abort_soak_test.log")
+    if os.path.exists(log):
+        os.remove(log)
+    env = dict(os.environ, JTX_ABORT_LOG=log)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "60", "45", "--no-rehearsal"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "0 faults, abort log empty" in r.stdout and "soak: " in r.stdout
+    n = int(r.stdout.split("soak: ")[1].split()[0])
+    assert n >= 20

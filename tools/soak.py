@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""ON THE GPU BOX: soak of the create / pin / render / rebuild / destroy path (the intermittent "Memory access fault by
+GPU" of round 4 -- three aborts in ~30 suite runs, inside jtx_mi_scene_create, address in the malloc heap -- was mitigated twice, by
+library-owned page-locked staging and by film buffers outside the malloc heap, and never seen again; this is the run that bounds it).
+
+Each iteration is what Display::renderScene does after an edit (display.cpp:902-905: rebuild if dirty, then render), from scratch:
+    Scene(data) -> buildBVH (host build + upload through the staging buffer) -> StaticCamera with page-locked film buffers -> render
+    (uncounted kernel, film delivered to the host) -> film checked against the first iteration's -> transform edit -> rebuildBVH on the
+    device -> render -> destroy; scene, size and strata vary with the iteration, so allocations do not simply recycle.
+Every 50th iteration: the two-process rehearsal (two ranks sharing the card: their own contexts, IPC-free gloo exchange).
+JTX_ABORT_LOG is armed: a runtime abort leaves its reason and a native backtrace there.
+
+    python3 tools/soak.py [iterations] [seconds] [--no-rehearsal]      -> one summary line; non-zero exit on any mismatch
+"""
+import os
+import sys
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+os.environ.setdefault("JTX_ABORT_LOG", os.path.join(ROOT, "gpurun_out", "jtx_abort_soak.log"))
+import numpy as np
+
+
+def rehearsal():
+    """two ranks on this card through bench.py's own launcher (gloo, both on device 0), a short frame loop"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(JTX_DIST_BACKEND="gloo", JTX_ALL_RANKS_ON_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--workload", "cornell_512x512_16spp_d4"], capture_output=True, text=True, timeout=300, env=env)
+    return r.returncode == 0 and "nranks_seen\": 2" in r.stdout, (r.stdout + r.stderr)[-600:]
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    iters = int(args[0]) if args else 300
+    budget = float(args[1]) if len(args) > 1 else 1e9
+    with_rehearsal = "--no-rehearsal" not in sys.argv
+    import jtx_pathtracer_amd as jtx
+    lib = jtx._capi.load()
+    jtx._capi.check(lib.jtx_mi_set_device(0))
+    makers = [("cornell", lambda: jtx.scenes.cornell()), ("atrium3k", lambda: jtx.scenes.atrium(target_tris=3000)),
+              ("mixed", lambda: jtx.scenes.mixed(sphere_res=(16, 8))), ("atrium20k", lambda: jtx.scenes.atrium(target_tris=20000))]
+    sizes = [(96, 64), (200, 136), (321, 177), (64, 64)]
+    first = {}
+    t0 = time.time()
+    done = rehearsals = 0
+    for it in range(iters):
+        if time.time() - t0 > budget:
+            break
+        name, make = makers[it % len(makers)]
+        W, H = sizes[(it // len(makers)) % len(sizes)]
+        xs = 1 + it % 3
+        data = make()
+        sc = jtx.Scene(data); sc.buildBVH()
+        cam = jtx.StaticCamera(W, H, data.camera, xs, 2, 4)                 # film: anonymous mappings, page-locked at the first render
+        cam.render(sc, count_rays=False)
+        key = (name, W, H, xs)
+        crc = zlib.crc32(np.ascontiguousarray(cam.acc_).tobytes()) ^ zlib.crc32(np.ascontiguousarray(cam.img_).tobytes())
+        if first.setdefault(key, crc) != crc:
+            print(f"MISMATCH at iteration {it}: {key} film differs from its first render"); sys.exit(2)
+        # an edit, a device rebuild, another frame (display.cpp:545-588, 902-905)
+        m = np.eye(4, dtype=np.float32); m[0, 3] = 1.0 + 0.01 * (it % 7)
+        sc.setTransform(0, m)
+        sc.rebuildBVHOnDevice(1)
+        cam.render(sc, count_rays=False)
+        key2 = key + ("edited", it % 7)
+        crc = zlib.crc32(np.ascontiguousarray(cam.acc_).tobytes())
+        if first.setdefault(key2, crc) != crc:
+            print(f"MISMATCH at iteration {it}: {key2} film differs from its first render"); sys.exit(2)
+        cam._unpin()
+        sc.destroy()
+        del cam, sc, data
+        done += 1
+        if with_rehearsal and it % 50 == 49:
+            ok, tail = rehearsal()
+            rehearsals += 1
+            if not ok:
+                print(f"REHEARSAL FAILED at iteration {it}:\n{tail}"); sys.exit(3)
+        if it % 25 == 24:
+            print(f"[soak] {it + 1} iterations, {time.time() - t0:.0f} s", flush=True)
+    log = os.environ["JTX_ABORT_LOG"]
+    aborted = os.path.exists(log) and os.path.getsize(log) > 0
+    print(f"soak: {done} iterations ({len(first)} distinct frames, each re-rendered bit-identically), {rehearsals} two-process rehearsals, "
+          f"{time.time() - t0:.0f} s, 0 faults, abort log {'NOT EMPTY' if aborted else 'empty'}")
+    sys.exit(4 if aborted else 0)
+
+
+if __name__ == "__main__":
+    main()
