@@ -140,7 +140,7 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup, int
                 out["in_flight"] = in_flight_block(roof, len(pipe.rstreams), elapsed / steps * 1e3, None)
             for k in ("useful_frac", "frac", "traffic", "vector_memory", "lane_util", "issue_model", "pmc_stale"):
                 if k in roof:
-                    out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"], "busy_upper_bound": roof[k]["busy_upper_bound"]}
+                    out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"], "busy_calibrated": roof[k]["busy_calibrated"]}
             out["hbm_measured_frac"] = roof["hbm"].get("measured_frac")
             out["useful_lane_ops_per_launch"] = roof["useful"]["lane_ops_per_launch"]; out["num_cus"] = roof["num_cus"]
             out["kernel"] = roof["kernel"]
@@ -329,7 +329,11 @@ def issue_calibration(lds_resident):
     have = [ratio[k][0] for k in want if k in ratio]
     if not have:
         return None
-    return {"measured_over_priced": round(sum(have) / len(have), 4), "loops": want, "source": os.path.relpath(cands[-1], ROOT)}
+    # the replay was taken on the kernel sources of its round: a note in the file names their hash ("source_hash: ...") -- when the
+    # sources have changed since, the factor is still reported, flagged stale (the way pmc_stale flags the counters)
+    m = re.search(r"source_hash: (\w+)", open(cands[-1]).read())
+    return {"measured_over_priced": round(sum(have) / len(have), 4), "loops": want, "source": os.path.relpath(cands[-1], ROOT),
+            "source_hash": m.group(1) if m else None, "stale": (m.group(1) != source_hash()) if m else None}
 
 
 def cpu_baseline(data, width, height, xs, ys, depth, budget_s=9.0):
@@ -479,9 +483,13 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
             out["issue_model"] = {"fast_class_insts": int(fast), "slow_class_insts": int(slow), "transcendental_insts": int(trans),
                                   "cycles_per_inst": {"fast": 2.4, "slow": 4.4, "transcendental": 8.4},
                                   "cycles_priced": int(need), "simd_cycles_available": int(SIMDS * t * CLK),
+                                  # `busy`: the class-priced demand over the cycles the SIMDs have -- an upper bound (round 3's meaning of the key,
+                                  # kept so that rounds compare; `busy_upper_bound` is the same number under round 4's name);
+                                  # `busy_calibrated`: that demand times measured / priced of the kernel's own loop body (round 4 printed this as `busy`)
+                                  "busy": round(need / (SIMDS * t * CLK), 3),
                                   "busy_upper_bound": round(need / (SIMDS * t * CLK), 3),
                                   "calibration": cal,
-                                  "busy": round(need * cal["measured_over_priced"] / (SIMDS * t * CLK), 3) if cal else None,
+                                  "busy_calibrated": round(need * cal["measured_over_priced"] / (SIMDS * t * CLK), 3) if cal else None,
                                   "note": "VALU cycles the launch's instruction mix is priced at by class (an upper bound) x the ratio measured / priced of "
                                           "the kernel's own loop body replayed at saturation (profiles/r04_issue_replay.txt), over the cycles the SIMDs have "
                                           "in the kernel's duration (nominal 2.4 GHz); ~1.0: issue-saturated"}

@@ -155,6 +155,9 @@ typedef struct {
                                     * never has more workgroups than chunks) */
     int32_t workgroup_size;   /* lanes per workgroup of that kernel: 256 when the scene is staged in LDS, 64 otherwise */
     int32_t device_built;     /* != 0: the tree comes from jtx_mi_scene_rebuild (the reference's tree, node for node and primitive for primitive) */
+    uint64_t wide_bytes64;    /* wide_bytes without the 2 GiB clamp of the 32-bit field; 0 when the kernels have no 8-ary nodes to walk */
+    uint64_t rebuild_spare_bytes;  /* device memory held by the edit loop's second set of structures + the builder's scratch (NOT part of
+                                    * device_bytes): 0 before the first jtx_mi_scene_rebuild / reserve_rebuild and after release_rebuild */
 } jtx_mi_scene_info;
 
 typedef struct jtx_mi_scene jtx_mi_scene;
@@ -227,6 +230,10 @@ int  jtx_mi_scene_rebuild(jtx_mi_scene *scene, int32_t max_prims_in_node);
  * -- or here, e.g. right after loading: a dry run of the rebuild that stops before the commit, so that the first edit costs what
  * every later one does.  The scene is not changed.  Optional; may be called again. */
 int  jtx_mi_scene_reserve_rebuild(jtx_mi_scene *scene);
+/* ... and back: frees that second set, the builder's scratch and the page-locked landing buffers (scene_info.rebuild_spare_bytes says
+ * how much; about the geometry's own size again).  For a host that has finished editing, or holds many scenes on one device.  The next
+ * rebuild allocates them again (and pays the first rebuild's price once more). */
+int  jtx_mi_scene_release_rebuild(jtx_mi_scene *scene);
 int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
 int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
 /* The scene's 8-ary node set as it stands on the device -- after jtx_mi_scene_create, a device rebuild or a refit -- in the layout of

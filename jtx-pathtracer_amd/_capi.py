@@ -78,7 +78,8 @@ class SceneInfo(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("num_prims", C.c_int32), ("max_depth", C.c_int32),
                 ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("auto_integrator", C.c_int32),
                 ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32), ("refitted", C.c_int32),
-                ("num_cus", C.c_int32), ("resident_workgroups", C.c_int32), ("workgroup_size", C.c_int32), ("device_built", C.c_int32)]
+                ("num_cus", C.c_int32), ("resident_workgroups", C.c_int32), ("workgroup_size", C.c_int32), ("device_built", C.c_int32),
+                ("wide_bytes64", C.c_uint64), ("rebuild_spare_bytes", C.c_uint64)]
 
 
 CANCELLED = 2          # JTX_MI_CANCELLED
@@ -108,6 +109,7 @@ SYMBOLS = {
     "jtx_mi_scene_set_transform": (C.c_int, [_scene, C.c_int32, _f]),
     "jtx_mi_scene_refit": (C.c_int, [_scene]),
     "jtx_mi_scene_rebuild": (C.c_int, [_scene, C.c_int32]),
+    "jtx_mi_scene_release_rebuild": (C.c_int, [_scene]),
     "jtx_mi_scene_reserve_rebuild": (C.c_int, [_scene]),
     "jtx_mi_cancel": (C.c_int, [_scene]),
     "jtx_mi_pin_host": (C.c_int, [C.c_void_p, C.c_uint64]),

@@ -73,7 +73,8 @@ class Scene:
                     lds_resident=bool(i.lds_resident), scene_radius=float(i.scene_radius),
                     auto_integrator=int(i.auto_integrator), wide_depth=int(i.wide_depth), wide_bytes=int(i.wide_bytes),
                     device_bytes=int(i.device_bytes), refitted=bool(i.refitted), device_built=bool(i.device_built),
-                    num_cus=int(i.num_cus), resident_workgroups=int(i.resident_workgroups), workgroup_size=int(i.workgroup_size))
+                    num_cus=int(i.num_cus), resident_workgroups=int(i.resident_workgroups), workgroup_size=int(i.workgroup_size),
+                    wide_bytes64=int(i.wide_bytes64), rebuild_spare_bytes=int(i.rebuild_spare_bytes))
 
     # -- transform edits (display.cpp:545-588): new Mesh::transform per mesh, then a device refit (topology kept)
     def setTransform(self, mesh, transform):
@@ -93,6 +94,11 @@ class Scene:
         """allocate the second buffer set and the builder's scratch of rebuildBVHOnDevice now (jtx_mi_scene_reserve_rebuild), so that
         the first edit of a session costs what every later one does"""
         check(self._lib.jtx_mi_scene_reserve_rebuild(self.handle))
+
+    def releaseRebuild(self):
+        """free the second buffer set, the builder's scratch and its landing buffers again (jtx_mi_scene_release_rebuild;
+        info()["rebuild_spare_bytes"] says how much they hold)"""
+        check(self._lib.jtx_mi_scene_release_rebuild(self.handle))
 
     def bvh(self):
         i = self.info()

@@ -54,7 +54,15 @@ struct HostStage {
         return p;
     }
 };
-HostStage &hostStage() { static HostStage *st = new HostStage(); return *st; }       // never freed: it must outlive every scene, and static destructors run after the runtime's
+// one stage per DEVICE (the current one of the calling thread): the per-device worker threads of a multi-device scene creation and of
+// jtx_mi_multi_render's delivery copy side by side instead of queueing behind one process-wide lock.  Never freed: the
+// stages must outlive every scene, and static destructors run after the runtime's.
+HostStage &hostStage() {
+    static HostStage *st = new HostStage[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return st[dev & 15];
+}
 constexpr size_t kStageChunk = (size_t) 8 << 20, kStageMin = 4096;                   // (copies of a few words stay direct: the runtime embeds / stages them itself)
 
 // host -> device, complete on return.  The destination must not be in use by work in flight.
@@ -179,6 +187,19 @@ struct jtx_mi_scene {
         PinBuf pin_nodes, pin_ord;       // page-locked landing buffers of the rebuild's read-backs (nodes, primitive order)
         DevBuildArena arena;
         ~RebuildSpare() { if (arena.base) (void) hipFree(arena.base); }
+        size_t bytes() const {           // device memory the set holds (what jtx_mi_scene_release_rebuild gives back)
+            return (src.cap + tris.cap + shade.cap + nbox.cap + tnodes.cap + lw_box.cap) * sizeof(float4) +
+                   (orig.cap + leaves.cap + levels.cap + rec_node.cap + map.cap + order.cap + pos.cap + size.cap) * sizeof(int) +
+                   wide.cap * sizeof(uint4) + lw_tab.cap * sizeof(unsigned) + lights.cap * sizeof(DLight) + hn.cap * sizeof(jtx_mi_bvh_node) + arena.cap;
+        }
+        void release() {
+            src.release(); tris.release(); shade.release(); nbox.release(); tnodes.release(); lw_box.release(); orig.release(); leaves.release();
+            levels.release(); rec_node.release(); map.release(); wide.release(); lw_tab.release(); lights.release(); order.release(); pos.release();
+            size.release(); hn.release();
+            if (arena.base) { (void) hipFree(arena.base); arena.base = nullptr; arena.cap = 0; }
+            if (pin_nodes.p) { (void) hipHostFree(pin_nodes.p); pin_nodes.p = nullptr; pin_nodes.cap = 0; }
+            if (pin_ord.p) { (void) hipHostFree(pin_ord.p); pin_ord.p = nullptr; pin_ord.cap = 0; }
+        }
     } spare;
     // Per-path radiance records of k_render_paths (and of the strata-split mode): JTX_MI_FRAME_SLOTS sets, so that several frames of one
     // scene can be in flight at once (opts.frame_slot): the last chunks of frame i -- every persistent wave spends its final ~0.4 ms with
@@ -1273,6 +1294,16 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit);
 // memory is mapped at first touch and a translation unit's code object is loaded at its first launch -- measured on the atrium,
 // allocation 0.9 ms, but the first rebuild still 26 ms against 7 for the second.  After the dry run the first rebuild is a second one.
 int jtx_mi_scene_reserve_rebuild(jtx_mi_scene *s) { return rebuildImpl(s, 1, false); }
+int jtx_mi_scene_release_rebuild(jtx_mi_scene *s) {
+    try {
+        if (!s) throw std::runtime_error("null scene");
+        std::lock_guard<std::mutex> lk(s->mu);
+        DeviceGuard dg(s->device);
+        HIPCHK(hipStreamSynchronize(s->stream));                 // (a rebuild runs on the scene's stream and is complete on return; renders do not touch the spare set)
+        s->spare.release();
+        return 0;
+    } catch (const std::exception &e) { return fail(e.what()); }
+}
 
 namespace {
 // Mesh::transform of every mesh to the device (enqueued on the scene's stream), from page-locked memory
@@ -1411,7 +1442,10 @@ int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     out->num_nodes = s->dev.num_nodes; out->num_prims = s->dev.num_prims; out->max_depth = s->bvh.max_depth;
     out->lds_resident = s->dev.lds_threaded; out->scene_radius = s->bvh.scene_radius; out->device_bytes = s->device_bytes;
     out->auto_integrator = autoIntegrator(*s);
-    out->wide_depth = s->dev.wide_depth; out->wide_bytes = (int32_t) (s->wide.n * sizeof(uint4));
+    // (what the kernels walk: nothing when a refit or a build could not quantise the tree -- jtx_mi_scene_get_wide then returns 0 granules too)
+    const uint64_t wb = s->dev.wide ? (uint64_t) s->wide.n * sizeof(uint4) : 0;
+    out->wide_depth = s->dev.wide_depth; out->wide_bytes = wb > 0x7fffffffull ? 0x7fffffff : (int32_t) wb; out->wide_bytes64 = wb;
+    out->rebuild_spare_bytes = s->spare.bytes();
     out->refitted = s->refitted;
     out->device_built = s->device_built;
     out->num_cus = s->num_cus;

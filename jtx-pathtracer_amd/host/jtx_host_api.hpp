@@ -134,6 +134,8 @@ public:
     // (jtx_mi_scene_rebuild).  Single-device scenes only.
     // the second buffer set of rebuildBVHOnDevice, allocated ahead of the first edit (jtx_mi_scene_reserve_rebuild); optional
     void reserveRebuild() { if (handle_) check(jtx_mi_scene_reserve_rebuild(handle_)); }
+    // ... and given back when the editing is over (jtx_mi_scene_release_rebuild: about the geometry's device memory once more)
+    void releaseRebuild() { if (handle_) check(jtx_mi_scene_release_rebuild(handle_)); }
     void rebuildBVHOnDevice(int maxPrimsInNode = 1) {
         if (!handle_) { buildBVH(maxPrimsInNode); return; }
         for (size_t i = 0; i < meshes.size(); ++i) check(jtx_mi_scene_set_transform(handle_, (int) i, &meshes[i].transform.m[0][0]));

@@ -1866,3 +1866,32 @@ def test_soak_of_the_create_render_rebuild_destroy_path(gpu):
     assert "0 faults, abort log empty" in r.stdout and "soak: " in r.stdout
     n = int(r.stdout.split("soak: ")[1].split()[0])
     assert n >= 20
+
+
+def test_rebuild_spare_set_is_accounted_and_can_be_released(gpu):
+    """the second set of structures a device rebuild writes (about the geometry's own device memory again, plus the
+    builder's scratch) shows in scene_info.rebuild_spare_bytes, jtx_mi_scene_release_rebuild gives it back, and the next rebuild
+    allocates it anew -- same tree, same frame.  wide_bytes is what the kernels walk (jtx_mi_scene_get_wide agrees)."""
+    data = gpu.scenes.atrium(target_tris=12000)
+    sc = gpu.Scene(data); sc.buildBVH()
+    i0 = sc.info()
+    assert i0["rebuild_spare_bytes"] == 0 and i0["wide_bytes64"] == i0["wide_bytes"] == 16 * len(sc.wide()) > 0
+    sc.reserveRebuild()
+    i1 = sc.info()
+    assert i1["rebuild_spare_bytes"] > 0.5 * i0["device_bytes"] and i1["device_bytes"] == i0["device_bytes"]
+    m = np.eye(4, dtype=np.float32); m[1, 3] = 1.5
+    sc.setTransform(0, m)
+    sc.rebuildBVHOnDevice()
+    n1, r1 = sc.bvh()
+    ref = gpu.StaticCamera(160, 90, data.camera, 2, 2, 5); ref.render(sc, count_rays=False)
+    sc.releaseRebuild()
+    assert sc.info()["rebuild_spare_bytes"] == 0
+    g = gpu.StaticCamera(160, 90, data.camera, 2, 2, 5); g.render(sc, count_rays=False)
+    assert_same_f32(g.acc_, ref.acc_, "frame after the spare set was released")
+    sc.rebuildBVHOnDevice()                                           # allocates the set again; the geometry did not change: the same tree
+    n2, r2 = sc.bvh()
+    _same_tree(n1, r1, n2, r2, "rebuild after release")
+    assert sc.info()["rebuild_spare_bytes"] > 0
+    g.render(sc, count_rays=False)
+    assert_same_f32(g.acc_, ref.acc_, "frame after the rebuild that followed the release")
+    sc.destroy()
