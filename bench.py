@@ -105,25 +105,26 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup, int
             integrator = scene.info()["auto_integrator"]
         pipe = jtx.distributed.ShardPipeline(scene, cam, 0, 1, dev, None, integrator=integrator, frames_in_flight=frames_in_flight())
 
-        def frame(count=False):
+        def frame(count=False, last=False):
             if count:
                 jtx.distributed.render_shard(scene, cam, 0, 1, acc, img, stream=tstream.cuda_stream, count_rays=True, integrator=integrator)
             else:
-                pipe.step()
+                pipe.step(last=last)
         frame(count=True)
         torch.cuda.synchronize()
         cnt = jtx._capi.Counters()
         jtx._capi.check(lib.jtx_mi_get_counters(scene.handle, C.byref(cnt)))
         mine = cnt.as_dict()
         rays = mine["n_closest"] + mine["n_any"]
+        pipe.prime()
         for _ in range(warmup):
             frame()
         torch.cuda.synchronize()
         ms = C.c_float(); nl = C.c_int32()
         jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
         t = time.perf_counter()
-        for _ in range(steps):
-            frame()
+        for i in range(steps):
+            frame(last=(i == steps - 1))
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t
         kernel_ms = serial_kernel_ms(jtx, torch, lib, scene, cam, 0, 1, dev, integrator, frames=min(3, steps))
@@ -537,8 +538,8 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cornell_1920x1080_64spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--atrium-tris", type=int, default=262144)
@@ -624,9 +625,9 @@ def main():
 
     xtimed = []                                              # serial exchange: (event before, event after) per frame, on the render stream
 
-    def step(count=False, profile=False):
+    def step(count=False, profile=False, last=False):
         if pipe is not None and not count and not profile:
-            pipe.step()
+            pipe.step(last=last)
             return
         jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count,
                                      integrator=integrator, profile_kernels=profile)
@@ -685,6 +686,8 @@ def main():
         jtx._capi.check(lib.jtx_mi_kernel_time_by_kind(scene.handle, kms, kn))
         kind_ms = [(float(kms[i]), int(kn[i])) for i in range(5)]
 
+    if pipe is not None:
+        pipe.prime()                                         # set-up: every frame slot's buffers exist and are mapped (untimed, like scene creation)
     for _ in range(args.warmup):
         step()
     fence()
@@ -694,8 +697,8 @@ def main():
     if pipe is not None:
         pipe.reset_timing()
     t = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(last=(i == args.steps - 1))
     fence()
     elapsed = time.perf_counter() - t
     jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))

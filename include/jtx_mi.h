@@ -127,6 +127,9 @@ typedef struct {
                                * by the library (an event per slot), whatever streams they come on; launches that need the scene's
                                * singletons (count_rays, integrator 2, path_integrator != 0) are ordered against all slots.  jtx_mi_render
                                * uses slot 0. */
+    int32_t sequence_end;     /* != 0: nothing follows this frame that could fill the end of its launch (the last frame of a sequence): the
+                               * launch is cut into many small chunks like a lone one, although other frames of the scene are in flight
+                               * (with a successor in flight the library prefers few large chunks: fewer fetches, the tail does not matter) */
 } jtx_mi_render_opts;
 
 /* ray / traffic counters */
@@ -276,10 +279,9 @@ int jtx_mi_render_device(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, con
 int jtx_mi_cancel_pending(jtx_mi_scene *scene, int32_t *out);   /* after a sync: 0 none, 1 pending (the last pass completed), 2 pending and the last pass was abandoned */
 int jtx_mi_cancel_reset(jtx_mi_scene *scene);
 int jtx_mi_sync(jtx_mi_scene *scene);
-/* GPU time of the integrator kernel(s) of the last render call(s) since the previous query: sum in ms and number of launches.
- * Launches of the persistent path kernel report their own clocks (first wave in to last wave out -- what a kernel trace shows; with
- * several frames of a scene in flight a launch waits for wave slots first, which an event pair on its stream would count in); all
- * other launches: HIP events recorded on the launch stream. */
+/* GPU time of the integrator kernel(s) of the last render call(s) since the previous query, from HIP events recorded on the launch
+ * stream: sum in ms and number of launches.  (With several frames of a scene in flight -- opts.frame_slot -- a launch's pair also times
+ * its wait for free wave slots: time single launches with one frame in flight.) */
 int jtx_mi_kernel_time(jtx_mi_scene *scene, float *ms_total, int32_t *launches);
 /* Wavefront renders with opts.reserved bit 0: summed GPU ms and launch count per kernel kind since the last
  * query: [0] generate, [1] trace closest, [2] shade, [3] trace any (shadow), [4] resolve. */

@@ -62,7 +62,7 @@ class CameraDesc(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("tile_rank", C.c_int32),
                 ("tile_world", C.c_int32), ("integrator", C.c_int32), ("count_rays", C.c_int32),
-                ("samples_per_tick", C.c_int32), ("reserved", C.c_int32), ("path_integrator", C.c_int32), ("frame_slot", C.c_int32)]
+                ("samples_per_tick", C.c_int32), ("reserved", C.c_int32), ("path_integrator", C.c_int32), ("frame_slot", C.c_int32), ("sequence_end", C.c_int32)]
 
 
 class Counters(C.Structure):

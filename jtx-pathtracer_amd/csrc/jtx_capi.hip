@@ -232,8 +232,7 @@ struct jtx_mi_scene {
     int   n_by_kind[5] = {0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;     // timing pairs of the launches since the last jtx_mi_kernel_time
-    std::vector<unsigned long long *> pending_clock;                         // ... and, for k_render_paths launches, their in-kernel clock pair (else null)
-    DevBuf<unsigned long long> clocks;                                       // 2 per chunk counter of the work ring
+
     size_t device_bytes = 0;
     int device = 0;
     std::mutex mu;
@@ -951,7 +950,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     p.counters = s.counters.p;
     // timing pairs are only drained by jtx_mi_kernel_time (bench / tools): a UI that never asks keeps the newest 64
     while (s.pending.size() >= 64 && hipEventQuery(s.pending.front().second) == hipSuccess) {
-        s.free_events.push_back(s.pending.front()); s.pending.erase(s.pending.begin()); s.pending_clock.erase(s.pending_clock.begin());
+        s.free_events.push_back(s.pending.front()); s.pending.erase(s.pending.begin());
     }
     auto ev = takeEvents(s);
     struct EvReturn { jtx_mi_scene &s; std::pair<hipEvent_t, hipEvent_t> ev; bool armed = true;
@@ -961,10 +960,9 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     if (owned == 0) {                 // a shard without tiles (more ranks than 32x32 tiles): nothing to launch, an empty timing pair
         HIPCHK(hipEventRecord(ev.second, stream));
         evGuard.armed = false;
-        s.pending.push_back(ev); s.pending_clock.push_back(nullptr);
+        s.pending.push_back(ev);
         return;
     }
-    unsigned long long *launchClock = nullptr;
     if (alt) {
         HIPCHK(jtx_launch_render_alt(p, owned, count, o.path_integrator, stream));
     } else if (integ == 1) {
@@ -986,7 +984,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             // (profiles/r05_frames_in_flight.md: C2 26.5 against 27.8 ms, a 1/8 shard 3.43 against 4.06 = 1/8 of the frame's kernel time)
             if (!getenv("JTX_STRATA_GROUPS")) {
                 bool pipelined = false;
-                for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) if (k != slot && hipEventQuery(s.slot_done[k]) == hipErrorNotReady) pipelined = true;
+                if (!o.sequence_end) for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) if (k != slot && hipEventQuery(s.slot_done[k]) == hipErrorNotReady) pipelined = true;
                 (void) hipGetLastError();
                 groups = 1;
                 if (pipelined && s.dev.lds_threaded) {
@@ -1022,13 +1020,9 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.strata_per_group = (q.sample_end - q.sample_begin + g - 1) / g;
                 q.num_groups = (q.sample_end - q.sample_begin + q.strata_per_group - 1) / q.strata_per_group;
                 q.num_subblocks = owned * 16;
-                if (!s.work.p) { s.work.alloc(kWorkRing); s.clocks.alloc(2 * kWorkRing); }
-                const unsigned ring = s.work_slot++ & (kWorkRing - 1);
-                q.work = s.work.p + ring;                                  // one counter per launch in flight
+                if (!s.work.p) s.work.alloc(kWorkRing);
+                q.work = s.work.p + (s.work_slot++ & (kWorkRing - 1));    // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
-                q.clock = s.clocks.p + 2 * ring;                           // (a pass split by the radiance cap: the clock of its last launch)
-                HIPCHK(hipMemsetAsync(q.clock, 0xff, 2 * sizeof(unsigned long long), stream));
-                launchClock = q.clock;
                 s.last_work = q.work;
                 s.pass_parts.push_back({q.work, q.sample_begin, q.sample_end});
                 HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
@@ -1050,7 +1044,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
     else launchWavefront(s, cam, o, sb, se, d_acc, d_img, stream, rank, world);
     if (!evClosed) HIPCHK(hipEventRecord(ev.second, stream));
     evGuard.armed = false;
-    s.pending.push_back(ev); s.pending_clock.push_back(launchClock);
+    s.pending.push_back(ev);
 }
 
 } // namespace
@@ -1512,21 +1506,13 @@ int jtx_mi_kernel_time(jtx_mi_scene *s, float *ms_total, int32_t *launches) {
         std::lock_guard<std::mutex> lk(s->mu);
         DeviceGuard dg(s->device);
         float total = 0; int n = 0;
-        for (size_t i = 0; i < s->pending.size(); ++i) {
-            auto &e = s->pending[i];
+        for (auto &e : s->pending) {
             HIPCHK(hipEventSynchronize(e.second));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
-            // a k_render_paths launch carries its own clocks (first wave in, last wave out; wall_clock64 ticks at 100 MHz): with several
-            // frames of the scene in flight the event pair also times the wait for free wave slots, the clocks do not
-            if (s->pending_clock[i]) {
-                unsigned long long c[2] = {~0ull, ~0ull};
-                HIPCHK(hipMemcpy(c, s->pending_clock[i], sizeof c, hipMemcpyDeviceToHost));
-                if (c[0] != ~0ull && c[1] != ~0ull && ~c[1] >= c[0]) ms = (float) ((double) (~c[1] - c[0]) * 1e-5);
-            }
             total += ms; ++n;
             s->free_events.push_back(e);
         }
-        s->pending.clear(); s->pending_clock.clear();
+        s->pending.clear();
         if (ms_total) *ms_total = total;
         if (launches) *launches = n;
         return 0;

@@ -268,7 +268,6 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     }
     if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);
     const int lane = threadIdx.x & 63;
-    if (p.clock && lane == 0) atomicMin(&p.clock[0], (unsigned long long) wall_clock64());
     const unsigned long long below = (1ull << lane) - 1ull;
     const int nchunks = p.num_subblocks * p.num_groups;
     JTX_PROF_TIMELINE_BEGIN
@@ -364,7 +363,6 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             }
         }
     }
-    if (p.clock && lane == 0) atomicMin(&p.clock[1], ~(unsigned long long) wall_clock64());
     if (SRC == SRC_WIDE) { JTX_PROF_WIDE_EXPORT(p, cnt) }
     JTX_PROF_PHASES_END(p, ps, lane, true)
     JTX_PROF_TIMELINE_END(p, lane, (int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6))

@@ -24,15 +24,14 @@ struct RenderParams {
     // then adds them to the film in sample order
     float4 *rad; int strata_per_group; int rad_stride;
     // k_render_paths: persistent waves take (8x8 pixel block, strata group) chunks from this counter (zeroed per launch)
+    // (Round 5 tried in-kernel launch clocks -- first wave in, last wave out, two atomics per wave -- to time launches that overlap:
+    //  their mere presence moved the register allocation of the 8-ary instances: +9 % static instructions, C3 300 -> 308 ms.  Taken
+    //  out again: launches are timed by event pairs, and the roofline's durations come from launches with one frame in flight.)
     unsigned *work; int num_subblocks; int num_groups;
     // cancellation (Camera::terminateRender / stopRender_, camera.hpp:77, polled per pixel camera.cpp:84-98): a host-mapped
     // word; persistent waves read it whenever they fetch a chunk and stop handing out paths, k_resolve_samples then leaves
     // the film as the last completed pass left it
     const unsigned *stop;
-    // k_render_paths: when and until when the launch really ran -- [0] = min over its waves of wall_clock64() at entry, [1] = min of
-    // ~wall_clock64() at exit (both words start as all ones); or null.  With several frames of a scene in flight an event pair on the
-    // launch stream also times the wait for free wave slots; this does not (it is what rocprofv3's kernel trace shows).
-    unsigned long long *clock;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----

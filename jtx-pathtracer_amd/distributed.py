@@ -37,7 +37,7 @@ def owned_tiles(width, height, rank, world):
 
 
 def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count_rays=False,
-                 sample_begin=0, sample_end=0, integrator=0, profile_kernels=False, frame_slot=0):
+                 sample_begin=0, sample_end=0, integrator=0, profile_kernels=False, frame_slot=0, sequence_end=False):
     """Launch this rank's share of the frame into device tensors `acc` (H*W*3 f32) / `img` (H*W*3 u8).
 
     Asynchronous on `stream` (an int hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).  `frame_slot` 0 / 1: two frames of
@@ -51,6 +51,7 @@ def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count
     o.integrator = integrator
     o.reserved = 1 if profile_kernels else 0
     o.frame_slot = frame_slot
+    o.sequence_end = 1 if sequence_end else 0
     capi.check(lib.jtx_mi_render_device(scene.handle, C.byref(cam_desc), C.byref(o),
                                         C.c_void_p(acc.data_ptr()),
                                         C.c_void_p(img.data_ptr()) if img is not None else None,
@@ -187,6 +188,16 @@ class ShardPipeline:
         self.timed = []                  # (timing only) per frame: (event before, event after) the exchange on the side stream
         self._ms, self._nms = 0.0, 0
 
+    def prime(self):
+        """one untimed frame per frame slot, then a synchronisation: every slot's radiance records (2 GB each for a 1080p x 64 spp frame)
+        are allocated and their pages mapped at first touch -- 6 ms per slot that belong to set-up, not to the first frames of a loop"""
+        import torch
+        for _ in range(len(self.accs)):
+            self.step(last=True)
+        torch.cuda.synchronize()
+        self.n = 0
+        self.reset_timing()
+
     def start_timing(self):
         self.timing = True
         self.reset_timing()
@@ -213,8 +224,9 @@ class ShardPipeline:
         for st in self.rstreams + ([self.xstream] if self.xstream is not None else []):
             e = torch.cuda.Event(); e.record(st); stream.wait_event(e)
 
-    def step(self, render_stream=None):
-        """enqueue one frame.  (`render_stream`: accepted for round 4's signature; the pipeline renders on streams of its own)"""
+    def step(self, render_stream=None, last=False):
+        """enqueue one frame.  `last`: nothing follows it (jtx_mi_render_opts.sequence_end: its launch is cut like a lone one, so that its
+        end is short).  (`render_stream`: accepted for round 4's signature; the pipeline renders on streams of its own)"""
         import torch
         b = self.n % len(self.accs)
         self.n += 1
@@ -222,7 +234,7 @@ class ShardPipeline:
         if self.gatherer is not None:
             rs.wait_event(self.exchanged[b])                 # the exchange two frames back has read this pair
         render_shard(self.scene, self.cam, self.rank, self.world, self.accs[b], self.imgs[b],
-                     stream=rs.cuda_stream, integrator=self.integrator, frame_slot=b % len(self.rstreams))
+                     stream=rs.cuda_stream, integrator=self.integrator, frame_slot=b % len(self.rstreams), sequence_end=last)
         self.rendered[b].record(rs)
         if self.gatherer is None:
             return
