@@ -7,10 +7,12 @@
 #include "jtx_launch.hpp"
 #include "jtx_wide_quant.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <csignal>
 #include <cxxabi.h>
+#include <deque>
 #include <execinfo.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -153,7 +155,7 @@ namespace {
 // after the stream has drained: did the last persistent launch stop on the cancellation flag (k_render_paths pushes its
 // chunk counter past 2^30 then, and k_resolve_samples skips the pass)?  Launches that never poll (counting, alternate
 // integrators, wavefront) complete, and a cancellation is honoured between their passes.
-bool passAbandoned(jtx_mi_scene &s);
+bool passAbandoned(jtx_mi_scene &s, int slot);
 }
 
 struct jtx_mi_scene {
@@ -212,14 +214,18 @@ struct jtx_mi_scene {
     hipEvent_t slot_done[JTX_MI_FRAME_SLOTS] = {};
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (kWorkRing, used round-robin)
     unsigned work_slot = 0;
-    unsigned *last_work = nullptr;   // chunk counter of the last k_render_paths launch: >= 2^30 after the stream drained = that pass was abandoned
-    // a pass whose radiance records exceed the buffer cap goes in several launches of consecutive strata, each resolved on its
-    // own: (chunk counter, first stratum, one past the last) of every launch of the last pass, in order
-    struct PassPart { unsigned *work; int begin, end; };
-    std::vector<PassPart> pass_parts;
-    int pass_resolved_end = 0;       // strata of the last pass that are in the film (set by passAbandoned)
+    // Per frame slot, the last pass launched in it.  last_work: chunk counter of its last k_render_paths launch (null: a launch without
+    // one): >= 2^30 after its stream drained = that pass was abandoned.  A pass whose radiance records exceed the buffer cap goes in several
+    // launches of consecutive strata, each resolved on its own: parts = (chunk counter, first stratum, one past the last) of every launch
+    // of the pass, in order.  resolved_end: strata of the pass that are in the film (set by passAbandoned).
+    struct PassPart { unsigned *work; volatile unsigned *abandoned; int begin, end; };   // (abandoned: the launch's word of abandon_host)
+    struct PassRec { unsigned *last_work = nullptr; std::vector<PassPart> parts; int resolved_end = 0; } pass[JTX_MI_FRAME_SLOTS];
+    int last_slot = 0;               // the slot of the last launch (jtx_mi_cancel_pending looks at that pass)
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
-    DevBuf<unsigned char> film_img;
+    DevBuf<unsigned char> film_img;  // RGB8 preview ...
+    DevBuf<unsigned char> film_imgx[JTX_MI_FRAME_SLOTS - 1];   // ... and those of passes i = 1, 2 (mod 3) when several passes are in flight: each waits in a buffer of its own
+    hipStream_t streamx[JTX_MI_FRAME_SLOTS - 1] = {};          // jtx_mi_render: the streams of those passes (created at the first progressive render)
+    hipEvent_t resolved_ev[JTX_MI_FRAME_SLOTS] = {};           // recorded behind the resolve of the last pass of each residue
     DevScene dev{};
     // wavefront integrator state (sized for pixels * strata-per-batch slots)
     DevBuf<float> wf_floats;         // all float SoA arrays, carved
@@ -240,13 +246,18 @@ struct jtx_mi_scene {
     int last_completed = 0;              // strata in the film after the last jtx_mi_render (== sample_end unless cancelled)
     unsigned *stop_host = nullptr;       // host-mapped cancellation word (jtx_mi_cancel), read by the persistent kernels
     const unsigned *stop_dev = nullptr;
+    unsigned *abandon_host = nullptr;    // host-mapped: one word per launch of the work ring, set by k_resolve_samples when its pass was abandoned
+    unsigned *abandon_dev = nullptr;
 
     ~jtx_mi_scene() {
         for (auto &e : pending) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         for (auto &e : free_events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         for (auto &e : slot_done) if (e) (void) hipEventDestroy(e);
+        for (auto &e : resolved_ev) if (e) (void) hipEventDestroy(e);
+        for (auto &x : streamx) if (x) (void) hipStreamDestroy(x);
         if (stream) (void) hipStreamDestroy(stream);
         if (stop_host) (void) hipHostFree(stop_host);
+        if (abandon_host) (void) hipHostFree(abandon_host);
         if (mesh_xf_pinned) (void) hipHostFree(mesh_xf_pinned);
         if (pin_img) (void) hipHostFree(pin_img);
         if (pin_acc) (void) hipHostFree(pin_acc);
@@ -900,8 +911,11 @@ void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_m
 }
 
 // One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
+// beforeResolve (jtx_mi_render, two passes in flight): the event behind the previous pass's resolve -- this pass's resolve adds to the same
+// film and must follow it; prevWork: that pass's chunk counter (RenderParams::prev_work).
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
-                  float *d_acc, unsigned char *d_img, hipStream_t stream) {
+                  float *d_acc, unsigned char *d_img, hipStream_t stream, hipEvent_t beforeResolve = nullptr, unsigned *prevWork = nullptr,
+                  int gridShare = 1) {
     const int slot = o.frame_slot;
     if (slot < 0 || slot >= JTX_MI_FRAME_SLOTS) throw std::runtime_error("frame_slot: 0 .. " + std::to_string(JTX_MI_FRAME_SLOTS - 1));
     if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (HBM wavefront)");
@@ -925,8 +939,11 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
         ~SlotFence() { for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) if (both || k == slot) (void) hipEventRecord(s.slot_done[k], st); }
     } fence(s, stream, slot, !slotted);
     RenderParams p{};
-    s.last_work = nullptr;            // only a launch that owns a chunk counter arms passAbandoned() (a stale one would void later passes)
-    s.pass_parts.clear(); s.pass_resolved_end = se;
+    jtx_mi_scene::PassRec &rec = s.pass[slot];
+    s.last_slot = slot;
+    rec.last_work = nullptr;          // only a launch that owns a chunk counter arms passAbandoned() (a stale one would void later passes)
+    rec.parts.clear(); rec.resolved_end = se;
+    p.prev_work = nullptr; p.abandoned = nullptr;
     p.scene = s.dev;
     p.cam = deriveCamera(cam);
     p.width = cam.width; p.height = cam.height; p.max_depth = cam.max_depth;
@@ -1021,12 +1038,17 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.num_groups = (q.sample_end - q.sample_begin + q.strata_per_group - 1) / q.strata_per_group;
                 q.num_subblocks = owned * 16;
                 if (!s.work.p) s.work.alloc(kWorkRing);
-                q.work = s.work.p + (s.work_slot++ & (kWorkRing - 1));    // one counter per launch in flight
+                const unsigned ring = s.work_slot++ & (kWorkRing - 1);
+                q.work = s.work.p + ring;                                  // one counter per launch in flight
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
-                s.last_work = q.work;
-                s.pass_parts.push_back({q.work, q.sample_begin, q.sample_end});
-                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
+                s.abandon_host[ring] = 0u;                                 // (this launch's resolve is the only writer, and it has not been enqueued yet)
+                q.abandoned = s.abandon_dev + ring;
+                q.prev_work = rec.parts.empty() ? prevWork : rec.parts.back().work;
+                rec.last_work = q.work;
+                rec.parts.push_back({q.work, s.abandon_host + ring, q.sample_begin, q.sample_end});
+                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream, gridShare));
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
+                if (beforeResolve && b0 == sb) HIPCHK(hipStreamWaitEvent(stream, beforeResolve, 0));      // the film: behind the previous pass's resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }
         } else if (groups > 1) {
@@ -1163,6 +1185,9 @@ int jtx_mi_scene_create(const jtx_mi_scene_desc *desc, jtx_mi_scene **out) {
         HIPCHK(hipHostMalloc((void **) &s->stop_host, sizeof(unsigned), hipHostMallocMapped));
         *s->stop_host = 0u;
         { void *d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, s->stop_host, 0)); s->stop_dev = (const unsigned *) d; }
+        HIPCHK(hipHostMalloc((void **) &s->abandon_host, kWorkRing * sizeof(unsigned), hipHostMallocMapped));
+        std::memset(s->abandon_host, 0, kWorkRing * sizeof(unsigned));
+        { void *d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, s->abandon_host, 0)); s->abandon_dev = (unsigned *) d; }
         { int cus = 0; HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device)); s->num_cus = cus > 0 ? cus : 256; }
         lap("stream, stop flag, CU count");
         *out = s;
@@ -1556,15 +1581,14 @@ int jtx_mi_get_counters(jtx_mi_scene *s, jtx_mi_counters *out) {
 }
 
 namespace {
-bool passAbandoned(jtx_mi_scene &s) {
-    if (!s.last_work) return false;
-    // the launches of the pass in order: every one before the first abandoned one completed and was resolved into the film
-    for (const auto &part : s.pass_parts) {
-        unsigned v = 0;
-        HIPCHK(hipMemcpy(&v, part.work, sizeof v, hipMemcpyDeviceToHost));
-        if (v >= 0x40000000u) { s.pass_resolved_end = part.begin; return true; }
-    }
-    if (!s.pass_parts.empty()) s.pass_resolved_end = s.pass_parts.back().end;
+bool passAbandoned(jtx_mi_scene &s, int slot) {
+    jtx_mi_scene::PassRec &rec = s.pass[slot];
+    if (!rec.last_work) return false;
+    // the launches of the pass in order: every one before the first abandoned one completed and was resolved into the film.  (The
+    // verdict is read from HOST memory: every launch's resolve has written it there before its stream drained -- no device copy.)
+    for (const auto &part : rec.parts)
+        if (*part.abandoned != 0u) { rec.resolved_end = part.begin; return true; }
+    if (!rec.parts.empty()) rec.resolved_end = rec.parts.back().end;
     return false;
 }
 }
@@ -1576,7 +1600,7 @@ int jtx_mi_cancel_pending(jtx_mi_scene *s, int32_t *out) {
         DeviceGuard dg(s->device);
         const bool pending = __atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE) != 0;
         bool abandoned = false;
-        if (pending) { std::lock_guard<std::mutex> lk(s->mu); abandoned = passAbandoned(*s); }   // (reads and writes the pass records of the scene)
+        if (pending) { std::lock_guard<std::mutex> lk(s->mu); abandoned = passAbandoned(*s, s->last_slot); }   // (reads and writes the pass records of the scene)
         *out = pending ? (abandoned ? 2 : 1) : 0;
         return 0;
     } catch (const std::exception &e) { return fail(e.what()); }
@@ -1607,20 +1631,67 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         const size_t npix = (size_t) cam->width * cam->height;
         std::unique_lock<std::mutex> lk(s->mu);
         __atomic_store_n(s->stop_host, 0u, __ATOMIC_RELEASE);                  // stopRender_ = false (camera.cpp:48)
-        if (s->film_acc.n != 3 * npix) { s->film_acc.alloc(3 * npix); s->film_img.alloc(3 * npix); }
+        if (s->film_acc.n != 3 * npix) { s->film_acc.alloc(3 * npix); s->film_img.alloc(3 * npix); for (auto &b : s->film_imgx) b.release(); }
         if (sb == 0) HIPCHK(hipMemsetAsync(s->film_acc.p, 0, sizeof(float) * 3 * npix, s->stream));
         else if (hostPinned(acc_rgb)) HIPCHK(hipMemcpyAsync(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix, hipMemcpyHostToDevice, s->stream));
         else { HIPCHK(hipStreamSynchronize(s->stream)); stagedH2D(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix); }      // a pageable caller buffer: through the library's staging
         HIPCHK(hipMemsetAsync(s->film_img.p, 0, 3 * npix, s->stream));
         const int tick = (cb && o.samples_per_tick > 0) ? o.samples_per_tick : (se - sb);
         jtx_mi_counters total{}; const bool count = o.count_rays != 0;
-        // Passes are pipelined one deep: pass i + 1 is enqueued before pass i's preview is handed to the callback, so the
-        // GPU never waits for the host.  Per pass only the RGB8 preview travels (what the UI shows, display.cpp:702-703);
-        // the float accumulation buffer is copied once, at the end or at the cancellation.
-        auto enqueue = [&](int b) {
-            const int e = b + tick < se ? b + tick : se;
-            launchRender(*s, *cam, o, b, e, s->film_acc.p, img_rgb ? s->film_img.p : nullptr, s->stream);
-            return e;
+        // SEVERAL PASSES IN FLIGHT (round 5): pass i runs on stream and frame slot i mod K (K = 3), so that pass i + 1's path kernel runs
+        // beside the last chunks of pass i, and pass i's resolve -- which finds no free wave slot while pass i + 1 fills the chip -- and
+        // its preview copy beside pass i + 2 (with one stratum per pass, the reference's default, camera.hpp:181, a pass is 0.45 ms of
+        // work, and its end, its resolve and the host's turn-around cost as much again).  Passes enter the film IN ORDER: the resolve of
+        // pass i + 1 waits for the event behind the resolve of pass i, and is skipped when pass i was abandoned (RenderParams::
+        // prev_work).  Per pass only the RGB8 preview travels (what the UI shows, display.cpp:702-703), each residue from a device buffer
+        // of its own; the float accumulation buffer is copied once, at the end or at the cancellation.  Counted passes go one at a time
+        // (the counter block is per launch); JTX_PASSES_IN_FLIGHT=1: all do.
+        constexpr int KMAX = JTX_MI_FRAME_SLOTS;
+        static const int maxInFlight = [] { const char *e = getenv("JTX_PASSES_IN_FLIGHT"); const int v = e ? atoi(e) : KMAX; return v < 1 ? 1 : (v > KMAX ? KMAX : v); }();
+        const int npasses = (se - sb + tick - 1) / tick;
+        const int K = (count || npasses < 2) ? 1 : (maxInFlight < npasses ? maxInFlight : npasses);
+        const bool two = K > 1;
+        // ... and a SMALL pass takes only part of the wave slots: so many waves that a lane gets ~JTX_PASS_PATHS_PER_LANE paths (16).  A wave
+        // ends with its lanes waiting for the longest of its last paths (up to maxDepth + 1 traversals); with one stratum per pass and the
+        // whole chip, a lane has 4.5 paths and that wait is 40 % of the launch.  The passes in flight fill the rest of the chip, and the
+        // resolve of a finished pass finds free slots at once instead of starving behind persistent waves (profiles/r05_progressive.md).
+        // JTX_PASS_GRID_SHARE=n: 1 / n of the slots, whatever the size.
+        static const int shareEnv = [] { const char *e = getenv("JTX_PASS_GRID_SHARE"); return e ? atoi(e) : 0; }();
+        static const int perLane = [] { const char *e = getenv("JTX_PASS_PATHS_PER_LANE"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
+        int gridShare = 1;
+        if (two) {
+            int bs = 0; const long cap = (long) jtx_render_paths_grid(s->dev, s->num_cus, &bs) * (bs / 64);
+            const long want = (long) ((double) npix * tick / (64.0 * perLane));
+            gridShare = want >= cap ? 1 : (int) std::min<long>(16, (cap + std::max<long>(want, 1) - 1) / std::max<long>(want, 1));
+            if (shareEnv > 0) gridShare = shareEnv;
+        }
+        hipStream_t st[KMAX]; unsigned char *dimg[KMAX];
+        for (int k = 0; k < KMAX; ++k) { st[k] = s->stream; dimg[k] = img_rgb ? s->film_img.p : nullptr; }
+        if (two) {
+            for (auto &e : s->resolved_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(s->resolved_ev[0], s->stream));
+            for (int k = 1; k < K; ++k) {
+                if (!s->streamx[k - 1]) HIPCHK(hipStreamCreateWithFlags(&s->streamx[k - 1], hipStreamNonBlocking));
+                st[k] = s->streamx[k - 1];
+                if (img_rgb) { if (s->film_imgx[k - 1].n != 3 * npix) s->film_imgx[k - 1].alloc(3 * npix); dimg[k] = s->film_imgx[k - 1].p; }
+                HIPCHK(hipStreamWaitEvent(st[k], s->resolved_ev[0], 0));        // every stream starts behind the film's set-up (clear / upload above)
+            }
+        }
+        struct DrainAll { hipStream_t *v; int n; ~DrainAll() { for (int k = 0; k < n; ++k) (void) hipStreamSynchronize(v[k]); } } drainAll{st, K};   // nothing of this call outlives it
+        auto syncAll = [&] { for (int k = 0; k < K; ++k) HIPCHK(hipStreamSynchronize(st[k])); };
+        struct Pass { int idx, begin, end; };
+        std::deque<Pass> flight;
+        int nextIdx = 0, nextBegin = sb;
+        auto enqueue = [&] {
+            const int idx = nextIdx++, b = nextBegin, e = b + tick < se ? b + tick : se, par = idx % K;
+            nextBegin = e;
+            jtx_mi_render_opts o2 = o; o2.frame_slot = par;
+            o2.sequence_end = (e >= se) ? 1 : 0;
+            const bool chain = two && idx > 0;
+            launchRender(*s, *cam, o2, b, e, s->film_acc.p, dimg[par], st[par], chain ? s->resolved_ev[(idx - 1) % K] : nullptr,
+                         chain ? s->pass[(idx - 1) % K].last_work : nullptr, gridShare);
+            if (two) HIPCHK(hipEventRecord(s->resolved_ev[par], st[par]));
+            flight.push_back({idx, b, e});
         };
         // Film delivery: a pinned caller buffer (jtx_mi_pin_host / hipHostRegister: what the Camera mirrors do with img_ /
         // acc_) is the DMA target itself; a pageable one is fed through the scene's pinned staging buffers and one host
@@ -1640,53 +1711,67 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double tMark = now();
         auto lap = [&](const char *what) { if (trace) { const double t = now(); fprintf(stderr, "[jtx_mi_render] %-18s %8.3f ms\n", what, t - tMark); tMark = t; } };
-        auto fetchImg = [&] {                                                   // blocks until the stream has drained
-            if (!img_rgb) { HIPCHK(hipStreamSynchronize(s->stream)); return; }
-            HIPCHK(hipMemcpyAsync(imgDirect ? img_rgb : s->pin_img, s->film_img.p, 3 * npix, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipStreamSynchronize(s->stream));
+        auto fetchImg = [&](int par) {                                          // the preview of the last pass of this parity; blocks until its stream has drained
+            if (!img_rgb) { HIPCHK(hipStreamSynchronize(st[par])); return; }
+            HIPCHK(hipMemcpyAsync(imgDirect ? img_rgb : s->pin_img, dimg[par], 3 * npix, hipMemcpyDeviceToHost, st[par]));
+            HIPCHK(hipStreamSynchronize(st[par]));
         };
         bool cancelled = false;
         int done = sb;                                                          // strata whose sums are in the film
-        int inFlightEnd = enqueue(sb);
-        while (true) {
+        int lastPar = 0;                                                        // parity of the last pass that entered the film (its preview is the film's)
+        // after a cancellation: the passes still in flight, in order -- each either ran to its end (its strata are in the film and count) or
+        // was abandoned, and then every later one was too (the resolve chain)
+        auto settle = [&] {
+            syncAll();
+            for (const Pass &q : flight) {
+                const int par = q.idx % K;
+                if (passAbandoned(*s, par)) { if (s->pass[par].resolved_end > done) { done = s->pass[par].resolved_end; lastPar = par; } break; }
+                done = q.end; lastPar = par;
+            }
+            flight.clear();
+        };
+        for (int k = 0; k < K && nextBegin < se; ++k) enqueue();
+        while (!flight.empty()) {
+            const Pass cur = flight.front();
+            const int par = cur.idx % K;
             lap("enqueue");
-            fetchImg();                                                         // the pass in flight: preview to (pinned) host memory
+            fetchImg(par);                                                      // this pass: preview to (pinned) host memory
             lap("pass + img D2H");
-            if (passAbandoned(*s)) {                                            // the kernels saw the cancellation: the abandoned launch left no trace;
-                if (s->pass_resolved_end > done) done = s->pass_resolved_end;   // earlier launches of a split pass are in the film and count
+            if (passAbandoned(*s, par)) {                                       // the kernels saw the cancellation: the abandoned launch left no trace;
+                if (s->pass[par].resolved_end > done) { done = s->pass[par].resolved_end; lastPar = par; }   // earlier launches of a split pass are in the film and count
+                flight.clear();                                                 // (the passes behind it are abandoned with it: the resolve chain)
                 cancelled = true; break;
             }
-            done = inFlightEnd;
+            flight.pop_front();
+            done = cur.end; lastPar = par;
             if (count) {
                 unsigned long long h[64];
                 HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
                 countersAddWords(total, h);
             }
-            const bool more = done < se;
-            if (more && !count) inFlightEnd = enqueue(done);                   // next pass runs while the host copies / the callback looks
-            if (img_rgb && !imgDirect && (cb || !more)) std::memcpy(img_rgb, s->pin_img, 3 * npix);
+            const bool more = nextBegin < se;
+            if (more && !count) enqueue();                                      // the next pass of this parity: behind this one's preview copy on its stream
+            if (img_rgb && !imgDirect && (cb || flight.empty())) std::memcpy(img_rgb, s->pin_img, 3 * npix);
             lap("img memcpy");
             if (cb) {
                 lk.unlock();
                 const int stop = cb(done, spp, user);                           // currentSample_ advance, camera.cpp:68-74
                 lk.lock();
                 if (stop) {
-                    if (more && !count) {                                       // abandon the pass in flight
+                    if (!flight.empty()) {                                      // abandon what is in flight
                         __atomic_store_n(s->stop_host, 1u, __ATOMIC_RELEASE);
-                        HIPCHK(hipStreamSynchronize(s->stream));
                         // the waves poll the flag at every 64th chunk fetch: a short pass (or a slow callback) completes and is
                         // resolved before they look -- then its strata ARE in the film and count as completed
-                        if (!passAbandoned(*s)) done = inFlightEnd;
-                        else if (s->pass_resolved_end > done) done = s->pass_resolved_end;
+                        settle();
                     }
                     cancelled = true; break;
                 }
             }
-            if (!more) break;
-            if (count) inFlightEnd = enqueue(done);                            // counted passes: the counter block is per launch
+            if (flight.empty() && more && count) enqueue();                     // counted passes: the counter block is per launch
         }
+        syncAll();
         HIPCHK(hipMemcpyAsync(accDirect ? acc_rgb : s->pin_acc, s->film_acc.p, sizeof(float) * 3 * npix, hipMemcpyDeviceToHost, s->stream));
-        if (cancelled) fetchImg(); else HIPCHK(hipStreamSynchronize(s->stream));
+        if (cancelled) fetchImg(lastPar); else HIPCHK(hipStreamSynchronize(s->stream));
         if (cancelled && img_rgb && !imgDirect) std::memcpy(img_rgb, s->pin_img, 3 * npix);
         lap("acc D2H");
         if (!accDirect) std::memcpy(acc_rgb, s->pin_acc, sizeof(float) * 3 * npix);

@@ -555,7 +555,16 @@ __global__ void __launch_bounds__(BLOCK) k_resolve_samples(RenderParams p) {
     if (pslot >= p.rad_stride || row >= p.height || col >= p.width) return;
     // a cancelled pass has incomplete records: the wave that saw the cancellation pushed the chunk counter past 2^30
     // (device memory: one cached load per thread, not one PCIe read of the host's flag)
-    if (p.work && *(volatile const unsigned *) p.work >= 0x40000000u) return;
+    const bool own = p.work && *(volatile const unsigned *) p.work >= 0x40000000u;
+    // ... or the pass before this one was: then this one does not enter the film either, and says so to the next
+    const bool prev = p.prev_work && *(volatile const unsigned *) p.prev_work >= 0x40000000u;
+    if (own || prev) {
+        if (pslot == 0) {
+            if (prev && !own) atomicMax(p.work, 0x40000000u);
+            if (p.abandoned) __hip_atomic_store(p.abandoned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host's copy of the verdict
+        }
+        return;
+    }
     const size_t pix = (size_t) row * p.width + col;
     f3 acc = mk3(0.0f);
     if (p.sample_begin > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
@@ -579,7 +588,10 @@ int jtx_render_paths_grid(const DevScene &sc, int num_cus, int *block_size) {
     return (int) (((long) num_cus * 4 * (wide ? JTX_WIDE_OCC : JTX_RP_OCC) * 64 + bs - 1) / bs);
 }
 
-hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream) {
+// share: this launch takes 1 / share of the wave slots (jtx_mi_render with `share` passes in flight: together they fill the chip, every
+// wave of a small pass gets `share` times as many chunks -- its end, where lanes wait for the longest of the last paths, weighs less --
+// and the resolve of a finished pass finds free slots at once)
+hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream, int share) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const bool lds = p.scene.lds_threaded != 0;
     const bool wide = !lds && p.scene.wide != nullptr;
@@ -593,6 +605,7 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, i
     // persistent grid: the waves the GPU can hold (occupancy of the launch bounds), no more than there are chunks
     const int occ = wide ? JTX_WIDE_OCC : JTX_RP_OCC;
     long waves = (long) num_cus * 4 * occ;
+    if (share > 1) waves = (waves / share + (bs / 64) - 1) / (bs / 64) * (bs / 64);
     const long chunks = (long) p.num_subblocks * p.num_groups;
     if (waves > chunks) waves = chunks;
     const dim3 grid((unsigned) ((waves * 64 + bs - 1) / bs)), block(bs);

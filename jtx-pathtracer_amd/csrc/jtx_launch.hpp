@@ -32,6 +32,14 @@ struct RenderParams {
     // word; persistent waves read it whenever they fetch a chunk and stop handing out paths, k_resolve_samples then leaves
     // the film as the last completed pass left it
     const unsigned *stop;
+    // k_resolve_samples only (at the END of the block: the path kernels' argument offsets stay where they were):
+    // prev_work: jtx_mi_render with several passes in flight -- the chunk counter of the pass BEFORE this one, or null.  The resolve leaves
+    //   the film alone, and marks its own pass abandoned, when that pass was abandoned: passes enter the film in order or not at all.
+    // abandoned: a host-mapped word of this launch; the resolve sets it when the pass was abandoned, so that the host learns it from its
+    //   own memory after the stream has drained -- a 4-byte device-to-host copy is a blit KERNEL, and waits a millisecond for a wave slot
+    //   while the next pass's persistent waves fill the chip (round 5 timeline: profiles/r05_progressive.md).
+    unsigned *prev_work;
+    unsigned *abandoned;
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
@@ -114,7 +122,7 @@ hipError_t jtx_wf_shade(const jtx::WfParams &p, int grid, bool count, int typeCo
 hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write_img, hipStream_t st);
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
-hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream);
+hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream, int share = 1);
 int jtx_render_paths_grid(const jtx::DevScene &sc, int num_cus, int *block_size);   // workgroups the persistent grid holds (host only)
 hipError_t jtx_launch_render_alt(const jtx::RenderParams &p, int num_owned_tiles, bool count, int li, hipStream_t stream);
 hipError_t jtx_launch_radiance_samples_alt(const jtx::DevScene &sc, const jtx::DCam &cam, int maxDepth, int li, int n, const int *row,
