@@ -323,6 +323,32 @@ def test_capi_exports_every_declared_symbol():
     assert C.sizeof(jtx._capi.BvhNode) == 32 and C.sizeof(jtx._capi.TriRef) == 8
 
 
+def test_ctypes_structs_match_the_header(tmp_path):
+    """the C-ABI's structs as a C compiler lays them out (gcc on include/jtx_mi.h: a plain C header) against the ctypes mirrors of
+    _capi.py -- sizes and the offsets of the fields this round added (frame_slot, sequence_end, the per-class tallies, the spare-set bytes)"""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "jtx_mi.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(jtx_mi_render_opts), offsetof(jtx_mi_render_opts, frame_slot),
+           offsetof(jtx_mi_render_opts, sequence_end), sizeof(jtx_mi_counters), offsetof(jtx_mi_counters, n_shade_class),
+           offsetof(jtx_mi_counters, n_eval_class), sizeof(jtx_mi_scene_info), offsetof(jtx_mi_scene_info, wide_bytes64),
+           offsetof(jtx_mi_scene_info, rebuild_spare_bytes), sizeof(jtx_mi_camera_desc), JTX_MI_FRAME_SLOTS);
+    return 0;
+}
+''')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    k = jtx._capi
+    want = [C.sizeof(k.RenderOpts), k.RenderOpts.frame_slot.offset, k.RenderOpts.sequence_end.offset, C.sizeof(k.Counters),
+            k.Counters.n_shade_class.offset, k.Counters.n_eval_class.offset, C.sizeof(k.SceneInfo), k.SceneInfo.wide_bytes64.offset,
+            k.SceneInfo.rebuild_spare_bytes.offset, C.sizeof(k.CameraDesc), jtx.distributed.FRAME_SLOTS]
+    assert got == want
+
+
 def test_no_cpu_fallback_in_product():
     """Without a GPU every compute entry point must fail loudly, never fall back to the CPU."""
     lib = jtx._capi.load()
