@@ -1169,7 +1169,7 @@ def test_cancel_from_the_callback_counts_a_pass_that_completed(gpu, cornell_pair
         cam.samplesPerPass_ = 2
         cam.render(sc, progress=lambda c, t: cam.terminateRender())         # stop at the first preview; pass 2 is in flight
         n = cam.currentSample_
-        assert n in (2, 4)
+        assert n in (2, 4, 6, 8)                                            # (up to three passes are in flight behind the callback's)
         part = gpu.StaticCamera(64, 64, data.camera, 4, 2, 4); part.render(sc, sample_begin=0, sample_end=n)
         assert_same_f32(cam.acc_, part.acc_, f"film after a callback cancel at {n}")
 
@@ -1896,3 +1896,43 @@ def test_rebuild_spare_set_is_accounted_and_can_be_released(gpu):
     g.render(sc, count_rays=False)
     assert_same_f32(g.acc_, ref.acc_, "frame after the rebuild that followed the release")
     sc.destroy()
+
+
+def test_cancellation_with_passes_in_flight_leaves_a_prefix_of_the_strata(gpu, mixed_pair):
+    """jtx_mi_render keeps three passes in flight (round 5); a cancellation from another thread may catch any of them anywhere.
+    Whatever it catches: the film must hold EXACTLY the strata [0, currentSample_) -- passes enter the film in order or not at all
+    (the resolve chain, RenderParams::prev_work) -- and the RGB8 preview must be that film's.  Twelve cancellations at different
+    moments of a 24-pass render, one stratum per pass, plus one from the callback."""
+    import threading, time
+    data, sc, osc = mixed_pair
+    W, H = 480, 270
+    refs = {}
+
+    def ref(n):
+        if n not in refs:
+            c = gpu.StaticCamera(W, H, data.camera, 6, 4, 6)
+            if n:
+                c.render(sc, sample_begin=0, sample_end=n)
+            refs[n] = (c.acc_.copy(), c.img_.copy())
+        return refs[n]
+    full = gpu.StaticCamera(W, H, data.camera, 6, 4, 6); full.samplesPerPass_ = 1
+    t0 = time.perf_counter(); full.render(sc, progress=lambda c, t: None); t_full = time.perf_counter() - t0
+    assert full.currentSample_ == 24
+    assert_same_f32(full.acc_, ref(24)[0], "24 passes, three in flight")
+    seen = set()
+    for k in range(12):
+        cam = gpu.StaticCamera(W, H, data.camera, 6, 4, 6); cam.samplesPerPass_ = 1
+        timer = threading.Timer(t_full * (0.05 + 0.08 * k), cam.terminateRender)
+        timer.start(); cam.render(sc, progress=lambda c, t: None); timer.join()
+        n = cam.currentSample_
+        seen.add(n)
+        acc, img = ref(n)
+        assert_same_f32(cam.acc_, acc, f"film after a cancellation that left {n} strata")
+        if n:
+            assert (cam.img_ == img).all(), f"preview after a cancellation that left {n} strata"
+    assert len(seen) >= 3 and min(seen) < 24, seen                            # the cancellations did land at different passes
+    cam = gpu.StaticCamera(W, H, data.camera, 6, 4, 6); cam.samplesPerPass_ = 1
+    cam.render(sc, progress=lambda c, t: cam.terminateRender() if c == 5 else None)
+    n = cam.currentSample_
+    assert 5 <= n <= 8
+    assert_same_f32(cam.acc_, ref(n)[0], f"film after a callback cancel at 5 that left {n} strata")
