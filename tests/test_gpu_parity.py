@@ -1936,3 +1936,59 @@ def test_cancellation_with_passes_in_flight_leaves_a_prefix_of_the_strata(gpu, m
     n = cam.currentSample_
     assert 5 <= n <= 8
     assert_same_f32(cam.acc_, ref(n)[0], f"film after a callback cancel at 5 that left {n} strata")
+
+
+def test_headline_frame_against_the_oracle_in_every_pixel(gpu, cornell_pair):
+    """The frame `bench.py` times (C2: Cornell 1920x1080, 64 spp, depth 8) against a WHOLE-FRAME run of the CPU oracle -- all 2 073 600
+    pixels, film words, RGB8 bytes and every ray counter (0.73 G rays on the host's cores: ~20 s) -- where the other full-size tests
+    compare the whole frame with the counting kernel and 256 pixels with the oracle.  Through the pipelined loop
+    the bench runs: three frames in flight, the middle one checked."""
+    import time
+    import torch
+    data, sc, osc = cornell_pair
+    W, H = 1920, 1080
+    cam = data.camera_desc(W, H, 8, 8, 8)
+    t0 = time.perf_counter()
+    acc, img, cnt = osc.render(cam, threads=min(os.cpu_count() or 1, 64))
+    t_oracle = time.perf_counter() - t0
+    assert cnt["n_camera"] == W * H * 64 and cnt["n_closest"] + cnt["n_any"] == 727984390           # BASELINE.md: 5.49 rays per sample
+    dev = torch.device("cuda", 0)
+    pipe = gpu.distributed.ShardPipeline(sc, cam, 0, 1, dev, None, integrator=1)
+    for k in range(3):
+        pipe.step(last=(k == 2))
+    torch.cuda.synchronize()
+    a = pipe.accs[1].cpu().numpy().reshape(H, W, 3); i = pipe.imgs[1].cpu().numpy().reshape(H, W, 3)
+    assert np.array_equal(a.view(np.uint32), acc.view(np.uint32)), f"{int((a.view(np.uint32) != acc.view(np.uint32)).any(-1).sum())} pixels differ"
+    assert np.array_equal(i, img)
+    # ... and the counting kernel's tallies (the bench line's numerators) are the oracle's, the per-class ones included
+    acc_c, img_c, cnt_g = _frame_on_device(gpu, sc, cam, 1, count=True)
+    assert cnt_g == cnt and np.array_equal(acc_c.view(np.uint32), acc.view(np.uint32))
+    assert t_oracle < 240
+
+
+@pytest.mark.parametrize("which", ["mixed", "atrium_full"])
+def test_timed_workloads_against_the_oracle_in_every_pixel(gpu, which, request):
+    """... and the other two timed workloads: C5 (mixed materials, 1920x1080, all 128 strata: ~30 s of oracle on the host's cores) and C3
+    (the 262 k-triangle atrium at 1920x1080: strata [0, 16) of its 64, ~20 s -- the whole frame would take the oracle 80 s) through the
+    uncounted kernels of the 8-ary BVH: every pixel's film words and RGB8 bytes, and through the counting kernel every ray counter."""
+    if which == "atrium_full":
+        data, sc, osc = request.getfixturevalue("atrium_full")
+        dims, s_end = (1920, 1080, 8, 8, 8), 16
+    else:
+        data = gpu.scenes.mixed()
+        sc = gpu.Scene(data); sc.buildBVH()
+        osc = ol.OracleScene(data)
+        dims, s_end = (1920, 1080, 16, 8, 8), 128
+    W, H = dims[0], dims[1]
+    cam = data.camera_desc(*dims)
+    acc, img, cnt = osc.render(cam, threads=min(os.cpu_count() or 1, 64), sample_begin=0, sample_end=s_end)
+    g = gpu.StaticCamera(W, H, data.camera, dims[2], dims[3], dims[4])
+    g.render(sc, count_rays=False, sample_begin=0, sample_end=s_end)
+    assert sc.info()["wide_depth"] >= 2
+    diff = (np.asarray(g.acc_).view(np.uint32) != acc.view(np.uint32)).any(-1)
+    assert not diff.any(), f"{int(diff.sum())} of {W * H} pixels differ"
+    assert np.array_equal(g.img_, img)
+    g.render(sc, count_rays=True, sample_begin=0, sample_end=s_end)
+    assert g.counters == cnt
+    if which != "atrium_full":
+        sc.destroy()
