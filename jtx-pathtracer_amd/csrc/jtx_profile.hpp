@@ -56,7 +56,7 @@
 
 // ---- wave timeline ----
 #ifdef JTX_PROFILE_TIMELINE
-#define JTX_PROF_TIMELINE_BEGIN const long long prof_tl0 = wall_clock64(); unsigned prof_tl_iters = 0, prof_tl_active = 0;
+#define JTX_PROF_TIMELINE_BEGIN const long long prof_tl0 = wall_clock64(); unsigned prof_tl_iters = 0, prof_tl_active = 0; (void) prof_tl_iters; (void) prof_tl_active;
 #define JTX_PROF_TIMELINE_ITER(alive) prof_tl_iters++; prof_tl_active += (alive) ? 1 : 0;
 #define JTX_PROF_TIMELINE_WAVE(p, wid)                                                                                   \
     if ((wid) < 65536) { (p).counters[64 + 2 * (wid)] = (unsigned long long) prof_tl0; (p).counters[64 + 2 * (wid) + 1] = (unsigned long long) wall_clock64(); }
