@@ -308,7 +308,8 @@ def source_hash():
     d = os.path.join(ROOT, "jtx-pathtracer_amd", "csrc")
     # what the timed kernel (k_render_paths + k_resolve_samples) is compiled from; the wide-node BUILDER lives in
     # jtx_capi.hip and shows in the counter file's wide_stats (node steps per ray) instead
-    for f in ("jtx_kernels.hip", "jtx_scene_dev.hpp", "jtx_wide_quant.hpp", "jtx_bxdf.hpp", "jtx_device_math.hpp", "jtx_launch.hpp", "jtx_tiles.hpp"):
+    for f in ("jtx_kernels.hip", "jtx_scene_dev.hpp", "jtx_wide_quant.hpp", "jtx_bxdf.hpp", "jtx_device_math.hpp", "jtx_launch.hpp", "jtx_tiles.hpp",
+              "jtx_profile.hpp"):
         h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
