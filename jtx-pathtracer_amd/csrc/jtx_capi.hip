@@ -209,7 +209,7 @@ struct jtx_mi_scene {
     // pass of frame i (which finds no free wave slot while frame i + 1 fills the chip) beside the first chunks of frame i + 2.
     // slot_done[k]: recorded behind the last launch that used set k; a launch waits for it first, so renders of one slot are ordered
     // by the library whatever streams they come on, and launches that use the scene's singletons (ray counters, wavefront arrays,
-    // strata-split buffers) wait for, and record into, both.
+    // strata-split buffers) wait for, and record into, all of them.
     DevBuf<float4> rad[JTX_MI_FRAME_SLOTS];
     hipEvent_t slot_done[JTX_MI_FRAME_SLOTS] = {};
     DevBuf<unsigned> work;           // chunk counters of the persistent k_render_paths launches (kWorkRing, used round-robin)
@@ -911,7 +911,7 @@ void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_m
 }
 
 // One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
-// beforeResolve (jtx_mi_render, two passes in flight): the event behind the previous pass's resolve -- this pass's resolve adds to the same
+// beforeResolve (jtx_mi_render, several passes in flight): the event behind the previous pass's resolve -- this pass's resolve adds to the same
 // film and must follow it; prevWork: that pass's chunk counter (RenderParams::prev_work).
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
                   float *d_acc, unsigned char *d_img, hipStream_t stream, hipEvent_t beforeResolve = nullptr, unsigned *prevWork = nullptr,
