@@ -6,7 +6,8 @@ library-owned page-locked staging and by film buffers outside the malloc heap, a
 Each iteration is what Display::renderScene does after an edit (display.cpp:902-905: rebuild if dirty, then render), from scratch:
     Scene(data) -> buildBVH (host build + upload through the staging buffer) -> StaticCamera with page-locked film buffers -> render
     (uncounted kernel, film delivered to the host) -> film checked against the first iteration's -> transform edit -> rebuildBVH on the
-    device -> render -> destroy; scene, size and strata vary with the iteration, so allocations do not simply recycle.
+    device -> render -> [every 5th: the frame again with a preview per pass -- three passes in flight -- and as four frames in flight on
+    three streams / frame slots] -> destroy; scene, size and strata vary with the iteration, so allocations do not simply recycle.
 Every 50th iteration: the two-process rehearsal (two ranks sharing the card: their own contexts, IPC-free gloo exchange).
 JTX_ABORT_LOG is armed: a runtime abort leaves its reason and a native backtrace there.
 
@@ -39,6 +40,8 @@ def main():
     iters = int(args[0]) if args else 300
     budget = float(args[1]) if len(args) > 1 else 1e9
     with_rehearsal = "--no-rehearsal" not in sys.argv
+    import torch                                           # (torch brings its own HIP runtime: it initialises first, as in bench.py and conftest.py)
+    torch.zeros(1, device="cuda")
     import jtx_pathtracer_amd as jtx
     lib = jtx._capi.load()
     jtx._capi.check(lib.jtx_mi_set_device(0))
@@ -71,6 +74,23 @@ def main():
         crc = zlib.crc32(np.ascontiguousarray(cam.acc_).tobytes())
         if first.setdefault(key2, crc) != crc:
             print(f"MISMATCH at iteration {it}: {key2} film differs from its first render"); sys.exit(2)
+        if it % 5 == 4:
+            # the same frame through a preview per pass (three passes in flight, per-residue streams and preview buffers) ...
+            prog = jtx.StaticCamera(W, H, data.camera, xs, 2, 4); prog.samplesPerPass_ = 1
+            prog.render(sc, count_rays=False, progress=lambda c, t: None)
+            if zlib.crc32(np.ascontiguousarray(prog.acc_).tobytes()) != crc:
+                print(f"MISMATCH at iteration {it}: {key2} progressive film differs"); sys.exit(2)
+            prog._unpin()
+            # ... and four frames in flight on three streams / frame slots, the scene destroyed right behind them
+            dev = torch.device("cuda", 0)
+            pipe = jtx.distributed.ShardPipeline(sc, data.camera_desc(W, H, xs, 2, 4), 0, 1, dev, None, integrator=1)
+            for k in range(4):
+                pipe.step(last=(k == 3))
+            torch.cuda.synchronize()
+            got = pipe.accs[0].cpu().numpy()
+            if zlib.crc32(np.ascontiguousarray(got).tobytes()) != crc:
+                print(f"MISMATCH at iteration {it}: {key2} pipelined film differs"); sys.exit(2)
+            del pipe
         cam._unpin()
         sc.destroy()
         del cam, sc, data
