@@ -6,4 +6,4 @@ The directory name has a hyphen (it is the name the task prescribes); import it 
 """
 from . import _capi, scenes, api, distributed, gltf     # noqa: F401
 from .api import Scene, MultiScene, StaticCamera, DynamicCamera, JtxMiError  # noqa: F401
-from .build import build_all, lib_is_built      # noqa: F401
+from .build import build_all, build_test_hooks, lib_is_built      # noqa: F401

@@ -39,6 +39,34 @@ def _compile_one(args):
     return src, cmd, r.returncode, r.stdout + r.stderr
 
 
+TEST_LIB = os.path.join(_HERE, "libjtx_mi_testhooks.so")
+
+
+def build_test_hooks(force=False):
+    """jtx-pathtracer_amd/libjtx_mi_testhooks.so: the product's objects with jtx_capi.hip recompiled -DJTX_TEST_HOOKS (the fault injection
+    of test_device_rebuild_is_failure_atomic).  Test infrastructure: nothing in the product loads it; the tests name it through JTX_MI_LIB
+    in a child process."""
+    import hashlib
+    build_all(force=False)
+    cc = _hipcc()
+    cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("JTX_EXTRA_HIPCC_FLAGS", "").split()
+    objdir = os.path.join(_HERE, "build")
+    tag = hashlib.sha1(" ".join(cflags).encode()).hexdigest()[:10]
+    objs = [os.path.join(objdir, f"{os.path.splitext(src)[0]}.{tag}.o") for src in SOURCES]
+    hook = os.path.join(objdir, f"jtx_capi.testhooks.{tag}.o")
+    newest = max(os.path.getmtime(os.path.join(CSRC, d)) for d in HEADERS + ["jtx_capi.hip"] if os.path.exists(os.path.join(CSRC, d)))
+    if force or not os.path.exists(hook) or os.path.getmtime(hook) < newest:
+        src, cmd, rc, out = _compile_one((cc, "jtx_capi.hip", hook, cflags + ["-DJTX_TEST_HOOKS=1"]))
+        if rc != 0:
+            raise RuntimeError("hipcc failed on jtx_capi.hip (test hooks):\n" + out)
+    if force or not os.path.exists(TEST_LIB) or os.path.getmtime(TEST_LIB) < max(os.path.getmtime(hook), os.path.getmtime(LIB)):
+        objs = [hook if os.path.basename(o).startswith("jtx_capi.") else o for o in objs]
+        r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TEST_LIB] + objs, cwd=CSRC, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (link, test hooks) failed:\n" + r.stdout + r.stderr)
+    return TEST_LIB
+
+
 def build_all(force=False, verbose=False):
     """Compile every HIP source into jtx-pathtracer_amd/libjtx_mi.so.  Returns the library path.
     One object per source under jtx-pathtracer_amd/build/ (compiled in parallel, re-used while neither the source, a header nor

@@ -1429,7 +1429,9 @@ static int rebuildImpl(jtx_mi_scene *s, int32_t max_prims_in_node, bool commit) 
             if (newLights) sp.lights.fill(ls);
         }
         if (!commit) return 0;                                                 // jtx_mi_scene_reserve_rebuild: memory touched, kernels loaded, scene untouched
+#ifdef JTX_TEST_HOOKS    /* libjtx_mi_testhooks.so only (build.py: build_test_hooks); the product library has no fault injection */
         if (getenv("JTX_FAIL_REBUILD_BEFORE_COMMIT")) throw std::runtime_error("injected failure before the commit (JTX_FAIL_REBUILD_BEFORE_COMMIT)");   // tests: failure atomicity
+#endif
         // ---- commit: swaps and assignments only -- nothing below can throw ----
         s->prim_src.swap(sp.src); s->tris.swap(sp.tris); s->shade.swap(sp.shade); s->orig_id.swap(sp.orig);
         s->nbox.swap(sp.nbox); s->leaf_nodes.swap(sp.leaves); s->level_nodes.swap(sp.levels);
