@@ -25,9 +25,6 @@ namespace jtx {
 #ifndef JTX_RP_OCC
 #define JTX_RP_OCC 7
 #endif
-#ifndef JTX_NT_RAD
-#define JTX_NT_RAD 0
-#endif
 #ifndef JTX_WIDE_OCC
 #define JTX_WIDE_OCC 8          // waves per SIMD of the wide-traversal instances
 #endif
@@ -247,6 +244,14 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 // group, 64 x strata paths, handed out stratum-major -- runs dry takes the next chunk from a global counter at once,
 // while its other lanes are still finishing paths of the previous chunk: no wave ever drains except at the very end
 // of the launch (a wave of 4 paths per lane lost ~12 % to its own drain), and the scene is staged once per workgroup.
+// a finished path's clamped radiance (camera.cpp:110-112) into its record
+JD void writeRadiance(const RenderParams &p, f3 c, int s, int slot) {
+    if (c.x > 1.0f) c.x = 1.0f;
+    if (c.y > 1.0f) c.y = 1.0f;
+    if (c.z > 1.0f) c.z = 1.0f;
+    p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
 template <int SRC, int MASK, int BS>
 __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) JTX_SGPR_ATTR k_render_paths(RenderParams p) {
     static_assert((SRC != SRC_LDS && SRC != SRC_LEAF) || BS == BLOCK, "stageScene strides by BLOCK");
@@ -324,7 +329,8 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                 const int row = row0 + (pl >> 3), col = col0 + (pl & 7);
                 if (row < p.height && col < p.width) {
                     s = sBegin + (u >> 6); slot = slot0 + pl;
-                    startPath(p.cam, row, col, s, ps); alive = true; need = false;
+                    startPath(p.cam, row, col, s, ps);
+                    alive = true; need = false;
                 }
             }
         }
@@ -338,7 +344,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes; src.np = sc.num_prims;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
-                                  src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad;
+                                  src.lbox = lds_lbox; src.gbox = sc.lw_box; src.groot = sc.tnodes; src.fresh = ps.depth == 0; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS;
@@ -346,19 +352,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             if (done) {
-                f3 c = ps.radiance;                                    // camera.cpp:110-112
-                if (c.x > 1.0f) c.x = 1.0f;
-                if (c.y > 1.0f) c.y = 1.0f;
-                if (c.z > 1.0f) c.z = 1.0f;
-#if JTX_NT_RAD
-                {   // written once, read once by the resolve pass: streamed, so that 2 GB of records do not wash the BVH out of L2
-                    typedef float nt4 __attribute__((ext_vector_type(4)));
-                    nt4 v; v.x = c.x; v.y = c.y; v.z = c.z; v.w = 0.0f;
-                    __builtin_nontemporal_store(v, (nt4 *) (p.rad + (size_t) (s - p.sample_begin) * p.rad_stride + slot));
-                }
-#else
-                p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot] = make_float4(c.x, c.y, c.z, 0.0f);
-#endif
+                writeRadiance(p, ps.radiance, s, slot);
                 alive = false; need = true;
             }
         }
@@ -396,7 +390,9 @@ JD void withBatchSrc(const DevScene &sc, int *smem, F &&body) {
     if (LDS_SCENE) stageScene(sc, lds_tnodes, lds_tris);                // (every thread of the workgroup: before any lane leaves)
     if constexpr (SRC == SRC_LDS) { LdsSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes; src.np = sc.num_prims; body(src); }
     else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
-                          src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad; body(src); }
+                          src.lbox = lds_lbox; src.gbox = sc.lw_box; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad;
+                          src.groot = sc.tnodes; src.fresh = true;        // the per-ray entry points take the root test of the path kernel's camera rays too
+                          body(src); }
     else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                           src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS; body(src); }
     else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris; body(src); }

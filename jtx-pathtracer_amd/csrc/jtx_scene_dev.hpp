@@ -150,13 +150,21 @@ JD bool slabRegular(const float4 na, const float4 nb, f3 o, f3 inv, float tmin, 
     return t0 <= t1;
 }
 
-// ... with t.max = +inf (closestHit's open interval): min(x, +inf) == x for every non-NaN x, one instruction less per box
-JD bool slabRegularOpen(const float4 na, const float4 nb, f3 o, f3 inv, float tmin) {
-    const float ax = (na.x - o.x) * inv.x, bx = (na.y - o.x) * inv.x;
-    const float ay = (na.z - o.y) * inv.y, by = (na.w - o.y) * inv.y;
-    const float az = (nb.x - o.z) * inv.z, bz = (nb.y - o.z) * inv.z;
-    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+// Phase A of the flat leaf list, the near / far planes of an axis picked by the SIGN of 1/d instead of by min / max (v_min_f32 / v_max_f32
+// issue at 4.4 cycles, v_mul_f32 / v_fma_f32 at 2.4: profiles/r03_valu_rates.txt).  ip = 1/d where it is positive and 0 elsewhere, in = 1/d
+// where it is negative and 0 elsewhere; a = lo - o <= b = hi - o.  For 1/d > 0: fma(a, ip, b * in) = a / d + (+-0) = a / d = min(a / d, b / d)
+// (monotone rounding), fma(b, ip, a * in) = b / d = the max; for 1/d < 0 the roles swap.  Equal to slabRegular's operands bit for bit up to
+// the sign of a zero, which only ever reaches the comparison t0 <= t1.
+template <bool OPEN>
+JD bool slabRegularSel(const float4 na, const float4 nb, f3 o, f3 ip, f3 in, float tmin, float tmax) {
+    const float ax = na.x - o.x, bx = na.y - o.x;
+    const float ay = na.z - o.y, by = na.w - o.y;
+    const float az = nb.x - o.z, bz = nb.y - o.z;
+    const float nx = __builtin_fmaf(ax, ip.x, bx * in.x), fx = __builtin_fmaf(bx, ip.x, ax * in.x);
+    const float ny = __builtin_fmaf(ay, ip.y, by * in.y), fy = __builtin_fmaf(by, ip.y, ay * in.y);
+    const float nz = __builtin_fmaf(az, ip.z, bz * in.z), fz = __builtin_fmaf(bz, ip.z, az * in.z);
+    const float t0 = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+    const float t1 = OPEN ? fminf(fminf(fx, fy), fz) : fminf(fminf(fx, fy), fminf(fz, tmax));
     return t0 <= t1;
 }
 
@@ -522,6 +530,8 @@ struct LeafSrc {
     const unsigned *tab;                            // LDS copy of the order / position tables
     int nleaf;
     int np, lpad;                                   // triangles (plane stride); padded leaf count (stride between the halves of lbox)
+    const float4 *groot = nullptr;                  // the binary records in HBM (record 0 = the root's box), or null
+    bool fresh = false;                             // this lane's ray is a camera ray (path kernel: depth 0)
     JD float4 tnode(int i, int h) const { return tnodes[h * half + i]; }
 #if JTX_LDS_PLANES
     JD float4 tri(int i, int h) const { return tris[h * np + i]; }
@@ -553,16 +563,32 @@ JD bool traverseLeaves(const LeafSrc &src, f3 o, f3 d, f3 inv, int negmask, floa
     // closestHit's interval is open-ended (integrator.cpp:181: Interval(0.001, INF)): min(x, +inf) == x for the non-NaN x of a
     // regular ray, so the t.max operand is dropped -- the compiler cannot (fminf(NaN, inf) is inf)
     const bool openEnd = !ANY && tmax == __builtin_inff();
+    const f3 ip = mk3(inv.x > 0.0f ? inv.x : 0.0f, inv.y > 0.0f ? inv.y : 0.0f, inv.z > 0.0f ? inv.z : 0.0f);
+    const f3 in = mk3(inv.x > 0.0f ? 0.0f : inv.x, inv.y > 0.0f ? 0.0f : inv.y, inv.z > 0.0f ? 0.0f : inv.z);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int gg = 0; gg < 8; ++gg) {
+        const int g = ANY ? 7 - gg : gg;
         if (4 * g < n) {                                                         // wave-uniform
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = ANY ? 3 - jj : jj;
                 const int i = 4 * g + j;
                 const float4 na = make_float4(cb[8 * i], cb[8 * i + 1], cb[8 * i + 2], cb[8 * i + 3]);
                 const float4 nb = make_float4(cb[8 * i + 4], cb[8 * i + 5], 0.0f, 0.0f);
-                const bool pass = openEnd ? slabRegularOpen(na, nb, o, inv, tmin) : slabRegular(na, nb, o, inv, tmin, tmax);
-                const unsigned at = ANY ? (unsigned) i : (pos[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                const bool pass = openEnd ? slabRegularSel<true>(na, nb, o, ip, in, tmin, tmax) : slabRegularSel<false>(na, nb, o, ip, in, tmin, tmax);
+                if (ANY) {
+                    // anyHit's mask is in leaf order: the boxes are taken from the last to the first and every verdict is shifted in
+                    // from the right as the carry of pm + pm (one v_addc_co_u32 instead of v_cndmask + shift + or)
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const unsigned long long verdict = __ballot(pass);
+                    unsigned long long carryOut;
+                    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(pm), "=s"(carryOut) : "s"(verdict));
+#else
+                    pm = pm + pm + (pass ? 1u : 0u);
+#endif
+                    continue;
+                }
+                const unsigned at = (pos[i >> 2] >> (8 * (i & 3))) & 0xffu;
                 pm |= (pass ? 1u : 0u) << at;
             }
         }
@@ -578,7 +604,7 @@ JD bool traverseLeaves(const LeafSrc &src, f3 o, f3 d, f3 inv, int negmask, floa
                 const int leaf = ANY ? k : (int) ((row[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 const float4 la = src.leafbox(leaf, 0), lb = src.leafbox(leaf, 1);
                 bool pass = true;
-                if (!ANY && shrunk) pass = slabRegular(la, lb, o, inv, tmin, tmax);
+                if (!ANY && shrunk) pass = slabRegularSel<false>(la, lb, o, ip, in, tmin, tmax);
                 if (pass) { leafOff = __float_as_int(lb.z); leafN = __float_as_int(lb.w); }
             }
             const unsigned long long walking = __ballot(leafN == 0 && pm != 0u);
@@ -608,8 +634,24 @@ JD bool traverseNoStack(const LeafSrc &src, int num_nodes, f3 o, f3 d, float tmi
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-    if (__builtin_expect(__ballot(!regularRay(o, inv, tmin, tmax)) == 0ull, 1))
+    if (__builtin_expect(__ballot(!regularRay(o, inv, tmin, tmax)) == 0ull, 1)) {
+        // Scene::closestHit tests the ROOT's box first (scene.cpp:20-24) and a ray that fails it has no hit; the leaf list never looks
+        // at the root (leaf boxes nest in it and the slab test is monotone in the planes).  A wave that holds nothing but camera rays
+        // -- every wave of the frame's surround, 44 % of C2's paths -- asks, and skips phase A when all of them miss.  The root
+        // record is read with wave-uniform addresses: scalar loads, SGPR operands.
+        if (!ANY && src.groot && __ballot(!src.fresh) == 0ull) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef const __attribute__((address_space(4))) float *CBox;
+#else
+            typedef const float *CBox;
+#endif
+            const CBox cb = (CBox) (const void *) src.groot;
+            const float4 na = make_float4(cb[0], cb[1], cb[2], cb[3]);
+            const float4 nb = make_float4(cb[4], cb[5], 0.0f, 0.0f);
+            if (__ballot(slabRegular(na, nb, o, inv, tmin, tmax)) == 0ull) return false;
+        }
         return traverseLeaves<ANY>(src, o, d, inv, negmask, tmin, tmax, rec);
+    }
     return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
 }
 

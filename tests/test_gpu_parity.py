@@ -1886,6 +1886,43 @@ def test_per_ray_parity_on_equal_t_ties_and_lds_copies(gpu, cornell_pair):
         sc.closestHit(o[:4], d[:4], traversal=sc.TRAVERSAL_SOURCE + 2)           # Cornell has no 8-ary nodes
 
 
+def test_per_ray_parity_of_rays_that_miss_the_root_box(gpu, cornell_pair):
+    """The leaf list asks the ROOT's box of a wave that holds nothing but camera rays and returns at once when every ray misses it
+    (Scene::closestHit's first node test, scene.cpp:20-24); the per-ray entry point takes the same test.  Rays from the camera's side
+    of the Cornell box: whole waves (64 consecutive rays) that miss the box, waves that all hit, waves that mix both, rays that graze
+    the root's faces and edges -- hit / prim / t / b1 / b2 / point / normal / uv bitwise the oracle's, via the leaf list and the binary records."""
+    data, sc, osc = cornell_pair
+    lo, hi = np.asarray(sc.bounds()[0], np.float64), np.asarray(sc.bounds()[1], np.float64)
+    ctr, ext = (lo + hi) / 2, (hi - lo)
+    rs = np.random.RandomState(91)
+    n = 64 * 600
+    eye = ctr + np.array([0.0, 0.0, 2.5]) * ext.max()
+    o = np.tile(eye.astype(np.float32), (n, 1))
+    tgt = np.empty((n, 3))
+    blk = np.arange(n) // 64
+    kind = blk % 4                                    # per wave: 0 all miss (beside the box), 1 all hit, 2 mixed, 3 grazing the faces / edges
+    away = ctr + np.stack([(1.5 + rs.uniform(0, 2, n)) * ext[0] * np.where(rs.rand(n) < 0.5, -1, 1), rs.uniform(-2, 2, n) * ext[1], rs.uniform(-1, 1, n) * ext[2]], 1)
+    inside = lo + rs.uniform(0.05, 0.95, (n, 3)) * ext
+    mixed = ctr + rs.uniform(-1.2, 1.2, (n, 3)) * ext
+    graze = inside.copy()
+    ax = rs.randint(0, 2, n)
+    graze[np.arange(n), ax] = np.where(rs.rand(n) < 0.5, lo[ax], hi[ax]) + rs.uniform(-1e-4, 1e-4, n) * ext[ax]
+    graze[:, 2] = hi[2]
+    for k, t in enumerate((away, inside, mixed, graze)):
+        tgt[kind == k] = t[kind == k]
+    d = (tgt - o).astype(np.float32)
+    g = _check_closest(sc, osc, o, d, sc.TRAVERSAL_PRODUCTION, "leaf", "rays from outside the root box")
+    hit = g["hit"].reshape(-1, 64)
+    assert (hit[0::4].sum(1) == 0).all() and (hit[1::4].sum(1) == 64).all(), "waves of all-missing / all-hitting rays"
+    m = hit[2::4].sum(1)
+    assert ((m > 0) & (m < 64)).any()
+    _check_closest(sc, osc, o, d, sc.TRAVERSAL_BINARY, "binary", "rays from outside the root box")
+    # from scattered origins too (no common eye), and with un-normalised directions scaled per ray
+    o2 = (eye + rs.uniform(-1, 1, (n, 3)) * ext * 0.5).astype(np.float32)
+    d2 = ((tgt - o2) * rs.uniform(0.25, 4.0, (n, 1))).astype(np.float32)
+    _check_closest(sc, osc, o2, d2, sc.TRAVERSAL_PRODUCTION, "leaf", "scattered origins outside the root box")
+
+
 def test_soak_of_the_create_render_rebuild_destroy_path(gpu):
     """tools/soak.py for a minute (the full 300 iterations are recorded in profiles/r05_soak.txt): scenes created,
     rendered into page-locked film buffers, edited, rebuilt on the device, rendered again and destroyed, by turns and at changing sizes --
