@@ -145,7 +145,7 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup, int
                 out["in_flight"] = in_flight_block(roof, len(pipe.rstreams), elapsed / steps * 1e3, None)
             for k in ("useful_frac", "frac", "traffic", "vector_memory", "lane_util", "issue_model", "pmc_stale"):
                 if k in roof:
-                    out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"], "busy_calibrated": roof[k]["busy_calibrated"]}
+                    out[k] = roof[k] if k != "issue_model" else {"busy": roof[k]["busy"], "busy_calibrated": roof[k]["busy_calibrated"], "co_issue": roof[k]["co_issue"]}
             out["hbm_measured_frac"] = roof["hbm"].get("measured_frac")
             out["useful_lane_ops_per_launch"] = roof["useful"]["lane_ops_per_launch"]; out["num_cus"] = roof["num_cus"]
             out["kernel"] = roof["kernel"]
@@ -331,7 +331,9 @@ def issue_calibration(lds_resident):
         m = re.match(r"(\w+): (\d+) VALU instructions.*measured / model = ([0-9.]+)", line)
         if m:
             ratio[m.group(1)] = (float(m.group(3)), int(m.group(2)))
-    want = ["c2_phase_a_closest"] if lds_resident else ["c3_node_closest", "c3_node_any"]
+    # (leaf list: ONE box of phase A as the compiler emits it, repeated -- tools/micro/rate10; the replay of the whole 716-instruction stream
+    #  is in the file too and runs 1.6 x slower per instruction than any part of it, for a reason that was not found)
+    want = (["c2_phase_a_box"] if "c2_phase_a_box" in ratio else ["c2_phase_a_closest"]) if lds_resident else ["c3_node_closest", "c3_node_any"]
     have = [ratio[k][0] for k in want if k in ratio]
     if not have:
         return None
@@ -496,9 +498,15 @@ def roofline_block(workload, scene_info, mine, kernel_name, kernel_ms, launches_
                                   "busy_upper_bound": round(need / (SIMDS * t * CLK), 3),
                                   "calibration": cal,
                                   "busy_calibrated": round(need * cal["measured_over_priced"] / (SIMDS * t * CLK), 3) if cal else None,
-                                  "note": "VALU cycles the launch's instruction mix is priced at by class (an upper bound) x the ratio measured / priced of "
-                                          "the kernel's own loop body replayed at saturation (profiles/r04_issue_replay.txt), over the cycles the SIMDs have "
-                                          "in the kernel's duration (nominal 2.4 GHz); ~1.0: issue-saturated"}
+                                  # round 5 (profiles/r05_box_rates.txt): the two classes are two PIPES that run side by side -- a leaf-box test of 24
+                                  # instructions takes 51 cycles where its classes add up to 75 -- so a mix is bound by the larger of (every instruction x
+                                  # the 2.13 cycles one issue takes) and (the half-rate instructions x 4.4 + transcendental x 8.4), not by their sum
+                                  "co_issue": {"issue_slots_busy": round(insts * 2.13 / (SIMDS * t * CLK), 3),
+                                               "half_rate_pipe_busy": round((slow * 4.4 + trans * 8.4) / (SIMDS * t * CLK), 3),
+                                               "cycles_per_issue": 2.13, "evidence": "profiles/r05_box_rates.txt"},
+                                  "note": "VALU cycles the launch's instruction mix is priced at by class (an upper bound: the classes overlap, see co_issue) x "
+                                          "the ratio measured / priced of the kernel's own loop body replayed at saturation (calibration.source), over the cycles "
+                                          "the SIMDs have in the kernel's duration (nominal 2.4 GHz)"}
         if c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
             # the second ceiling of the HBM-resident kernels: the vector-memory pipeline (one address unit and one data-return unit per CU)
             unit_cycles = num_cus * c["GRBM_GUI_ACTIVE"] / 8.0

@@ -314,9 +314,9 @@ struct WideState {
 
 // The 8 child boxes of a wide node against a ray (never misses a box AABB::hit would pass), with the answer in POSITION space of the
 // ray's order list: ohLo / ohHi hold, per slot byte, the one-hot
-// position of the slot in the ray's visiting order (0: no child).  Per child t1 - t0 instead of a compare (a miss is a NEGATIVE
-// difference: t0, t1 are finite for the rays the wide nodes take, t1 is never -0 -- every far value is b + mu with mu > 0 -- and
-// t0 == t1 gives +0), v_perm_b32's sign selectors turn four sign bits into four bytes 0xff / 0x00, (not miss) AND one-hot, summed
+// position of the slot in the ray's visiting order (0: no child).  Per child a DIFFERENCE instead of a compare (a miss is a NEGATIVE
+// difference: near and far are finite for the rays the wide nodes take, far is never -0 -- every far value is b + mu with mu > 0 -- and
+// equal operands give +0; since round 5 the smallest of far - near, t.max - near and far - t.min, see below), v_perm_b32's sign selectors turn four sign bits into four bytes 0xff / 0x00, (not miss) AND one-hot, summed
 // over the bytes (distinct bits: a sum is an OR), is the pending mask: 8 v_sub + 4 v_perm + 3 v_bitop3 + 1 v_sad_u8 (48 cycles by
 // tools/micro/rate7.hip) where compare / select / or and the 8-bit permutation took 45 instructions of the 4.4-cycle class (198).
 JD unsigned wideNodePend(const uint4 n0, const uint4 n2, const uint4 n3, const uint4 n4, unsigned ohLo, unsigned ohHi, f3 o, f3 inv, float tmin, float tmax) {
@@ -336,11 +336,12 @@ JD unsigned wideNodePend(const uint4 n0, const uint4 n2, const uint4 n3, const u
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int w = s >> 2, b = s & 3;
-        const float t0 = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)),
-                               fmaxf(__fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz), tmin));
-        const float t1 = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)),
-                               fminf(__fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz), tmax));
-        df[s] = t1 - t0;
+        // the interval's ends as DIFFERENCES (v_sub_f32 issues beside the v_min / v_max class, profiles/r05_box_rates.txt): the child is missed
+        // iff far < near or t.max < near or far < t.min -- min(far, t.max) < max(near, t.min) without its "t.max < t.min" term (an empty
+        // interval then only costs visits)
+        const float tn = fmaxf(fmaxf(__fmaf_rn(ubyteToFloat(nxq[w], b), axx, bnx), __fmaf_rn(ubyteToFloat(nyq[w], b), ayy, bny)), __fmaf_rn(ubyteToFloat(nzq[w], b), azz, bnz));
+        const float tf = fminf(fminf(__fmaf_rn(ubyteToFloat(fxq[w], b), axx, bfx), __fmaf_rn(ubyteToFloat(fyq[w], b), ayy, bfy)), __fmaf_rn(ubyteToFloat(fzq[w], b), azz, bfz));
+        df[s] = fminf(fminf(tf - tn, tmax - tn), tf - tmin);
 #if defined(__HIP_DEVICE_COMPILE__)
         // v_perm_b32 D, S0, S1, sel: selector 0x0b = 8 x S0[31], 0x09 = 8 x S1[31], 0x0c = 0x00 (checked on the chip: rate7.hip)
         if (s & 1) {

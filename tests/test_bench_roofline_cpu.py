@@ -27,7 +27,7 @@ def _replay():
     return out
 
 
-def _check(workload, kernel_ms, cus, lane_ops, useful_frac, frac, busy, busy_cal, traffic):
+def _check(workload, kernel_ms, cus, lane_ops, useful_frac, frac, busy, busy_cal, traffic, co=None):
     t = kernel_ms * 1e-3
     # useful_frac: lane-ops / time / (CUs x 128 lanes x 2.4 GHz)
     assert abs(lane_ops / t / (cus * 128 * 2.4e9) - useful_frac) < 2e-4
@@ -39,9 +39,18 @@ def _check(workload, kernel_ms, cus, lane_ops, useful_frac, frac, busy, busy_cal
     priced = fast * 2.4 + (pmc["SQ_INSTS_VALU"] - fast - trans) * 4.4 + trans * 8.4
     assert abs(priced / (cus * 4 * t * 2.4e9) - busy) < 2e-3                   # `busy`: the class-priced upper bound (round 3's meaning)
     rp = _replay()
-    cal = rp["c2_phase_a_closest"] if workload.startswith("cornell") else 0.5 * (rp["c3_node_closest"] + rp["c3_node_any"])
+    # the leaf list is calibrated on ONE box of its phase A as compiled (tools/micro/rate10; the replay of the whole stream is pessimistic,
+    # profiles/r05_issue_replay.txt), the 8-ary traversal on its two node steps
+    cal = rp["c2_phase_a_box"] if workload.startswith("cornell") else 0.5 * (rp["c3_node_closest"] + rp["c3_node_any"])
     assert abs(priced * cal / (cus * 4 * t * 2.4e9) - busy_cal) < 3e-3
-    assert 0.95 <= busy_cal <= 1.06 < busy                                     # calibrated, it reads ~1.0 at saturation
+    assert 0.65 <= busy_cal <= 1.06 < busy                                     # the class prices ADD what the two pipes do side by side
+    if co is not None:
+        # round 5's two-pipe view (profiles/r05_box_rates.txt): every instruction takes an issue slot of 2.13 cycles, the half-rate and
+        # transcendental ones their own pipe besides; the larger share binds, and neither exceeds what the SIMDs have
+        assert abs(pmc["SQ_INSTS_VALU"] * 2.13 / (cus * 4 * t * 2.4e9) - co["issue_slots_busy"]) < 2e-3
+        assert abs(((pmc["SQ_INSTS_VALU"] - fast - trans) * 4.4 + trans * 8.4) / (cus * 4 * t * 2.4e9) - co["half_rate_pipe_busy"]) < 2e-3
+        assert 0.6 < max(co["issue_slots_busy"], co["half_rate_pipe_busy"]) < 0.95
+        assert (co["issue_slots_busy"] > co["half_rate_pipe_busy"]) == workload.startswith("cornell")     # leaf list: issue; 8-ary nodes: the half-rate pipe
     assert abs((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 - traffic) < 1e6
 
 
@@ -68,7 +77,7 @@ def test_recorded_bench_line_is_reproducible_from_profiles():
     line = _line("r05_bench.json")
     r = line["roofline"]
     _check(line["config"]["workload"], r["kernel_ms"], r["num_cus"], r["useful"]["lane_ops_per_launch"], r["useful_frac"], r["frac"],
-           r["issue_model"]["busy"], r["issue_model"]["busy_calibrated"], r["traffic"])
+           r["issue_model"]["busy"], r["issue_model"]["busy_calibrated"], r["traffic"], r["issue_model"]["co_issue"])
     assert 0.15 < r["useful_frac"] < 0.3 and not r["pmc_stale"] and r["issue_model"]["calibration"]["stale"] is False
     assert abs(line["value"] - line["config"]["rays_per_frame"] / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
     # the numerator re-derives from the line's own tables: events x operations, the BxDF's share by class
@@ -103,7 +112,7 @@ def test_the_other_workloads_ride_in_the_same_line_and_re_derive():
     for name in ("atrium_1920x1080_64spp_d8", "mixed_1920x1080_128spp_d8"):
         e = w[name]
         _check(name, e["kernel_ms"], e["num_cus"], e["useful_lane_ops_per_launch"], e["useful_frac"], e["frac"], e["issue_model"]["busy"],
-               e["issue_model"]["busy_calibrated"], e["traffic"])
+               e["issue_model"]["busy_calibrated"], e["traffic"], e["issue_model"]["co_issue"])
         assert abs(e["value"] - e["rays_per_frame"] / (e["ms_per_step"] * 1e-3) / 1e6) / e["value"] < 1e-3
         assert e["vector_memory"]["ta_busy"] > 0.75                         # the second ceiling of the HBM-resident kernels
         assert e["frames_in_flight"] == 3 and e["ms_per_step"] < e["kernel_ms"] * 1.01
