@@ -1653,13 +1653,13 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         const int npasses = (se - sb + tick - 1) / tick;
         const int K = (count || npasses < 2) ? 1 : (maxInFlight < npasses ? maxInFlight : npasses);
         const bool two = K > 1;
-        // ... and a SMALL pass takes only part of the wave slots: so many waves that a lane gets ~JTX_PASS_PATHS_PER_LANE paths (16).  A wave
+        // ... and a SMALL pass takes only part of the wave slots: so many waves that a lane gets ~JTX_PASS_PATHS_PER_LANE paths (20).  A wave
         // ends with its lanes waiting for the longest of its last paths (up to maxDepth + 1 traversals); with one stratum per pass and the
         // whole chip, a lane has 4.5 paths and that wait is 40 % of the launch.  The passes in flight fill the rest of the chip, and the
         // resolve of a finished pass finds free slots at once instead of starving behind persistent waves (profiles/r05_progressive.md).
         // JTX_PASS_GRID_SHARE=n: 1 / n of the slots, whatever the size.
         static const int shareEnv = [] { const char *e = getenv("JTX_PASS_GRID_SHARE"); return e ? atoi(e) : 0; }();
-        static const int perLane = [] { const char *e = getenv("JTX_PASS_PATHS_PER_LANE"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
+        static const int perLane = [] { const char *e = getenv("JTX_PASS_PATHS_PER_LANE"); const int v = e ? atoi(e) : 20; return v < 1 ? 1 : v; }();
         int gridShare = 1;
         if (two) {
             int bs = 0; const long cap = (long) jtx_render_paths_grid(s->dev, s->num_cus, &bs) * (bs / 64);
