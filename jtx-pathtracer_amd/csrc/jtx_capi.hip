@@ -490,11 +490,19 @@ bool buildWide(const std::vector<jtx_mi_bvh_node> &nodes, std::vector<uint4> &ou
 // Tiny scenes: the flat leaf list of traverseLeaves (leaves in b.nodes order; per octant: leaf at position p, position of
 // leaf l -- read off the threaded orderings).  pos[k * nn + g]: node g's place in octant k's order.
 // -> number of leaves in the list (0: none -- more than 32 leaves, or a single node); box / tab filled (grow-only) when > 0
+static bool leafPlanesInRange(const std::vector<jtx_mi_bvh_node> &nodes) {
+    for (const jtx_mi_bvh_node &n : nodes) if (n.num_prims)
+        for (int a = 0; a < 3; ++a) if (!(std::fabs(n.pmin[a]) <= jtx::LEAF_RANGE && std::fabs(n.pmax[a]) <= jtx::LEAF_RANGE)) return false;
+    return true;
+}
 int buildLeafTables(const std::vector<jtx_mi_bvh_node> &nodes, const std::vector<int> &pos, DevBuf<float4> &box, DevBuf<unsigned> &tabBuf) {
     const size_t nn = nodes.size();
     std::vector<int> leafId(nn, -1); int nl = 0;
     for (size_t i = 0; i < nn; ++i) if (nodes[i].num_prims) leafId[i] = nl++;
     if (!(nl > 0 && nl <= 32 && nn > 1)) return 0;
+    // the list's planes within +-2^60 (jtx::LEAF_RANGE): with a ray origin bounded the same way plane - o stays finite, which the
+    // fma form of the leaf-box test relies on (jtx_scene_dev.hpp: slabRegularSel); scenes beyond that walk the binary records
+    if (!leafPlanesInRange(nodes)) return 0;
     const int npad = (nl + 3) & ~3;                                     // phase A of traverseLeaves runs in groups of four
     std::vector<float4> lb(2 * (size_t) npad, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t i = 0; i < nn; ++i) if (leafId[i] >= 0) {
@@ -1269,6 +1277,7 @@ int jtx_mi_scene_refit(jtx_mi_scene *s) {
                 if (any) stagedH2D(s->lights.p, ls.data(), ls.size() * sizeof(DLight));
             }
         }
+        if (s->dev.lw_leaves && !leafPlanesInRange(s->bvh.nodes)) { s->dev.lw_leaves = 0; s->dev.lw_box = nullptr; s->dev.lw_tab = nullptr; }   // refitted out of the list's range
         if (s->dev.lw_leaves) {                                                 // tiny scenes: the flat leaf list follows the refitted nodes
             std::vector<float4> lb(s->lw_box.n, make_float4(0.f, 0.f, 0.f, 0.f)); int l = 0;
             for (const jtx_mi_bvh_node &n : s->bvh.nodes) if (n.num_prims) {

@@ -629,13 +629,21 @@ JD bool traverseLeaves(const LeafSrc &src, f3 o, f3 d, f3 inv, int negmask, floa
     return hitAnything;
 }
 
+// rays the leaf list may take: regular, with |o| <= 2^60 -- the list's planes are bounded the same way (buildLeafTables, jtx_capi.hip), so
+// lo - o and hi - o are finite and the vanishing term of slabRegularSel's fma IS a zero (inf * 0 would be a NaN where AABB::hit has +-inf)
+constexpr float LEAF_RANGE = 1152921504606846976.0f;   // 2^60
+JD bool leafRayOk(f3 o, f3 inv, float tmin, float tmax) {
+    return finiteNonZero(inv.x) && finiteNonZero(inv.y) && finiteNonZero(inv.z) &&
+           fabsf(o.x) <= LEAF_RANGE && fabsf(o.y) <= LEAF_RANGE && fabsf(o.z) <= LEAF_RANGE && tmin == tmin && tmax == tmax;
+}
+
 template <bool ANY, bool COUNT>
 JD bool traverseNoStack(const LeafSrc &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     static_assert(!COUNT, "the counted kernels reproduce the reference's node visits: binary records only");
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
-    if (__builtin_expect(__ballot(!regularRay(o, inv, tmin, tmax)) == 0ull, 1)) {
+    if (__builtin_expect(__ballot(!leafRayOk(o, inv, tmin, tmax)) == 0ull, 1)) {
         // Scene::closestHit tests the ROOT's box first (scene.cpp:20-24) and a ray that fails it has no hit; the leaf list never looks
         // at the root (leaf boxes nest in it and the slab test is monotone in the planes).  A wave that holds nothing but camera rays
         // -- every wave of the frame's surround, 44 % of C2's paths -- asks, and skips phase A when all of them miss.  The root

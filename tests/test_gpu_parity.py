@@ -1921,6 +1921,20 @@ def test_per_ray_parity_of_rays_that_miss_the_root_box(gpu, cornell_pair):
     o2 = (eye + rs.uniform(-1, 1, (n, 3)) * ext * 0.5).astype(np.float32)
     d2 = ((tgt - o2) * rs.uniform(0.25, 4.0, (n, 1))).astype(np.float32)
     _check_closest(sc, osc, o2, d2, sc.TRAVERSAL_PRODUCTION, "leaf", "scattered origins outside the root box")
+    # origins beyond the leaf list's range (|o| > 2^60: plane - o must stay finite for the fma form of its box test): those waves walk the
+    # binary records -- same answers; and a list is not built at all for a scene whose planes lie out there
+    o3 = o2.copy(); o3[::3] *= np.float32(3e25)
+    d3 = (tgt - o3.astype(np.float64)).astype(np.float32)
+    _check_closest(sc, osc, o3, d3, sc.TRAVERSAL_PRODUCTION, "leaf", "origins beyond 2^60")
+    _check_any(sc, osc, o3, d3, np.full(n, 0.999, np.float32), sc.TRAVERSAL_PRODUCTION, "leaf", "origins beyond 2^60, anyHit")
+    far = gpu.scenes.cornell()
+    m = np.eye(4, dtype=np.float32); m[0, 3] = 4e18
+    for mesh in far.meshes:
+        mesh["transform"] = np.ascontiguousarray(m @ np.asarray(mesh["transform"], np.float32), np.float32)
+    fsc = gpu.Scene(far); fsc.buildBVH()
+    assert fsc.info()["lds_resident"] and fsc.closestHit(o[:64], d[:64], traversal=fsc.TRAVERSAL_PRODUCTION) is not None
+    assert fsc.SOURCE_NAMES[fsc.last_source] == "lds", "a scene beyond the leaf list's range walks the LDS copy of the binary records"
+    fsc.destroy()
 
 
 def test_soak_of_the_create_render_rebuild_destroy_path(gpu):
