@@ -315,6 +315,9 @@ def source_hash():
     for f in ("jtx_kernels.hip", "jtx_scene_dev.hpp", "jtx_wide_quant.hpp", "jtx_bxdf.hpp", "jtx_device_math.hpp", "jtx_launch.hpp", "jtx_tiles.hpp",
               "jtx_profile.hpp"):
         h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    # ... and the flags they are compiled with (round 5: -fno-slp-vectorize changed every kernel's code without touching a source line)
+    bp = open(os.path.join(ROOT, "jtx-pathtracer_amd", "build.py")).read()
+    h.update(bp[bp.index("FLAGS = ["):bp.index("]", bp.index("FLAGS = [")) + 1].encode())
     return h.hexdigest()[:16]
 
 

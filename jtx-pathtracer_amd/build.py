@@ -10,7 +10,11 @@ SOURCES = ["jtx_kernels.hip", "jtx_alt.hip", "jtx_wavefront.hip", "jtx_capi.hip"
 HEADERS = ["jtx_device_math.hpp", "jtx_bxdf.hpp", "jtx_scene_dev.hpp", "jtx_launch.hpp", "jtx_host.hpp", "jtx_tiles.hpp", "jtx_wide_quant.hpp", "jtx_inflate.hpp", "jtx_profile.hpp", "jtx_profile_readers.hpp",
            os.path.join("..", "..", "include", "jtx_mi.h")]
 # -ffp-contract=off: device results must equal the strict-fp32 CPU oracle bit for bit.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+# -fno-slp-vectorize: the SLP vectoriser turns pairs of fp32 operations into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32.  On gfx950 a packed
+# fp32 instruction takes the two issue slots of the operations it replaces, lets nothing run beside it on the half-rate pipe, and wants its
+# operands in aligned register pairs (profiles/r05_box_rates.txt): without it the path kernels spill 12 / 50 / 53 VGPRs instead of 45 / 86 /
+# 160 and run 11 % (C2), 5 % (C3), 8 % (C5) faster.  The arithmetic is the same operation for operation (packed or not, each lane is IEEE fp32).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 
 

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../jtx-pathtracer_amd/csrc" || exit 1
 tag=$1; flags=$2; vsrc=${3:-jtx_kernels.hip}
 OBJ=/tmp/jtxobj; mkdir -p $OBJ
-CF="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function"
+CF="--offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -Wall -Wno-unused-function"
 SRCS=$(python3 -c "import re;print(' '.join(re.findall(r'\"(jtx_[a-z_]+\.(?:hip|cpp))\"', open('../build.py').read().split('SOURCES')[1].split(']')[0])))")
 for f in $SRCS; do
   o=$OBJ/${f%.*}.o
