@@ -153,3 +153,25 @@ def test_a_scene_file_becomes_a_workload(tmp_path):
     assert c["yfov"] == 60.0 and 0 < c["center"][1] < 548.9                     # inside the bounds, looking down the longest axis
     name2, data2, _ = bench.load_workload(jtx, "cornell_1920x1080_64spp_d8")
     assert name2 == "cornell_1920x1080_64spp_d8" and data2.num_triangles == 32
+
+
+def test_build_flags_are_part_of_the_profile_stamp(tmp_path, monkeypatch):
+    """round 5: -fno-slp-vectorize changed every kernel's code without touching a source line, so the stamp that ties profiles/ counters
+    to a build covers the compile flags too; the flag itself stays (packed fp32 is a measured loss on gfx950: profiles/r05_box_rates.txt)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("jtx_build", os.path.join(ROOT, "jtx-pathtracer_amd", "build.py"))
+    build = importlib.util.module_from_spec(spec); spec.loader.exec_module(build)
+    assert "-fno-slp-vectorize" in build.FLAGS and "-ffp-contract=off" in build.FLAGS and "--offload-arch=gfx950" in build.FLAGS
+    assert not any(f.startswith("-ffast-math") or f == "-Ofast" for f in build.FLAGS)
+    h0 = bench.source_hash()
+    assert h0 == json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))["source_hash"]        # the committed counters are this build's
+    real_open = open
+    def fake_open(path, *a, **k):
+        f = real_open(path, *a, **k)
+        if str(path).endswith(os.path.join("jtx-pathtracer_amd", "build.py")) and not a and not k:
+            text = f.read().replace('"-fno-slp-vectorize", ', ""); f.close()
+            import io
+            return io.StringIO(text)
+        return f
+    monkeypatch.setattr("builtins.open", fake_open)
+    assert bench.source_hash() != h0
