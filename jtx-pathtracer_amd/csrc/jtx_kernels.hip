@@ -19,6 +19,20 @@
 
 namespace jtx {
 
+// node steps per scheduling vote of the 8-ary walk in the path kernel: Lambert-only instance closest / any, all-BxDF instance closest / any
+// (final build of round 5, ms per frame: C3 with 1,1 / 2,1 / 1,2 / 2,2 / 3,3 = 283.4 / 276.9 / 278.4 / 275.1 / 282.7; C5 with 1,1 / 2,1 / 1,2 = 263.1 / 266.5 / 265.1)
+#ifndef JTX_WIDE_STEPS_LC
+#define JTX_WIDE_STEPS_LC 2
+#endif
+#ifndef JTX_WIDE_STEPS_LA
+#define JTX_WIDE_STEPS_LA 2
+#endif
+#ifndef JTX_WIDE_STEPS_MC
+#define JTX_WIDE_STEPS_MC 1
+#endif
+#ifndef JTX_WIDE_STEPS_MA
+#define JTX_WIDE_STEPS_MA 1
+#endif
 #ifndef JTX_RP_BLOCK
 #define JTX_RP_BLOCK 256
 #endif
@@ -346,7 +360,8 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             else if constexpr (SRC == SRC_LEAF) { LeafSrc src; src.tnodes = lds_tnodes; src.tris = lds_tris; src.half = 8 * sc.num_nodes;
                                   src.lbox = lds_lbox; src.gbox = sc.lw_box; src.groot = sc.tnodes; src.fresh = ps.depth == 0; src.tab = lds_tab; src.nleaf = sc.lw_leaves; src.np = sc.num_prims; src.lpad = lwPad;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
-            else if constexpr (SRC == SRC_WIDE) { WideSrc src; src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
+            else if constexpr (SRC == SRC_WIDE) { WideSrcT<(MASK == MAT_DIFFUSE_ONLY ? JTX_WIDE_STEPS_LC : JTX_WIDE_STEPS_MC), (MASK == MAT_DIFFUSE_ONLY ? JTX_WIDE_STEPS_LA : JTX_WIDE_STEPS_MA)> src;
+                                  src.wide = sc.wide; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   src.stk = (uint2 *) smem + threadIdx.x; src.stride = BS;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;

@@ -425,7 +425,7 @@ JD void wideRaySetup(WideRay &r, f3 o, f3 d, f3 inv, int negmask, float tmin, fl
     r.o = o; r.d = d; r.inv = inv; r.tmin = tmin; r.tmax = tmax; r.negmask = negmask;
 }
 
-template <bool ANY, class Src>
+template <bool ANY, int STEPS, class Src>
 JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk, int stride, f3 o, f3 d, f3 inv,
                      int negmask, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     WideRay r; wideRaySetup(r, o, d, inv, negmask, tmin, tmax);
@@ -435,7 +435,7 @@ JD bool traverseWide(const uint4 *__restrict__ wide, const Src &src, uint2 *stk,
     while (true) {
         while (true) {
 #pragma unroll
-            for (int rep = 0; rep < JTX_WIDE_STEPS; ++rep) {
+            for (int rep = 0; rep < STEPS; ++rep) {
                 WSTAT(cnt.w_node_iters++;
                       { const int na = __popcll(__ballot(ws.walking()));
                         cnt.w_hist[na <= 2 ? 0 : na <= 4 ? 1 : na <= 8 ? 2 : na <= 16 ? 3 : na <= 32 ? 4 : na <= 48 ? 5 : 6]++; })
@@ -474,7 +474,11 @@ JD bool wideRayOk(f3 o, f3 inv, float tmin, float tmax) {
 }
 
 // HBM-resident scene, uncounted kernels: wide traversal; a wave with an irregular ray walks the binary records
-struct WideSrc {
+// SC / SA: node steps between two scheduling votes of a closestHit / anyHit walk (the votes are pure overhead, a second step before the
+// vote lets a finished lane idle one step longer: the Lambert kernel gains with 2, the all-BxDF kernel -- more registers live -- loses)
+template <int SC, int SA>
+struct WideSrcT {
+    static constexpr int stepsClosest = SC, stepsAny = SA;
     const uint4 *wide;
     const float4 *tnodes, *tris;
     uint2 *stk;               // this lane's LDS stack column
@@ -482,15 +486,16 @@ struct WideSrc {
     JD float4 tnode(int i, int h) const { return tnodes[2 * i + h]; }
     JD float4 tri(int i, int h) const { return tris[3 * i + h]; }
 };
+typedef WideSrcT<JTX_WIDE_STEPS, JTX_WIDE_STEPS> WideSrc;
 
-template <bool ANY, bool COUNT>
-JD bool traverseNoStack(const WideSrc &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
+template <bool ANY, bool COUNT, int SC, int SA>
+JD bool traverseNoStack(const WideSrcT<SC, SA> &src, int num_nodes, f3 o, f3 d, float tmin, float tmax, HitRec &rec, Counters9 &cnt) {
     static_assert(!COUNT, "the counted kernels reproduce the reference's node visits: binary records only");
     if (num_nodes == 0) return false;
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int negmask = (inv.x < 0.0f ? 1 : 0) | (inv.y < 0.0f ? 2 : 0) | (inv.z < 0.0f ? 4 : 0);
     if (__builtin_expect(__ballot(!wideRayOk(o, inv, tmin, tmax)) == 0ull, 1))
-        return traverseWide<ANY>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
+        return traverseWide<ANY, (ANY ? SA : SC)>(src.wide, src, src.stk, src.stride, o, d, inv, negmask, tmin, tmax, rec, cnt);
     return traverseThreaded<ANY, false, false>(src, num_nodes, o, d, inv, negmask, tmin, tmax, rec, cnt);
 }
 
