@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define JTX_MI_VERSION 5
+#define JTX_MI_VERSION 6
 #define JTX_MI_FRAME_SLOTS 3
 #define JTX_MI_CANCELLED 2   /* jtx_mi_render: stopped by the callback / jtx_mi_cancel; the film holds the completed passes */
 
@@ -123,13 +123,17 @@ typedef struct {
                                * records of the persistent path kernel) this render uses.  Renders of one scene in DIFFERENT slots may be
                                * in flight at the same time on different streams -- the workers of StaticCamera::render never wait for a
                                * frame boundary either (camera.cpp:53-64, 81-123): here the last chunks of frame i overlap the first chunks
-                               * of frame i + 1, and the resolve pass of frame i those of frame i + 2.  Renders in the SAME slot are ordered
+                               * of frame i + 1.  Renders in the SAME slot are ordered
                                * by the library (an event per slot), whatever streams they come on; launches that need the scene's
                                * singletons (count_rays, integrator 2, path_integrator != 0) are ordered against all slots.  jtx_mi_render
                                * uses slot 0. */
     int32_t sequence_end;     /* != 0: nothing follows this frame that could fill the end of its launch (the last frame of a sequence): the
                                * launch is cut into many small chunks like a lone one, although other frames of the scene are in flight
                                * (with a successor in flight the library prefers few large chunks: fewer fetches, the tail does not matter) */
+    int32_t max_record_mb;    /* cap, in MiB, on a frame slot's buffer of per-path radiance records (16 B per path of one launch of the
+                               * persistent path kernel: C2's 64-spp frame 2.1 GB); <= 0: 8192 (env JTX_MAX_RAD_MB: the same for callers
+                               * that pass no opts).  A range of strata that would need more goes in several launches of consecutive
+                               * strata, the film continuing in order */
 } jtx_mi_render_opts;
 
 /* ray / traffic counters */
@@ -161,6 +165,10 @@ typedef struct {
     uint64_t wide_bytes64;    /* wide_bytes without the 2 GiB clamp of the 32-bit field; 0 when the kernels have no 8-ary nodes to walk */
     uint64_t rebuild_spare_bytes;  /* device memory held by the edit loop's second set of structures + the builder's scratch (NOT part of
                                     * device_bytes): 0 before the first jtx_mi_scene_rebuild / reserve_rebuild and after release_rebuild */
+    uint64_t frame_slot_bytes;     /* device memory held by the frame slots' working memory -- the per-path radiance records of the persistent
+                                    * path kernel and its chunk counters, allocated by the first render that uses a slot and sized by the
+                                    * largest launch since (NOT part of device_bytes; the reference's only per-frame state is acc_ / img_,
+                                    * image.hpp:64-92): 0 after jtx_mi_scene_release_frames */
 } jtx_mi_scene_info;
 
 typedef struct jtx_mi_scene jtx_mi_scene;
@@ -237,6 +245,9 @@ int  jtx_mi_scene_reserve_rebuild(jtx_mi_scene *scene);
  * how much; about the geometry's own size again).  For a host that has finished editing, or holds many scenes on one device.  The next
  * rebuild allocates them again (and pays the first rebuild's price once more). */
 int  jtx_mi_scene_release_rebuild(jtx_mi_scene *scene);
+/* Frees the frame slots' working memory (scene_info.frame_slot_bytes; e.g. a host that drops from three frames in flight to one, or
+ * holds many scenes on one device).  Waits for the device to go idle first.  The next render allocates what it needs again. */
+int  jtx_mi_scene_release_frames(jtx_mi_scene *scene);
 int  jtx_mi_scene_get_info(const jtx_mi_scene *scene, jtx_mi_scene_info *out);
 int  jtx_mi_scene_get_bvh(const jtx_mi_scene *scene, jtx_mi_bvh_node *nodes_out, jtx_mi_tri_ref *refs_out);
 /* The scene's 8-ary node set as it stands on the device -- after jtx_mi_scene_create, a device rebuild or a refit -- in the layout of
@@ -246,14 +257,19 @@ int  jtx_mi_scene_get_wide(jtx_mi_scene *scene, uint32_t *granules_out, int64_t 
 
 /* StaticCamera::render(const Scene&) (camera.cpp:45-128), blocking.  acc_rgb: W*H*3 float sums
  * (AccumulationBuffer), img_rgb: W*H*3 u8 (RGB8Image); both HOST buffers owned by the caller.
- * With a callback, one pass = opts.samples_per_tick strata (samplesPerPass_, camera.hpp:181): after every pass img_rgb
- * holds the preview of the samples so far (what the UI uploads, display.cpp:702-703) and cb(current_sample, total, user)
- * runs while the next pass is already rendering; acc_rgb is written once, before the call returns.
+ * With a callback, one pass = opts.samples_per_tick strata (samplesPerPass_, camera.hpp:181).  All passes of a frame go in ONE launch
+ * of the persistent path kernel (integrateMIS; counting launches, the alternate Li and integrator 2 go pass by pass), a second kernel
+ * beside it adding every finished pass to the film and the preview, in order.  cb(current_sample, total, user) runs once per pass, in
+ * order, when that pass is in the film of EVERY pixel, while the launch goes on rendering; img_rgb then holds the preview as it
+ * stood at that moment (what the UI uploads, display.cpp:702-703): every pixel shows at least current_sample strata, some already a
+ * pass more -- the reference's UI reads img_ unsynchronised beside the tile workers as well.  The launch does not wait for the
+ * callback: a slow one is told of several passes in a row.  acc_rgb is written once, before the call returns.
  * Cancellation (Camera::terminateRender, camera.hpp:77; the reference polls stopRender_ per pixel, camera.cpp:84-98):
- * a non-zero return of the callback, or jtx_mi_cancel() from ANY thread at ANY time -- the persistent kernels poll the
- * flag whenever a wave fetches its next chunk of 64 x strata paths, so a running pass stops within microseconds of work
- * per wave; an abandoned pass leaves no trace in the film.  Returns JTX_MI_CANCELLED then (acc_rgb / img_rgb hold the
- * completed passes; jtx_mi_last_completed_sample tells how many strata that is), 0 when the frame is complete. */
+ * a non-zero return of the callback, or jtx_mi_cancel() from ANY thread at ANY time -- the persistent waves poll the
+ * flag when they fetch chunks of 64 x strata paths, so a running launch stops within microseconds of work per wave; a pass
+ * that is unfinished then leaves no trace in the film.  Returns JTX_MI_CANCELLED then: acc_rgb / img_rgb hold EXACTLY the strata
+ * [0, n) of every pixel -- what a render of sample_end = n gives, bit for bit -- and jtx_mi_last_completed_sample tells n (passes
+ * that were already in flight when the stop arrived may be in it); 0 when the frame is complete. */
 int jtx_mi_render(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
                   float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user);
 int jtx_mi_cancel(jtx_mi_scene *scene);                                     /* Camera::terminateRender(); thread-safe */
@@ -268,8 +284,9 @@ int jtx_mi_last_completed_sample(const jtx_mi_scene *scene, int32_t *out);  /* c
 
 /* Same, DEVICE buffers, asynchronous on `stream` (a hipStream_t, NULL = the library's own stream).
  * d_acc_rgb must stay valid until the stream is synchronised.  Used by bench.py / multi-GPU.
- * Renders of one scene are ordered per opts.frame_slot (see there): two frames of a scene can be in flight, one per slot, on two
- * streams, each into film buffers of its own; renders of DIFFERENT scenes are independent.  jtx_mi_render uses the library's own
+ * Renders of one scene are ordered per opts.frame_slot (see there): JTX_MI_FRAME_SLOTS frames of a scene can be in flight, one per
+ * slot, each on a stream and into film buffers of its own (launches that use the scene's singletons -- count_rays, integrator 2,
+ * path_integrator != 0, JTX_DYNAMIC_PATHS=0 -- wait for every slot); renders of DIFFERENT scenes are independent.  jtx_mi_render uses the library's own
  * stream and slot 0.  (jtx_mi_kernel_time pairs are per launch: overlapping launches overlap in time, their durations do not add up
  * to the wall time.)
  * jtx_mi_cancel() also stops a device render in flight (the film then keeps its previous content). */

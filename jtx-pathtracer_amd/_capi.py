@@ -62,7 +62,7 @@ class CameraDesc(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("tile_rank", C.c_int32),
                 ("tile_world", C.c_int32), ("integrator", C.c_int32), ("count_rays", C.c_int32),
-                ("samples_per_tick", C.c_int32), ("reserved", C.c_int32), ("path_integrator", C.c_int32), ("frame_slot", C.c_int32), ("sequence_end", C.c_int32)]
+                ("samples_per_tick", C.c_int32), ("reserved", C.c_int32), ("path_integrator", C.c_int32), ("frame_slot", C.c_int32), ("sequence_end", C.c_int32), ("max_record_mb", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -79,7 +79,7 @@ class SceneInfo(C.Structure):
                 ("lds_resident", C.c_int32), ("scene_radius", C.c_float), ("auto_integrator", C.c_int32),
                 ("device_bytes", C.c_uint64), ("wide_depth", C.c_int32), ("wide_bytes", C.c_int32), ("refitted", C.c_int32),
                 ("num_cus", C.c_int32), ("resident_workgroups", C.c_int32), ("workgroup_size", C.c_int32), ("device_built", C.c_int32),
-                ("wide_bytes64", C.c_uint64), ("rebuild_spare_bytes", C.c_uint64)]
+                ("wide_bytes64", C.c_uint64), ("rebuild_spare_bytes", C.c_uint64), ("frame_slot_bytes", C.c_uint64)]
 
 
 CANCELLED = 2          # JTX_MI_CANCELLED
@@ -111,6 +111,7 @@ SYMBOLS = {
     "jtx_mi_scene_rebuild": (C.c_int, [_scene, C.c_int32]),
     "jtx_mi_scene_release_rebuild": (C.c_int, [_scene]),
     "jtx_mi_scene_reserve_rebuild": (C.c_int, [_scene]),
+    "jtx_mi_scene_release_frames": (C.c_int, [_scene]),
     "jtx_mi_cancel": (C.c_int, [_scene]),
     "jtx_mi_pin_host": (C.c_int, [C.c_void_p, C.c_uint64]),
     "jtx_mi_unpin_host": (C.c_int, [C.c_void_p]),

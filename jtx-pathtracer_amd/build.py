@@ -55,8 +55,13 @@ def build_test_hooks(force=False):
     cc = _hipcc()
     cflags = [f for f in FLAGS if f != "-shared"] + os.environ.get("JTX_EXTRA_HIPCC_FLAGS", "").split()
     objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
     tag = hashlib.sha1(" ".join(cflags).encode()).hexdigest()[:10]
     objs = [os.path.join(objdir, f"{os.path.splitext(src)[0]}.{tag}.o") for src in SOURCES]
+    # the product's objects of THIS flag set must stand: a fresh libjtx_mi.so says nothing about them (build/ does not travel to the
+    # GPU box, JTX_EXTRA_HIPCC_FLAGS moves the tag) -- compile what is missing or stale
+    if not all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(os.path.join(CSRC, src)) for o, src in zip(objs, SOURCES)):
+        build_all(force=True)
     hook = os.path.join(objdir, f"jtx_capi.testhooks.{tag}.o")
     newest = max(os.path.getmtime(os.path.join(CSRC, d)) for d in HEADERS + ["jtx_capi.hip"] if os.path.exists(os.path.join(CSRC, d)))
     if force or not os.path.exists(hook) or os.path.getmtime(hook) < newest:

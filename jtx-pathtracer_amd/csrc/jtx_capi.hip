@@ -129,7 +129,8 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard &) = delete; DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
-constexpr size_t kMaxRadBytes = (size_t) 8 << 30;   // per-path radiance buffer of one pass (k_render_paths); env JTX_MAX_RAD_MB overrides
+constexpr size_t kMaxRadBytes = (size_t) 8 << 30;   // per-path radiance buffer of one pass (k_render_paths); opts.max_record_mb / env JTX_MAX_RAD_MB override
+constexpr int kResolverMax = 64;                  // workgroups of the progressive resolver (words of prog_host per kind)
 constexpr int kWorkRing = 1024;                   // chunk counters of k_render_paths launches (power of two): at most half of them per pass
 constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + tris staged in LDS when they fit this (8 blocks/CU)
 
@@ -222,10 +223,14 @@ struct jtx_mi_scene {
     struct PassRec { unsigned *last_work = nullptr; std::vector<PassPart> parts; int resolved_end = 0; } pass[JTX_MI_FRAME_SLOTS];
     int last_slot = 0;               // the slot of the last launch (jtx_mi_cancel_pending looks at that pass)
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
-    DevBuf<unsigned char> film_img;  // RGB8 preview ...
-    DevBuf<unsigned char> film_imgx[JTX_MI_FRAME_SLOTS - 1];   // ... and those of passes i = 1, 2 (mod 3) when several passes are in flight: each waits in a buffer of its own
-    hipStream_t streamx[JTX_MI_FRAME_SLOTS - 1] = {};          // jtx_mi_render: the streams of those passes (created at the first progressive render)
-    hipEvent_t resolved_ev[JTX_MI_FRAME_SLOTS] = {};           // recorded behind the resolve of the last pass of each residue
+    DevBuf<unsigned char> film_img;  // RGB8 preview
+    // progressive launches (jtx_mi_render with a callback: one k_render_paths<.., PROG> launch for all passes + k_resolve_progressive beside it)
+    DevBuf<unsigned> prog_ctl;       // [0] chunk counter, [1] closed-at, [16 ..] one word per persistent wave (RenderParams::prog_slots)
+    hipStream_t resolve_stream = nullptr, copy_stream = nullptr;   // the resolver's stream; the stream previews travel on
+    hipEvent_t prog_ready = nullptr, prog_paths_done = nullptr, prog_resolved = nullptr;
+    unsigned *prog_host = nullptr;   // host-mapped: [0, 64) started, [64, 128) progress: one word per resolver workgroup
+    unsigned *prog_host_dev = nullptr;
+    unsigned prog_epoch = 0;
     DevScene dev{};
     // wavefront integrator state (sized for pixels * strata-per-batch slots)
     DevBuf<float> wf_floats;         // all float SoA arrays, carved
@@ -253,8 +258,9 @@ struct jtx_mi_scene {
         for (auto &e : pending) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         for (auto &e : free_events) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
         for (auto &e : slot_done) if (e) (void) hipEventDestroy(e);
-        for (auto &e : resolved_ev) if (e) (void) hipEventDestroy(e);
-        for (auto &x : streamx) if (x) (void) hipStreamDestroy(x);
+        for (hipEvent_t e : {prog_ready, prog_paths_done, prog_resolved}) if (e) (void) hipEventDestroy(e);
+        for (hipStream_t x : {resolve_stream, copy_stream}) if (x) (void) hipStreamDestroy(x);
+        if (prog_host) (void) hipHostFree(prog_host);
         if (stream) (void) hipStreamDestroy(stream);
         if (stop_host) (void) hipHostFree(stop_host);
         if (abandon_host) (void) hipHostFree(abandon_host);
@@ -921,9 +927,21 @@ void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_m
 // One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
 // beforeResolve (jtx_mi_render, several passes in flight): the event behind the previous pass's resolve -- this pass's resolve adds to the same
 // film and must follow it; prevWork: that pass's chunk counter (RenderParams::prev_work).
+// Does this render go through the persistent path kernel (working memory per frame slot)?  Everything else -- counting launches, the alternate
+// Li, integrator 2, JTX_DYNAMIC_PATHS=0 -- uses per-scene singletons.
+bool usesPathKernel(const jtx_mi_scene &s, const jtx_mi_render_opts &o) {
+    static const int dynamicPaths = [] { const char *e = getenv("JTX_DYNAMIC_PATHS"); return e ? atoi(e) : 1; }();
+    const int integ = o.integrator != 0 ? o.integrator : autoIntegrator(s);
+    const bool alt = o.path_integrator != 0 || (s.dev.material_mask & 16) != 0;
+    return !alt && integ == 1 && dynamicPaths && o.count_rays == 0;
+}
+
+// prog != nullptr: a PROGRESSIVE launch -- all passes of [sb, se) in one k_render_paths<.., PROG> launch on `stream`, k_resolve_progressive beside it
+// on the scene's resolver stream (the caller has checked that the persistent path kernel takes this render and that the range's records fit)
+struct ProgLaunch { int tick = 1; int resolver_wgs = 0; int spg = 1, groups = 0; unsigned epoch = 0; };
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
-                  float *d_acc, unsigned char *d_img, hipStream_t stream, hipEvent_t beforeResolve = nullptr, unsigned *prevWork = nullptr,
-                  int gridShare = 1) {
+                  float *d_acc, unsigned char *d_img, hipStream_t stream, ProgLaunch *prog = nullptr) {
+    hipEvent_t beforeResolve = nullptr; unsigned *prevWork = nullptr; const int gridShare = 1;
     const int slot = o.frame_slot;
     if (slot < 0 || slot >= JTX_MI_FRAME_SLOTS) throw std::runtime_error("frame_slot: 0 .. " + std::to_string(JTX_MI_FRAME_SLOTS - 1));
     if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (HBM wavefront)");
@@ -1023,6 +1041,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             // than kMaxRadBytes goes in several passes of consecutive strata (the resolve continues the sums in order)
             size_t maxRad = kMaxRadBytes;
             { const char *e = getenv("JTX_MAX_RAD_MB"); if (e && atol(e) > 0) maxRad = (size_t) atol(e) << 20; }
+            if (o.max_record_mb > 0) maxRad = (size_t) o.max_record_mb << 20;
             const long perPass = (long) (maxRad / ((size_t) p.rad_stride * sizeof(float4)));
             const int chunk = perPass >= se - sb ? se - sb : (perPass > 1 ? (int) perPass : 1);
             const size_t need = (size_t) p.rad_stride * (size_t) chunk;
@@ -1035,9 +1054,56 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
             // one chunk counter per launch: a pass split into several launches (radiance buffer cap) and the pass pipelined behind it
             // must never share one (passAbandoned() reads them per part) -- a ring of kWorkRing, at most half of it per pass
             const int nparts = (se - sb + chunk - 1) / chunk;
-            if (nparts > kWorkRing / 2)
+            // (every frame slot may have a pass in flight, and a resolve still reads the counter of the pass before its own: a pass
+            //  takes at most 1 / (slots + 1) of the ring, so that no counter comes round while a launch in flight can read it)
+            constexpr int kPartsMax = kWorkRing / (JTX_MI_FRAME_SLOTS + 1);
+            if (nparts > kPartsMax)
                 throw std::runtime_error("the radiance buffer cap splits this pass into " + std::to_string(nparts) + " launches (more than " +
-                                         std::to_string(kWorkRing / 2) + "): raise JTX_MAX_RAD_MB or render fewer strata per pass");
+                                         std::to_string(kPartsMax) + "): raise max_record_mb / JTX_MAX_RAD_MB or render fewer strata per pass");
+            if (prog) {
+                // ---- one launch for all passes; the resolver beside it ----
+                if (nparts != 1) throw std::runtime_error("progressive launch: the range's radiance records exceed the cap (the caller splits the range)");
+                RenderParams q = p;
+                q.strata_per_group = prog->spg;
+                q.num_groups = (se - sb + prog->spg - 1) / prog->spg;
+                q.num_subblocks = owned * 16;
+                prog->groups = q.num_groups;
+                const int nwaves = jtx_render_paths_waves(q, s.num_cus, 1, prog->resolver_wgs);
+                const size_t words = 16 + (size_t) nwaves;
+                if (s.prog_ctl.n < words) { if (s.prog_ctl.p) HIPCHK(hipDeviceSynchronize()); s.prog_ctl.alloc(words + 1024); }
+                HIPCHK(hipMemsetAsync(s.prog_ctl.p, 0xff, words * sizeof(unsigned), stream));       // closed-at and every wave's word: "none"
+                HIPCHK(hipMemsetAsync(s.prog_ctl.p, 0, sizeof(unsigned), stream));                  // the chunk counter
+                q.work = s.prog_ctl.p; q.prog_closed_at = s.prog_ctl.p + 1; q.prog_slots = s.prog_ctl.p + 16;
+                rec.last_work = nullptr;                                   // (progress comes from the resolver's words, not from a chunk counter)
+                if (!s.resolve_stream) HIPCHK(hipStreamCreateWithFlags(&s.resolve_stream, hipStreamNonBlocking));
+                for (hipEvent_t *e : {&s.prog_ready, &s.prog_paths_done, &s.prog_resolved}) if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+                if (!s.prog_host) {
+                    HIPCHK(hipHostMalloc((void **) &s.prog_host, 2 * kResolverMax * sizeof(unsigned), hipHostMallocMapped));
+                    std::memset(s.prog_host, 0, 2 * kResolverMax * sizeof(unsigned));
+                    void *d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, s.prog_host, 0)); s.prog_host_dev = (unsigned *) d;
+                }
+                prog->epoch = (++s.prog_epoch & 0x7fffu) + 1u;
+                const int nr = prog->resolver_wgs;
+                // the resolver first, and not before the film and the control words stand; the path kernel once the resolver's workgroups
+                // have their wave slots (they say so in host memory; a resolver that finds none yet still gives the right film, later)
+                HIPCHK(hipEventRecord(s.prog_ready, stream));
+                HIPCHK(hipStreamWaitEvent(s.resolve_stream, s.prog_ready, 0));
+                HIPCHK(jtx_launch_resolve_progressive(q, owned, nwaves, nr, s.prog_host_dev, s.prog_host_dev + kResolverMax, prog->epoch, s.resolve_stream));
+                HIPCHK(hipEventRecord(s.prog_resolved, s.resolve_stream));
+                {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while (true) {
+                        int in = 0;
+                        for (int w = 0; w < nr; ++w) in += __atomic_load_n(s.prog_host + w, __ATOMIC_ACQUIRE) == prog->epoch ? 1 : 0;
+                        if (in == nr || std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+                        std::this_thread::yield();
+                    }
+                }
+                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, nr));
+                HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true;
+                HIPCHK(hipEventRecord(s.prog_paths_done, stream));
+                HIPCHK(hipStreamWaitEvent(stream, s.prog_resolved, 0));    // the stream (and the slot's fence) stands for both kernels from here on
+            } else
             for (int b0 = sb; b0 < se; b0 += chunk) {
                 RenderParams q = p;
                 q.sample_begin = b0; q.sample_end = b0 + chunk < se ? b0 + chunk : se;
@@ -1476,6 +1542,8 @@ int jtx_mi_scene_get_info(const jtx_mi_scene *s, jtx_mi_scene_info *out) {
     const uint64_t wb = s->dev.wide ? (uint64_t) s->wide.n * sizeof(uint4) : 0;
     out->wide_depth = s->dev.wide_depth; out->wide_bytes = wb > 0x7fffffffull ? 0x7fffffff : (int32_t) wb; out->wide_bytes64 = wb;
     out->rebuild_spare_bytes = s->spare.bytes();
+    out->frame_slot_bytes = (s->work.cap + s->prog_ctl.cap) * sizeof(unsigned);
+    for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) out->frame_slot_bytes += s->rad[k].cap * sizeof(float4);
     out->refitted = s->refitted;
     out->device_built = s->device_built;
     out->num_cus = s->num_cus;
@@ -1642,68 +1710,15 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         const size_t npix = (size_t) cam->width * cam->height;
         std::unique_lock<std::mutex> lk(s->mu);
         __atomic_store_n(s->stop_host, 0u, __ATOMIC_RELEASE);                  // stopRender_ = false (camera.cpp:48)
-        if (s->film_acc.n != 3 * npix) { s->film_acc.alloc(3 * npix); s->film_img.alloc(3 * npix); for (auto &b : s->film_imgx) b.release(); }
+        if (s->film_acc.n != 3 * npix) { s->film_acc.alloc(3 * npix); s->film_img.alloc(3 * npix); }
         if (sb == 0) HIPCHK(hipMemsetAsync(s->film_acc.p, 0, sizeof(float) * 3 * npix, s->stream));
         else if (hostPinned(acc_rgb)) HIPCHK(hipMemcpyAsync(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix, hipMemcpyHostToDevice, s->stream));
         else { HIPCHK(hipStreamSynchronize(s->stream)); stagedH2D(s->film_acc.p, acc_rgb, sizeof(float) * 3 * npix); }      // a pageable caller buffer: through the library's staging
         HIPCHK(hipMemsetAsync(s->film_img.p, 0, 3 * npix, s->stream));
-        const int tick = (cb && o.samples_per_tick > 0) ? o.samples_per_tick : (se - sb);
+        const int tick = (cb && o.samples_per_tick > 0 && o.samples_per_tick < se - sb) ? o.samples_per_tick : (se - sb);
         jtx_mi_counters total{}; const bool count = o.count_rays != 0;
-        // SEVERAL PASSES IN FLIGHT (round 5): pass i runs on stream and frame slot i mod K (K = 3), so that pass i + 1's path kernel runs
-        // beside the last chunks of pass i, and pass i's resolve -- which finds no free wave slot while pass i + 1 fills the chip -- and
-        // its preview copy beside pass i + 2 (with one stratum per pass, the reference's default, camera.hpp:181, a pass is 0.45 ms of
-        // work, and its end, its resolve and the host's turn-around cost as much again).  Passes enter the film IN ORDER: the resolve of
-        // pass i + 1 waits for the event behind the resolve of pass i, and is skipped when pass i was abandoned (RenderParams::
-        // prev_work).  Per pass only the RGB8 preview travels (what the UI shows, display.cpp:702-703), each residue from a device buffer
-        // of its own; the float accumulation buffer is copied once, at the end or at the cancellation.  Counted passes go one at a time
-        // (the counter block is per launch); JTX_PASSES_IN_FLIGHT=1: all do.
-        constexpr int KMAX = JTX_MI_FRAME_SLOTS;
-        static const int maxInFlight = [] { const char *e = getenv("JTX_PASSES_IN_FLIGHT"); const int v = e ? atoi(e) : KMAX; return v < 1 ? 1 : (v > KMAX ? KMAX : v); }();
-        const int npasses = (se - sb + tick - 1) / tick;
-        const int K = (count || npasses < 2) ? 1 : (maxInFlight < npasses ? maxInFlight : npasses);
-        const bool two = K > 1;
-        // ... and a SMALL pass takes only part of the wave slots: so many waves that a lane gets ~JTX_PASS_PATHS_PER_LANE paths (20).  A wave
-        // ends with its lanes waiting for the longest of its last paths (up to maxDepth + 1 traversals); with one stratum per pass and the
-        // whole chip, a lane has 4.5 paths and that wait is 40 % of the launch.  The passes in flight fill the rest of the chip, and the
-        // resolve of a finished pass finds free slots at once instead of starving behind persistent waves (profiles/r05_progressive.md).
-        // JTX_PASS_GRID_SHARE=n: 1 / n of the slots, whatever the size.
-        static const int shareEnv = [] { const char *e = getenv("JTX_PASS_GRID_SHARE"); return e ? atoi(e) : 0; }();
-        static const int perLane = [] { const char *e = getenv("JTX_PASS_PATHS_PER_LANE"); const int v = e ? atoi(e) : 20; return v < 1 ? 1 : v; }();
-        int gridShare = 1;
-        if (two) {
-            int bs = 0; const long cap = (long) jtx_render_paths_grid(s->dev, s->num_cus, &bs) * (bs / 64);
-            const long want = (long) ((double) npix * tick / (64.0 * perLane));
-            gridShare = want >= cap ? 1 : (int) std::min<long>(16, (cap + std::max<long>(want, 1) - 1) / std::max<long>(want, 1));
-            if (shareEnv > 0) gridShare = shareEnv;
-        }
-        hipStream_t st[KMAX]; unsigned char *dimg[KMAX];
-        for (int k = 0; k < KMAX; ++k) { st[k] = s->stream; dimg[k] = img_rgb ? s->film_img.p : nullptr; }
-        if (two) {
-            for (auto &e : s->resolved_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HIPCHK(hipEventRecord(s->resolved_ev[0], s->stream));
-            for (int k = 1; k < K; ++k) {
-                if (!s->streamx[k - 1]) HIPCHK(hipStreamCreateWithFlags(&s->streamx[k - 1], hipStreamNonBlocking));
-                st[k] = s->streamx[k - 1];
-                if (img_rgb) { if (s->film_imgx[k - 1].n != 3 * npix) s->film_imgx[k - 1].alloc(3 * npix); dimg[k] = s->film_imgx[k - 1].p; }
-                HIPCHK(hipStreamWaitEvent(st[k], s->resolved_ev[0], 0));        // every stream starts behind the film's set-up (clear / upload above)
-            }
-        }
-        struct DrainAll { hipStream_t *v; int n; ~DrainAll() { for (int k = 0; k < n; ++k) (void) hipStreamSynchronize(v[k]); } } drainAll{st, K};   // nothing of this call outlives it
-        auto syncAll = [&] { for (int k = 0; k < K; ++k) HIPCHK(hipStreamSynchronize(st[k])); };
-        struct Pass { int idx, begin, end; };
-        std::deque<Pass> flight;
-        int nextIdx = 0, nextBegin = sb;
-        auto enqueue = [&] {
-            const int idx = nextIdx++, b = nextBegin, e = b + tick < se ? b + tick : se, par = idx % K;
-            nextBegin = e;
-            jtx_mi_render_opts o2 = o; o2.frame_slot = par;
-            o2.sequence_end = (e >= se) ? 1 : 0;
-            const bool chain = two && idx > 0;
-            launchRender(*s, *cam, o2, b, e, s->film_acc.p, dimg[par], st[par], chain ? s->resolved_ev[(idx - 1) % K] : nullptr,
-                         chain ? s->pass[(idx - 1) % K].last_work : nullptr, gridShare);
-            if (two) HIPCHK(hipEventRecord(s->resolved_ev[par], st[par]));
-            flight.push_back({idx, b, e});
-        };
+        unsigned char *dimg = img_rgb ? s->film_img.p : nullptr;
+        struct Drain { hipStream_t a, b, c; ~Drain() { for (hipStream_t x : {a, b, c}) if (x) (void) hipStreamSynchronize(x); } };   // nothing of this call outlives it
         // Film delivery: a pinned caller buffer (jtx_mi_pin_host / hipHostRegister: what the Camera mirrors do with img_ /
         // acc_) is the DMA target itself; a pageable one is fed through the scene's pinned staging buffers and one host
         // memcpy -- hipMemcpy to pageable memory would stage through small driver buffers at a fraction of the PCIe rate.
@@ -1722,71 +1737,127 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double tMark = now();
         auto lap = [&](const char *what) { if (trace) { const double t = now(); fprintf(stderr, "[jtx_mi_render] %-18s %8.3f ms\n", what, t - tMark); tMark = t; } };
-        auto fetchImg = [&](int par) {                                          // the preview of the last pass of this parity; blocks until its stream has drained
-            if (!img_rgb) { HIPCHK(hipStreamSynchronize(st[par])); return; }
-            HIPCHK(hipMemcpyAsync(imgDirect ? img_rgb : s->pin_img, dimg[par], 3 * npix, hipMemcpyDeviceToHost, st[par]));
-            HIPCHK(hipStreamSynchronize(st[par]));
-        };
         bool cancelled = false;
-        int done = sb;                                                          // strata whose sums are in the film
-        int lastPar = 0;                                                        // parity of the last pass that entered the film (its preview is the film's)
-        // after a cancellation: the passes still in flight, in order -- each either ran to its end (its strata are in the film and count) or
-        // was abandoned, and then every later one was too (the resolve chain)
-        auto settle = [&] {
-            syncAll();
-            for (const Pass &q : flight) {
-                const int par = q.idx % K;
-                if (passAbandoned(*s, par)) { if (s->pass[par].resolved_end > done) { done = s->pass[par].resolved_end; lastPar = par; } break; }
-                done = q.end; lastPar = par;
-            }
-            flight.clear();
-        };
-        for (int k = 0; k < K && nextBegin < se; ++k) enqueue();
-        while (!flight.empty()) {
-            const Pass cur = flight.front();
-            const int par = cur.idx % K;
-            lap("enqueue");
-            fetchImg(par);                                                      // this pass: preview to (pinned) host memory
-            lap("pass + img D2H");
-            if (passAbandoned(*s, par)) {                                       // the kernels saw the cancellation: the abandoned launch left no trace;
-                if (s->pass[par].resolved_end > done) { done = s->pass[par].resolved_end; lastPar = par; }   // earlier launches of a split pass are in the film and count
-                flight.clear();                                                 // (the passes behind it are abandoned with it: the resolve chain)
-                cancelled = true; break;
-            }
-            flight.pop_front();
-            done = cur.end; lastPar = par;
-            if (count) {
-                unsigned long long h[64];
-                HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
-                countersAddWords(total, h);
-            }
-            const bool more = nextBegin < se;
-            if (more && !count) enqueue();                                      // the next pass of this parity: behind this one's preview copy on its stream
-            if (img_rgb && !imgDirect && (cb || flight.empty())) std::memcpy(img_rgb, s->pin_img, 3 * npix);
-            lap("img memcpy");
-            if (cb) {
-                lk.unlock();
-                const int stop = cb(done, spp, user);                           // currentSample_ advance, camera.cpp:68-74
-                lk.lock();
-                if (stop) {
-                    if (!flight.empty()) {                                      // abandon what is in flight
-                        __atomic_store_n(s->stop_host, 1u, __ATOMIC_RELEASE);
-                        // the waves poll the flag at every 64th chunk fetch: a short pass (or a slow callback) completes and is
-                        // resolved before they look -- then its strata ARE in the film and count as completed
-                        settle();
+        int done = sb;                                                          // strata whose sums are in the film of every pixel
+        static const int progressiveOn = [] { const char *e = getenv("JTX_PROGRESSIVE_LAUNCH"); return e ? atoi(e) : 1; }();
+        if (cb && tick < se - sb && progressiveOn && usesPathKernel(*s, o)) {
+            // ---- PROGRESSIVE (round 6): ONE launch for all passes, whatever samplesPerPass_ is (before: a launch, a resolve, a preview copy and
+            // a host turn-around per pass -- 46.5 ms per C2 frame at samplesPerPass_ = 1 for a 22.7 ms kernel).  k_render_paths<.., PROG> traces
+            // pass after pass; k_resolve_progressive, beside it, adds every pass that is complete to the film and the preview and says, in
+            // host-mapped memory, how many passes are in the film of EVERY pixel (currentSample_, camera.cpp:68-74).  This thread watches
+            // that: when it has advanced, the RGB8 preview is copied as it stands -- every pixel of it shows at least the reported strata,
+            // some already a pass more: the reference's UI reads img_ unsynchronised beside the tile workers too (display.cpp:702-703) --
+            // and the callback runs once per pass, in order.  The launch does not wait for the callback.  A stop (the callback's return
+            // value, jtx_mi_cancel from any thread) closes the chunk counter: the passes whose chunks were all dealt are finished and
+            // added, the pass after them leaves no trace.
+            // A range whose records exceed the cap goes in several such launches, one after the other.
+            if (!s->copy_stream) HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+            if (!s->resolve_stream) HIPCHK(hipStreamCreateWithFlags(&s->resolve_stream, hipStreamNonBlocking));
+            Drain drain{s->stream, s->resolve_stream, s->copy_stream};
+            const int world = o.tile_world > 1 ? o.tile_world : 1, rank = o.tile_world > 1 ? o.tile_rank : 0;
+            const int tiles = ((cam->width + 31) / 32) * ((cam->height + 31) / 32);
+            const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
+            size_t maxRad = kMaxRadBytes;
+            { const char *e = getenv("JTX_MAX_RAD_MB"); if (e && atol(e) > 0) maxRad = (size_t) atol(e) << 20; }
+            if (o.max_record_mb > 0) maxRad = (size_t) o.max_record_mb << 20;
+            const size_t rowBytes = (size_t) (owned > 0 ? owned : 1) * 1024 * sizeof(float4);
+            long perLaunch = (long) (maxRad / rowBytes) / tick * tick;          // whole passes
+            if (perLaunch < tick) throw std::runtime_error("one pass of " + std::to_string(tick) + " strata does not fit the radiance-record cap: raise max_record_mb or lower samples_per_tick");
+            static const int resolverEnv = [] { const char *e = getenv("JTX_RESOLVER_WGS"); return e ? atoi(e) : 0; }();
+            int nr = resolverEnv > 0 ? resolverEnv : 32;
+            if (nr > kResolverMax) nr = kResolverMax;
+            if (nr > owned * 4) nr = owned * 4 > 0 ? owned * 4 : 1;             // (a workgroup per 256 pixel slots at most)
+            int reported = sb;                                                  // strata the callback has been told of
+            bool stopAsked = false;
+            for (int b0 = sb; b0 < se && !cancelled; ) {
+                const int e0 = (long) b0 + perLaunch < se ? b0 + (int) perLaunch : se;
+                ProgLaunch pl; pl.tick = tick; pl.resolver_wgs = nr;
+                // a pass is a strata group, or a whole number of them when passes are long and the launch would have few chunks
+                pl.spg = tick;
+                if ((e0 - b0) % tick == 0) while (pl.spg % 2 == 0 && pl.spg >= 16 && (long) owned * 16 * ((e0 - b0) / pl.spg) < 250000) pl.spg /= 2;
+                jtx_mi_render_opts o2 = o; o2.frame_slot = 0; o2.sequence_end = 1;
+                launchRender(*s, *cam, o2, b0, e0, s->film_acc.p, dimg, s->stream, &pl);
+                lap("enqueue");
+                const int perPass = tick / pl.spg;                              // groups per pass
+                auto completed = [&] {                                          // strata of this launch that are in the film of every pixel
+                    unsigned g = 0xffffu;
+                    for (int w = 0; w < nr; ++w) {
+                        const unsigned v = __atomic_load_n(s->prog_host + kResolverMax + w, __ATOMIC_ACQUIRE);
+                        const unsigned gw = (v >> 16) == pl.epoch ? (v & 0xffffu) : 0u;
+                        g = gw < g ? gw : g;
                     }
+                    if (owned == 0) g = (unsigned) pl.groups;
+                    const long d = (long) b0 + (long) (g / perPass * perPass) * pl.spg;        // whole passes
+                    return d < e0 ? (int) d : e0;
+                };
+                unsigned idle = 0;
+                while (true) {
+                    const bool finished = hipEventQuery(s->prog_resolved) == hipSuccess && hipEventQuery(s->prog_paths_done) == hipSuccess;   // (first: the words read below are then final)
+                    (void) hipGetLastError();
+                    const int have = completed();
+                    if (have > reported && !stopAsked) {
+                        idle = 0;
+                        if (img_rgb) {                                          // the preview as it stands, to (pinned) host memory
+                            HIPCHK(hipMemcpyAsync(imgDirect ? img_rgb : s->pin_img, dimg, 3 * npix, hipMemcpyDeviceToHost, s->copy_stream));
+                            HIPCHK(hipStreamSynchronize(s->copy_stream));
+                            if (!imgDirect) std::memcpy(img_rgb, s->pin_img, 3 * npix);
+                        }
+                        lap("preview");
+                        while (reported < have && !stopAsked) {
+                            reported = reported + tick < have ? reported + tick : have;
+                            lk.unlock();
+                            const int stop = cb(reported, spp, user);           // currentSample_ advance, camera.cpp:68-74
+                            lk.lock();
+                            if (stop) { stopAsked = true; __atomic_store_n(s->stop_host, 1u, __ATOMIC_RELEASE); }
+                        }
+                    }
+                    if (finished) break;
+                    if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield();
+                }
+                HIPCHK(hipStreamSynchronize(s->stream));
+                done = completed();
+                if (done < e0 || stopAsked) cancelled = true;
+                b0 = e0;
+                lap("launch");
+            }
+        } else {
+            // ---- one pass at a time: a frame without passes (one launch), or launches on the scene's singletons (counting, the alternate
+            // Li, integrator 2), which do not poll the cancellation word -- it is honoured between their passes ----
+            Drain drain{s->stream, nullptr, nullptr};
+            for (int b = sb; b < se; b += tick) {
+                const int e = b + tick < se ? b + tick : se;
+                if (b > sb && __atomic_load_n(s->stop_host, __ATOMIC_ACQUIRE) != 0) { cancelled = true; break; }
+                launchRender(*s, *cam, o, b, e, s->film_acc.p, dimg, s->stream);
+                if (img_rgb && cb) HIPCHK(hipMemcpyAsync(imgDirect ? img_rgb : s->pin_img, dimg, 3 * npix, hipMemcpyDeviceToHost, s->stream));
+                HIPCHK(hipStreamSynchronize(s->stream));
+                lap("pass");
+                if (passAbandoned(*s, o.frame_slot)) {                         // the kernels saw the cancellation: the abandoned launch left no trace;
+                    if (s->pass[o.frame_slot].resolved_end > done) done = s->pass[o.frame_slot].resolved_end;   // earlier launches of a split pass are in the film and count
                     cancelled = true; break;
                 }
+                done = e;
+                if (count) {
+                    unsigned long long h[64];
+                    HIPCHK(hipMemcpy(h, s->counters.p, sizeof h, hipMemcpyDeviceToHost));
+                    countersAddWords(total, h);
+                }
+                if (cb) {
+                    if (img_rgb && !imgDirect) std::memcpy(img_rgb, s->pin_img, 3 * npix);
+                    lk.unlock();
+                    const int stop = cb(done, spp, user);                       // currentSample_ advance, camera.cpp:68-74
+                    lk.lock();
+                    if (stop) { cancelled = true; break; }
+                }
             }
-            if (flight.empty() && more && count) enqueue();                     // counted passes: the counter block is per launch
         }
-        syncAll();
+        // the film as the launches left it: accumulation buffer and the preview that belongs to it
         HIPCHK(hipMemcpyAsync(accDirect ? acc_rgb : s->pin_acc, s->film_acc.p, sizeof(float) * 3 * npix, hipMemcpyDeviceToHost, s->stream));
-        if (cancelled) fetchImg(lastPar); else HIPCHK(hipStreamSynchronize(s->stream));
-        if (cancelled && img_rgb && !imgDirect) std::memcpy(img_rgb, s->pin_img, 3 * npix);
-        lap("acc D2H");
+        if (img_rgb) HIPCHK(hipMemcpyAsync(imgDirect ? img_rgb : s->pin_img, dimg, 3 * npix, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        lap("film D2H");
         if (!accDirect) std::memcpy(acc_rgb, s->pin_acc, sizeof(float) * 3 * npix);
-        lap("acc memcpy");
+        if (img_rgb && !imgDirect) std::memcpy(img_rgb, s->pin_img, 3 * npix);
+        lap("film memcpy");
         s->last_completed = done;
         if (count) {   // leave the frame totals on the device for jtx_mi_get_counters
             unsigned long long h[64] = {};
@@ -1809,6 +1880,19 @@ int jtx_mi_unpin_host(void *ptr) {
     hipError_t e = hipHostUnregister(ptr);
     if (e != hipSuccess) { (void) hipGetLastError(); return fail(std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
     return 0;
+}
+
+// the frame slots' working memory (radiance records, chunk counters) back to the device; the next render allocates what it needs
+int jtx_mi_scene_release_frames(jtx_mi_scene *s) {
+    try {
+        if (!s) throw std::runtime_error("null scene");
+        std::lock_guard<std::mutex> lk(s->mu);
+        DeviceGuard dg(s->device);
+        HIPCHK(hipDeviceSynchronize());                 // launches in any slot, on any stream, have ended
+        for (int k = 0; k < JTX_MI_FRAME_SLOTS; ++k) { s->rad[k].release(); s->pass[k] = jtx_mi_scene::PassRec{}; }
+        s->work.release(); s->work_slot = 0; s->prog_ctl.release();
+        return 0;
+    } catch (const std::exception &e) { return fail(std::string("release_frames: ") + e.what()); }
 }
 
 int jtx_mi_last_completed_sample(const jtx_mi_scene *s, int32_t *out) {

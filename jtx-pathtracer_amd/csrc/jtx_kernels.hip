@@ -259,16 +259,42 @@ __global__ void __launch_bounds__(BLOCK, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP
 // while its other lanes are still finishing paths of the previous chunk: no wave ever drains except at the very end
 // of the launch (a wave of 4 paths per lane lost ~12 % to its own drain), and the scene is staged once per workgroup.
 // a finished path's clamped radiance (camera.cpp:110-112) into its record
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned PROG_NONE = 0xffffffffu;        // a wave's word of prog_slots: not started / gone; prog_closed_at: no cancellation
+// WT: write-through (sc1) -- the record is read by ANOTHER kernel while this one still runs (k_resolve_progressive; per-XCD L2s are not
+// coherent: a plain store would sit in this XCD's L2 until the launch ends)
+template <bool WT>
 JD void writeRadiance(const RenderParams &p, f3 c, int s, int slot) {
     if (c.x > 1.0f) c.x = 1.0f;
     if (c.y > 1.0f) c.y = 1.0f;
     if (c.z > 1.0f) c.z = 1.0f;
-    p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot] = make_float4(c.x, c.y, c.z, 0.0f);
+    if constexpr (WT) {
+        u32x4 v; v.x = __float_as_uint(c.x); v.y = __float_as_uint(c.y); v.z = __float_as_uint(c.z); v.w = 0u;
+        const float4 *q = p.rad + ((size_t) (s - p.sample_begin) * p.rad_stride + slot);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+    } else
+        p.rad[(size_t) (s - p.sample_begin) * p.rad_stride + slot] = make_float4(c.x, c.y, c.z, 0.0f);
 }
 
-template <int SRC, int MASK, int BS>
+// PROG (round 6): the PROGRESSIVE instance -- ONE launch for all passes of a frame (StaticCamera::render's loop over passes,
+// camera.cpp:66-126, inside one kernel), beside k_resolve_progressive, which adds finished passes to the film while this kernel
+// is still tracing later ones.  The path code is the same; what is added sits in the chunk fetch (once per 64 x strata paths):
+// the wave publishes the OLDEST STRATUM it still has a path of (a wave-wide minimum over its live lanes and the chunk it has just
+// fetched) after draining its record stores -- chunks are dealt in stratum order, so every record of every stratum below the minimum
+// over all waves is in memory --, records are stored write-through, and a cancellation closes the chunk counter but keeps the
+// chunk in hand (the chunks dealt so far are all traced: the resolver takes the passes they complete, an unfinished pass leaves
+// no trace).  Costs the kernel 1.1 % (C2 22.68 -> 22.93 ms, C3 274.9 -> 278.1; the in-kernel commit it replaced: 17 - 33 %,
+// EXPERIMENTS.md) -- the batch instance (PROG = false) is the code of round 5, instruction for instruction.
+template <int SRC, int MASK, int BS, bool PROG>
 __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OCC) JTX_SGPR_ATTR k_render_paths(RenderParams p) {
     static_assert((SRC != SRC_LDS && SRC != SRC_LEAF) || BS == BLOCK, "stageScene strides by BLOCK");
+    if constexpr (PROG) {
+        // before the first fetch: "this wave may hold paths of any stratum" (a wave that has not come this far holds none: its word
+        // stays PROG_NONE, and every chunk it will ever fetch lies behind the counter)
+        if ((threadIdx.x & 63) == 0)
+            __hip_atomic_store(p.prog_slots + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)), (unsigned) p.sample_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     extern __shared__ __attribute__((aligned(16))) int smem[];
     constexpr bool LDS_SCENE = SRC == SRC_LDS || SRC == SRC_LEAF;
     const DevScene &sc = p.scene;
@@ -317,11 +343,23 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                     // cancellation poll: the flag lives in HOST memory (one PCIe read), so only every 64th fetch looks, and the
                     // wave that sees it pushes the chunk counter past the end: every other wave stops at its next fetch
                     if (p.stop && (c & 63) == 0 && c < nchunks && __hip_atomic_load(p.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-                        atomicMax(p.work, 0x40000000u); c = nchunks;
+                        if constexpr (PROG) {                            // the chunk in hand is traced: chunks [0, old) are all of the launch
+                            const unsigned old = atomicMax(p.work, 0x40000000u);
+                            if (old < 0x40000000u) __hip_atomic_store(p.prog_closed_at, old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else { atomicMax(p.work, 0x40000000u); c = nchunks; }
                     }
                 }
 #endif
                 c = __shfl(c, 0, 64);
+                if constexpr (PROG) {
+                    int m = alive ? s : 0x7fffffff;                      // the oldest stratum this wave still has a path of ...
+                    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(m, off, 64); m = o < m ? o : m; }
+                    const int first = c < nchunks ? p.sample_begin + (c / p.num_subblocks) * p.strata_per_group : 0x7fffffff;
+                    m = first < m ? first : m;                           // ... or is about to start
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the records of the paths that have ended are out
+                    if (lane == 0) __hip_atomic_store(p.prog_slots + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)),
+                                                      m == 0x7fffffff ? PROG_NONE : (unsigned) m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (c >= nchunks) { exhausted = true; need = false; break; }
                 // chunk c: strata group-major, so that the whole frame advances stratum range by stratum range
                 const int grp = c / p.num_subblocks, sb8 = c - grp * p.num_subblocks;      // 8x8 block index of this rank
@@ -367,10 +405,14 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
             else                { GlobalSrc src; src.tnodes = sc.tnodes; src.tris = sc.tris;
                                   done = pathBounce<false, MASK>(sc, src, p.max_depth, ps, cnt) == BOUNCE_DONE; }
             if (done) {
-                writeRadiance(p, ps.radiance, s, slot);
+                writeRadiance<PROG>(p, ps.radiance, s, slot);
                 alive = false; need = true;
             }
         }
+    }
+    if constexpr (PROG) {                                               // gone: every record of this wave is out
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(p.prog_slots + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)), PROG_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (SRC == SRC_WIDE) { JTX_PROF_WIDE_EXPORT(p, cnt) }
     JTX_PROF_PHASES_END(p, ps, lane, true)
@@ -602,29 +644,159 @@ int jtx_render_paths_grid(const DevScene &sc, int num_cus, int *block_size) {
 // share: this launch takes 1 / share of the wave slots (jtx_mi_render with `share` passes in flight: together they fill the chip, every
 // wave of a small pass gets `share` times as many chunks -- its end, where lanes wait for the longest of the last paths, weighs less --
 // and the resolve of a finished pass finds free slots at once)
-hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream, int share) {
+// leave_workgroups: wave slots (in workgroups of this launch) left to a kernel that runs beside it (the progressive resolver)
+static long renderPathsWaves(const RenderParams &p, int num_cus, int share, int leave_workgroups, int *bsOut) {
+    const bool lds = p.scene.lds_threaded != 0;
+    const bool wide = !lds && p.scene.wide != nullptr;
+    const int bs = lds ? BLOCK : 64;                                     // 64: the workgroup of the kernels that stage nothing
+    if (bsOut) *bsOut = bs;
+    // persistent grid: the waves the GPU can hold (occupancy of the launch bounds), no more than there are chunks
+    const int occ = wide ? JTX_WIDE_OCC : JTX_RP_OCC;
+    long waves = (long) num_cus * 4 * occ;
+    if (share > 1) waves = (waves / share + (bs / 64) - 1) / (bs / 64) * (bs / 64);
+    if (leave_workgroups > 0 && waves > (long) 2 * leave_workgroups * (bs / 64)) waves -= (long) leave_workgroups * (bs / 64);
+    const long chunks = (long) p.num_subblocks * p.num_groups;
+    if (waves > chunks) waves = chunks;
+    return ((waves * 64 + bs - 1) / bs) * (bs / 64);                     // whole workgroups
+}
+int jtx_render_paths_waves(const RenderParams &p, int num_cus, int share, int leave_workgroups) { return (int) renderPathsWaves(p, num_cus, share, leave_workgroups, nullptr); }
+
+hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream, int share, bool progressive, int leave_workgroups) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const bool lds = p.scene.lds_threaded != 0;
     const bool wide = !lds && p.scene.wide != nullptr;
     constexpr int SMALL = 64;                                            // workgroup of the kernels that stage nothing
-    const int bs = lds ? BLOCK : SMALL;
+    int bs = 0;
+    const long waves = renderPathsWaves(p, num_cus, share, leave_workgroups, &bs);
     static const int leafWalk = [] { const char *e = getenv("JTX_LEAF_WALK"); return e ? atoi(e) : 1; }();
     const bool leaf = lds && p.scene.lw_leaves > 0 && leafWalk;
     const size_t shmem = wide ? (size_t) p.scene.wide_depth * bs * sizeof(uint2)
                               : ldsBytes(p.scene, lds) + (leaf ? (size_t) 2 * ((p.scene.lw_leaves + 3) & ~3) * sizeof(float4) + 128 * sizeof(unsigned) : 0);
     const bool lambert = p.scene.material_mask == MAT_DIFFUSE_ONLY;
-    // persistent grid: the waves the GPU can hold (occupancy of the launch bounds), no more than there are chunks
-    const int occ = wide ? JTX_WIDE_OCC : JTX_RP_OCC;
-    long waves = (long) num_cus * 4 * occ;
-    if (share > 1) waves = (waves / share + (bs / 64) - 1) / (bs / 64) * (bs / 64);
-    const long chunks = (long) p.num_subblocks * p.num_groups;
-    if (waves > chunks) waves = chunks;
-    const dim3 grid((unsigned) ((waves * 64 + bs - 1) / bs)), block(bs);
-#define LAUNCH_PA(L, M, B) hipLaunchKernelGGL((k_render_paths<L, M, B>), grid, block, shmem, stream, p)
+    const dim3 grid((unsigned) (waves * 64 / bs)), block(bs);
+#define LAUNCH_PA(L, M, B) do { if (progressive) hipLaunchKernelGGL((k_render_paths<L, M, B, true>), grid, block, shmem, stream, p); \
+                                else hipLaunchKernelGGL((k_render_paths<L, M, B, false>), grid, block, shmem, stream, p); } while (0)
     if (leaf) { if (lambert) LAUNCH_PA(SRC_LEAF, MAT_DIFFUSE_ONLY, BLOCK); else LAUNCH_PA(SRC_LEAF, MAT_ALL, BLOCK); }
     else if (lambert) { if (lds) LAUNCH_PA(SRC_LDS, MAT_DIFFUSE_ONLY, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_DIFFUSE_ONLY, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_DIFFUSE_ONLY, SMALL); }
     else         { if (lds) LAUNCH_PA(SRC_LDS, MAT_ALL, BLOCK); else if (wide) LAUNCH_PA(SRC_WIDE, MAT_ALL, SMALL); else LAUNCH_PA(SRC_GLOBAL, MAT_ALL, SMALL); }
 #undef LAUNCH_PA
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_resolve_progressive: the film side of a progressive launch.  A few persistent workgroups beside k_render_paths<.., PROG>: each owns a
+// fixed share of the rank's pixels and adds, pass after pass, the records of every pass that is COMPLETE -- in sample order per pixel,
+// AccumulationBuffer::updatePixel's float sums (image.hpp:82-86) -- and writes the RGB8 preview (image.hpp:47-52; the divisor is the
+// strata so far, camera.cpp:115).  Complete = dealt and out of every wave's hands:
+//     dealt  = chunks the counter has handed out (after a cancellation: the count it was closed at) -- read FIRST;
+//     oldest = the minimum over the path waves' words of prog_slots (the oldest stratum a wave still has a path of; a wave stores the
+//              launch's first stratum before its first fetch and drains its record stores before every update: a stale word is a
+//              smaller one) -- read SECOND, so that every chunk counted in `dealt` is covered by its wave's word;
+//     passes complete = min(dealt / chunks per pass, (oldest - first stratum) / strata per pass).
+// A pass that a cancellation left unfinished is never added: the film then holds exactly the passes before it.
+// No workgroup ever waits for another, and the path kernel never waits for this one: if the resolver finds no wave slots until the path
+// kernel has ended, it adds all passes then (what k_resolve_samples does for a batch launch).
+// progress_host[workgroup] = epoch << 16 | passes in the film of ALL its pixels (host-mapped; the host takes the minimum: currentSample_).
+// ------------------------------------------------------------------------------------------------
+namespace jtx {
+constexpr int RESOLVE_BLOCK = 256;
+__global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderParams p, int num_path_waves, unsigned *started_host, unsigned *progress_host, unsigned epoch) {
+    __shared__ unsigned shDealt, shOldest[RESOLVE_BLOCK / 64];
+    const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+    if (tid == 0) __hip_atomic_store(started_host + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int nchunks = p.num_subblocks * p.num_groups;
+    int done = 0;                                                       // passes this workgroup has added for all its pixels
+    unsigned dealtSeen = 0u;
+    while (true) {
+        // ---- how many passes are complete? ----
+        if (tid == 0) {
+            const unsigned wk = atomicAdd(p.work, 0u);                  // (an atomic: performed where the path waves' fetches are)
+            unsigned dealt;
+            unsigned known = 0x80000000u;                               // bit 31: `dealt` is final once every wave is gone
+            if (wk < 0x40000000u) { dealt = wk < (unsigned) nchunks ? wk : (unsigned) nchunks; if (wk < (unsigned) nchunks) known = 0u; }
+            else {                                                      // closed by a cancellation: the wave that closed it says at what count
+                const unsigned ca = atomicOr(p.prog_closed_at, 0u);
+                if (ca == PROG_NONE) { dealt = dealtSeen; known = 0u; } else dealt = ca < (unsigned) nchunks ? ca : (unsigned) nchunks;
+            }
+            shDealt = dealt | known;
+        }
+        __syncthreads();
+        const unsigned dealtWord = shDealt;
+        const unsigned dealt = dealtWord & 0x7fffffffu;
+        const bool dealtFinal = (dealtWord & 0x80000000u) != 0u;
+        dealtSeen = dealt;
+        unsigned m = PROG_NONE;
+        for (int i = tid; i < num_path_waves; i += RESOLVE_BLOCK) {
+            const unsigned v = __hip_atomic_load(p.prog_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = v < m ? v : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(m, off, 64); m = o < m ? o : m; }
+        if ((tid & 63) == 0) shOldest[tid >> 6] = m;
+        __syncthreads();
+        unsigned oldest = shOldest[0];
+        for (int i = 1; i < RESOLVE_BLOCK / 64; ++i) oldest = shOldest[i] < oldest ? shOldest[i] : oldest;
+        __syncthreads();                                                // (shDealt / shOldest are rewritten in the next round)
+        const bool allGone = oldest == PROG_NONE;
+        int complete = (int) (dealt / (unsigned) p.num_subblocks);
+        if (!allGone) { const int byWaves = ((int) oldest - p.sample_begin) / p.strata_per_group; complete = byWaves < complete ? byWaves : complete; }
+        if (complete > p.num_groups) complete = p.num_groups;
+        // the last round: every chunk is dealt (or the counter is closed and says how many were) and no wave holds a path
+        const bool last = allGone && dealtFinal;
+        if (complete > done) {
+            // ---- passes [done, complete) into the film of this workgroup's pixels ----
+            const int sA = p.sample_begin + done * p.strata_per_group;
+            int sB = p.sample_begin + complete * p.strata_per_group; if (sB > p.sample_end) sB = p.sample_end;
+            for (int pslot = wg * RESOLVE_BLOCK + tid; pslot < p.rad_stride; pslot += nwg * RESOLVE_BLOCK) {
+                const int owned = pslot >> 10, sub = (pslot >> 6) & 15, l = pslot & 63;
+                const int tile = p.tile_rank + owned * p.tile_world;
+                const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
+                const int row = trow * 32 + (sub >> 2) * 8 + (l >> 3);
+                const int col = tcol * 32 + (sub & 3) * 8 + (l & 7);
+                if (row >= p.height || col >= p.width) continue;
+                const size_t pix = (size_t) row * p.width + col;
+                f3 acc = mk3(0.0f);
+                if (sA > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
+                const float4 *r = p.rad + ((size_t) (sA - p.sample_begin) * p.rad_stride + pslot);
+                int s = sA;
+                for (; s + 4 <= sB; s += 4, r += (size_t) 4 * p.rad_stride) {             // four loads in flight, the sums in sample order
+                    u32x4 c0, c1, c2, c3;
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+                                 : "v"(r), "v"(r + p.rad_stride), "v"(r + (size_t) 2 * p.rad_stride), "v"(r + (size_t) 3 * p.rad_stride) : "memory");
+                    acc = acc + mk3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
+                    acc = acc + mk3(__uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z));
+                    acc = acc + mk3(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z));
+                    acc = acc + mk3(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
+                }
+                for (; s < sB; ++s, r += p.rad_stride) {
+                    u32x4 c0;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(c0) : "v"(r) : "memory");
+                    acc = acc + mk3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
+                }
+                p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
+                if (p.img) {                                             // write-through: the host copies previews while the launch runs
+                    const float inv = (float) sB;                        // currSample + 1 of the last pass added (camera.cpp:115)
+                    unsigned char *q = p.img + 3 * pix;
+                    __hip_atomic_store(q, toByte(acc.x / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(q + 1, toByte(acc.y / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(q + 2, toByte(acc.z / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            done = complete;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                            // every pixel of the workgroup: then the host may hear of it
+            if (tid == 0) __hip_atomic_store(progress_host + wg, (epoch << 16) | (unsigned) done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (last) break;
+        else __builtin_amdgcn_s_sleep(32);
+    }
+}
+} // namespace jtx
+
+hipError_t jtx_launch_resolve_progressive(const RenderParams &p, int num_owned_tiles, int num_path_waves, int num_workgroups, unsigned *started_host,
+                                          unsigned *progress_host, unsigned epoch, hipStream_t stream) {
+    if (num_owned_tiles <= 0 || num_workgroups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve_progressive, dim3((unsigned) num_workgroups), dim3(RESOLVE_BLOCK), 0, stream, p, num_path_waves, started_host, progress_host, epoch);
     return hipGetLastError();
 }
 

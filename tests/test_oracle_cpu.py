@@ -319,23 +319,24 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(jtx._capi.SYMBOLS), declared ^ set(jtx._capi.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.jtx_mi_version() == 5
+    assert lib.jtx_mi_version() == 6
     assert C.sizeof(jtx._capi.BvhNode) == 32 and C.sizeof(jtx._capi.TriRef) == 8
 
 
 def test_ctypes_structs_match_the_header(tmp_path):
     """the C-ABI's structs as a C compiler lays them out (gcc on include/jtx_mi.h: a plain C header) against the ctypes mirrors of
-    _capi.py -- sizes and the offsets of the fields this round added (frame_slot, sequence_end, the per-class tallies, the spare-set bytes)"""
+    _capi.py -- sizes and the offsets of the fields rounds 5 and 6 added (frame_slot, sequence_end, the per-class tallies, the spare-set bytes; max_record_mb, frame_slot_bytes)"""
     import subprocess
     src = tmp_path / "sizes.c"
     src.write_text('''#include <stdio.h>
 #include <stddef.h>
 #include "jtx_mi.h"
 int main(void) {
-    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(jtx_mi_render_opts), offsetof(jtx_mi_render_opts, frame_slot),
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d %zu %zu\\n", sizeof(jtx_mi_render_opts), offsetof(jtx_mi_render_opts, frame_slot),
            offsetof(jtx_mi_render_opts, sequence_end), sizeof(jtx_mi_counters), offsetof(jtx_mi_counters, n_shade_class),
            offsetof(jtx_mi_counters, n_eval_class), sizeof(jtx_mi_scene_info), offsetof(jtx_mi_scene_info, wide_bytes64),
-           offsetof(jtx_mi_scene_info, rebuild_spare_bytes), sizeof(jtx_mi_camera_desc), JTX_MI_FRAME_SLOTS);
+           offsetof(jtx_mi_scene_info, rebuild_spare_bytes), sizeof(jtx_mi_camera_desc), JTX_MI_FRAME_SLOTS,
+           offsetof(jtx_mi_render_opts, max_record_mb), offsetof(jtx_mi_scene_info, frame_slot_bytes));
     return 0;
 }
 ''')
@@ -345,7 +346,8 @@ int main(void) {
     k = jtx._capi
     want = [C.sizeof(k.RenderOpts), k.RenderOpts.frame_slot.offset, k.RenderOpts.sequence_end.offset, C.sizeof(k.Counters),
             k.Counters.n_shade_class.offset, k.Counters.n_eval_class.offset, C.sizeof(k.SceneInfo), k.SceneInfo.wide_bytes64.offset,
-            k.SceneInfo.rebuild_spare_bytes.offset, C.sizeof(k.CameraDesc), jtx.distributed.FRAME_SLOTS]
+            k.SceneInfo.rebuild_spare_bytes.offset, C.sizeof(k.CameraDesc), jtx.distributed.FRAME_SLOTS,
+            k.RenderOpts.max_record_mb.offset, k.SceneInfo.frame_slot_bytes.offset]
     assert got == want
 
 
