@@ -74,7 +74,11 @@ class Scene:
                     auto_integrator=int(i.auto_integrator), wide_depth=int(i.wide_depth), wide_bytes=int(i.wide_bytes),
                     device_bytes=int(i.device_bytes), refitted=bool(i.refitted), device_built=bool(i.device_built),
                     num_cus=int(i.num_cus), resident_workgroups=int(i.resident_workgroups), workgroup_size=int(i.workgroup_size),
-                    wide_bytes64=int(i.wide_bytes64), rebuild_spare_bytes=int(i.rebuild_spare_bytes))
+                    wide_bytes64=int(i.wide_bytes64), rebuild_spare_bytes=int(i.rebuild_spare_bytes), frame_slot_bytes=int(i.frame_slot_bytes))
+
+    def releaseFrames(self):
+        """jtx_mi_scene_release_frames: the frame slots' working memory (info()["frame_slot_bytes"]) back to the device."""
+        check(self._lib.jtx_mi_scene_release_frames(self.handle))
 
     # -- transform edits (display.cpp:545-588): new Mesh::transform per mesh, then a device refit (topology kept)
     def setTransform(self, mesh, transform):
@@ -357,7 +361,7 @@ class StaticCamera:
         return c
 
     def render(self, scene, count_rays=False, progress=None, tile_rank=0, tile_world=1, sample_begin=0, sample_end=0,
-               integrator=0, path_integrator=0):
+               integrator=0, path_integrator=0, max_record_mb=0):
         """StaticCamera::render(const Scene&) (camera.cpp:45-128).  path_integrator: which Li (camera.cpp:104-106):
         0 integrateMIS, 1 integrate, 2 integrateBasic."""
         self.stopRender_ = False
@@ -368,6 +372,7 @@ class StaticCamera:
         o.sample_begin, o.sample_end = sample_begin, sample_end
         o.integrator = integrator
         o.path_integrator = path_integrator
+        o.max_record_mb = max_record_mb
         o.samples_per_tick = self.samplesPerPass_ if progress is not None else 0
 
         def _cb(cur, total, _user):

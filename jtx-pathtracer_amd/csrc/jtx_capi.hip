@@ -130,7 +130,7 @@ struct DeviceGuard {
 };
 
 constexpr size_t kMaxRadBytes = (size_t) 8 << 30;   // per-path radiance buffer of one pass (k_render_paths); opts.max_record_mb / env JTX_MAX_RAD_MB override
-constexpr int kResolverMax = 64;                  // workgroups of the progressive resolver (words of prog_host per kind)
+constexpr int kResolverMax = 128;                 // workgroups of the progressive resolver (words of prog_host per kind)
 constexpr int kWorkRing = 1024;                   // chunk counters of k_render_paths launches (power of two): at most half of them per pass
 constexpr size_t kLdsThreadedBudget = 20 * 1024; // 8 threaded node orderings + tris staged in LDS when they fit this (8 blocks/CU)
 
@@ -225,7 +225,7 @@ struct jtx_mi_scene {
     DevBuf<float> film_acc;          // device film for jtx_mi_render (host-buffer variant)
     DevBuf<unsigned char> film_img;  // RGB8 preview
     // progressive launches (jtx_mi_render with a callback: one k_render_paths<.., PROG> launch for all passes + k_resolve_progressive beside it)
-    DevBuf<unsigned> prog_ctl;       // [0] chunk counter, [1] closed-at, [16 ..] one word per persistent wave (RenderParams::prog_slots)
+    DevBuf<unsigned> prog_ctl;       // [0] chunk counter, [32] closed-at, [64] the resolver leader's word, [128 ..] one word per persistent wave (RenderParams::prog_slots)
     hipStream_t resolve_stream = nullptr, copy_stream = nullptr;   // the resolver's stream; the stream previews travel on
     hipEvent_t prog_ready = nullptr, prog_paths_done = nullptr, prog_resolved = nullptr;
     unsigned *prog_host = nullptr;   // host-mapped: [0, 64) started, [64, 128) progress: one word per resolver workgroup
@@ -938,7 +938,7 @@ bool usesPathKernel(const jtx_mi_scene &s, const jtx_mi_render_opts &o) {
 
 // prog != nullptr: a PROGRESSIVE launch -- all passes of [sb, se) in one k_render_paths<.., PROG> launch on `stream`, k_resolve_progressive beside it
 // on the scene's resolver stream (the caller has checked that the persistent path kernel takes this render and that the range's records fit)
-struct ProgLaunch { int tick = 1; int resolver_wgs = 0; int spg = 1, groups = 0; unsigned epoch = 0; };
+struct ProgLaunch { int tick = 1; int resolver_wgs = 0; int spg = 1, groups = 0; unsigned epoch = 0; };     // in: tick, resolver_wgs, spg; out: groups, epoch
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
                   float *d_acc, unsigned char *d_img, hipStream_t stream, ProgLaunch *prog = nullptr) {
     hipEvent_t beforeResolve = nullptr; unsigned *prevWork = nullptr; const int gridShare = 1;
@@ -1068,12 +1068,19 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.num_groups = (se - sb + prog->spg - 1) / prog->spg;
                 q.num_subblocks = owned * 16;
                 prog->groups = q.num_groups;
-                const int nwaves = jtx_render_paths_waves(q, s.num_cus, 1, prog->resolver_wgs);
-                const size_t words = 16 + (size_t) nwaves;
+                q.prog_groups_per_pass = prog->tick > prog->spg ? prog->tick / prog->spg : 1;
+                const int leave = jtx_resolve_progressive_waves(prog->resolver_wgs);
+                const int nwaves = jtx_render_paths_waves(q, s.num_cus, 1, leave);
+                // the chunk counter, the closed-at word, the resolver leader's word and the waves' words on cache lines of their own: the
+                // counter takes every fetch of every wave, and a poll of a word on ITS line queues up with them
+                constexpr int kClosedAt = 32, kLeader = 64, kSlots = 128;
+                const size_t words = kSlots + (size_t) nwaves;
                 if (s.prog_ctl.n < words) { if (s.prog_ctl.p) HIPCHK(hipDeviceSynchronize()); s.prog_ctl.alloc(words + 1024); }
-                HIPCHK(hipMemsetAsync(s.prog_ctl.p, 0xff, words * sizeof(unsigned), stream));       // closed-at and every wave's word: "none"
-                HIPCHK(hipMemsetAsync(s.prog_ctl.p, 0, sizeof(unsigned), stream));                  // the chunk counter
-                q.work = s.prog_ctl.p; q.prog_closed_at = s.prog_ctl.p + 1; q.prog_slots = s.prog_ctl.p + 16;
+                // closed-at and every wave's word: "none" (a wave that has not started holds no path); chunk counter and the resolver leader's word: 0
+                HIPCHK(hipMemsetAsync(s.prog_ctl.p, 0xff, words * sizeof(unsigned), stream));
+                HIPCHK(hipMemsetAsync(s.prog_ctl.p, 0, sizeof(unsigned), stream));
+                HIPCHK(hipMemsetAsync(s.prog_ctl.p + kLeader, 0, (kSlots - kLeader) * sizeof(unsigned), stream));
+                q.work = s.prog_ctl.p; q.prog_closed_at = s.prog_ctl.p + kClosedAt; q.prog_leader = s.prog_ctl.p + kLeader; q.prog_slots = s.prog_ctl.p + kSlots;
                 rec.last_work = nullptr;                                   // (progress comes from the resolver's words, not from a chunk counter)
                 if (!s.resolve_stream) HIPCHK(hipStreamCreateWithFlags(&s.resolve_stream, hipStreamNonBlocking));
                 for (hipEvent_t *e : {&s.prog_ready, &s.prog_paths_done, &s.prog_resolved}) if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -1095,11 +1102,15 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                     while (true) {
                         int in = 0;
                         for (int w = 0; w < nr; ++w) in += __atomic_load_n(s.prog_host + w, __ATOMIC_ACQUIRE) == prog->epoch ? 1 : 0;
-                        if (in == nr || std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+                        if (in == nr) break;
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+                            if (getenv("JTX_TRACE_RENDER")) fprintf(stderr, "[jtx_mi_render] resolver check-in timed out: %d of %d workgroups\n", in, nr);
+                            break;
+                        }
                         std::this_thread::yield();
                     }
                 }
-                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, nr));
+                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, leave));
                 HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true;
                 HIPCHK(hipEventRecord(s.prog_paths_done, stream));
                 HIPCHK(hipStreamWaitEvent(stream, s.prog_resolved, 0));    // the stream (and the slot's fence) stands for both kernels from here on
@@ -1764,22 +1775,28 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
             long perLaunch = (long) (maxRad / rowBytes) / tick * tick;          // whole passes
             if (perLaunch < tick) throw std::runtime_error("one pass of " + std::to_string(tick) + " strata does not fit the radiance-record cap: raise max_record_mb or lower samples_per_tick");
             static const int resolverEnv = [] { const char *e = getenv("JTX_RESOLVER_WGS"); return e ? atoi(e) : 0; }();
-            int nr = resolverEnv > 0 ? resolverEnv : 32;
+            int nr = resolverEnv > 0 ? resolverEnv : 64;                        // one watches the path waves, the others add passes
             if (nr > kResolverMax) nr = kResolverMax;
-            if (nr > owned * 4) nr = owned * 4 > 0 ? owned * 4 : 1;             // (a workgroup per 256 pixel slots at most)
+            if (nr > owned * 4 + 1) nr = owned * 4 + 1;                         // (a worker per 256 pixel slots at most)
+            if (nr < 2) nr = 2;
             int reported = sb;                                                  // strata the callback has been told of
             bool stopAsked = false;
             for (int b0 = sb; b0 < se && !cancelled; ) {
                 const int e0 = (long) b0 + perLaunch < se ? b0 + (int) perLaunch : se;
                 ProgLaunch pl; pl.tick = tick; pl.resolver_wgs = nr;
-                // a pass is a strata group, or a whole number of them when passes are long and the launch would have few chunks
+                // strata per group (= per chunk of an 8x8 block, and the step in which the film advances): a pass; a whole fraction of one
+                // when passes are long and the launch would have few chunks; SEVERAL short passes when a pass alone makes chunks too small
+                // for the persistent waves (C2, one stratum per chunk: kernel 25.2 ms against 22.7 at eight) -- the callback still runs
+                // once per pass, the film and the preview then advance every few passes (at C2's 0.36 ms per pass, far above any display
+                // rate: the reference's UI polls currentSample_ once per frame it draws, display.cpp:700-706)
+                static const int minStrata = [] { const char *e = getenv("JTX_PROG_MIN_STRATA"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
                 pl.spg = tick;
                 if ((e0 - b0) % tick == 0) while (pl.spg % 2 == 0 && pl.spg >= 16 && (long) owned * 16 * ((e0 - b0) / pl.spg) < 250000) pl.spg /= 2;
+                while (pl.spg < minStrata && pl.spg * 2 <= e0 - b0) pl.spg += tick;
                 jtx_mi_render_opts o2 = o; o2.frame_slot = 0; o2.sequence_end = 1;
                 launchRender(*s, *cam, o2, b0, e0, s->film_acc.p, dimg, s->stream, &pl);
                 lap("enqueue");
-                const int perPass = tick / pl.spg;                              // groups per pass
-                auto completed = [&] {                                          // strata of this launch that are in the film of every pixel
+                auto completed = [&] {                                          // strata of this launch that are in the film of every pixel: whole passes
                     unsigned g = 0xffffu;
                     for (int w = 0; w < nr; ++w) {
                         const unsigned v = __atomic_load_n(s->prog_host + kResolverMax + w, __ATOMIC_ACQUIRE);
@@ -1787,7 +1804,7 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                         g = gw < g ? gw : g;
                     }
                     if (owned == 0) g = (unsigned) pl.groups;
-                    const long d = (long) b0 + (long) (g / perPass * perPass) * pl.spg;        // whole passes
+                    const long d = (long) b0 + (long) g * pl.spg;               // (the resolver adds whole passes only)
                     return d < e0 ? (int) d : e0;
                 };
                 unsigned idle = 0;
@@ -1815,6 +1832,7 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                     if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield();
                 }
                 HIPCHK(hipStreamSynchronize(s->stream));
+                if (getenv("JTX_DBG_PROG")) { unsigned h[48]; HIPCHK(hipMemcpy(h, s->prog_ctl.p + 64 + 16, sizeof h, hipMemcpyDeviceToHost)); for (unsigned i = 0; i < h[0] && i < 14; ++i) fprintf(stderr, "[leader] t %8.3f ms dealt groups %u by waves %u\n", (h[1 + 3 * i] - h[1]) / 1000.0, h[2 + 3 * i], h[3 + 3 * i]); }
                 done = completed();
                 if (done < e0 || stopAsked) cancelled = true;
                 b0 = e0;

@@ -644,8 +644,9 @@ int jtx_render_paths_grid(const DevScene &sc, int num_cus, int *block_size) {
 // share: this launch takes 1 / share of the wave slots (jtx_mi_render with `share` passes in flight: together they fill the chip, every
 // wave of a small pass gets `share` times as many chunks -- its end, where lanes wait for the longest of the last paths, weighs less --
 // and the resolve of a finished pass finds free slots at once)
-// leave_workgroups: wave slots (in workgroups of this launch) left to a kernel that runs beside it (the progressive resolver)
-static long renderPathsWaves(const RenderParams &p, int num_cus, int share, int leave_workgroups, int *bsOut) {
+// leave_waves: wave slots left to a kernel that runs beside it (the progressive resolver)
+constexpr int RESOLVE_BLOCK_HOST = 256;            // = jtx::RESOLVE_BLOCK (k_resolve_progressive)
+static long renderPathsWaves(const RenderParams &p, int num_cus, int share, int leave_waves, int *bsOut) {
     const bool lds = p.scene.lds_threaded != 0;
     const bool wide = !lds && p.scene.wide != nullptr;
     const int bs = lds ? BLOCK : 64;                                     // 64: the workgroup of the kernels that stage nothing
@@ -654,20 +655,21 @@ static long renderPathsWaves(const RenderParams &p, int num_cus, int share, int 
     const int occ = wide ? JTX_WIDE_OCC : JTX_RP_OCC;
     long waves = (long) num_cus * 4 * occ;
     if (share > 1) waves = (waves / share + (bs / 64) - 1) / (bs / 64) * (bs / 64);
-    if (leave_workgroups > 0 && waves > (long) 2 * leave_workgroups * (bs / 64)) waves -= (long) leave_workgroups * (bs / 64);
+    if (leave_waves > 0 && waves > (long) 2 * leave_waves) waves -= ((long) leave_waves + (bs / 64) - 1) / (bs / 64) * (bs / 64);
     const long chunks = (long) p.num_subblocks * p.num_groups;
     if (waves > chunks) waves = chunks;
     return ((waves * 64 + bs - 1) / bs) * (bs / 64);                     // whole workgroups
 }
-int jtx_render_paths_waves(const RenderParams &p, int num_cus, int share, int leave_workgroups) { return (int) renderPathsWaves(p, num_cus, share, leave_workgroups, nullptr); }
+int jtx_render_paths_waves(const RenderParams &p, int num_cus, int share, int leave_waves) { return (int) renderPathsWaves(p, num_cus, share, leave_waves, nullptr); }
+int jtx_resolve_progressive_waves(int num_workgroups) { return num_workgroups * (RESOLVE_BLOCK_HOST / 64); }
 
-hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream, int share, bool progressive, int leave_workgroups) {
+hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream, int share, bool progressive, int leave_waves) {
     if (num_owned_tiles <= 0) return hipSuccess;
     const bool lds = p.scene.lds_threaded != 0;
     const bool wide = !lds && p.scene.wide != nullptr;
     constexpr int SMALL = 64;                                            // workgroup of the kernels that stage nothing
     int bs = 0;
-    const long waves = renderPathsWaves(p, num_cus, share, leave_workgroups, &bs);
+    const long waves = renderPathsWaves(p, num_cus, share, leave_waves, &bs);
     static const int leafWalk = [] { const char *e = getenv("JTX_LEAF_WALK"); return e ? atoi(e) : 1; }();
     const bool leaf = lds && p.scene.lw_leaves > 0 && leafWalk;
     const size_t shmem = wide ? (size_t) p.scene.wide_depth * bs * sizeof(uint2)
@@ -694,101 +696,146 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, i
 //              smaller one) -- read SECOND, so that every chunk counted in `dealt` is covered by its wave's word;
 //     passes complete = min(dealt / chunks per pass, (oldest - first stratum) / strata per pass).
 // A pass that a cancellation left unfinished is never added: the film then holds exactly the passes before it.
-// No workgroup ever waits for another, and the path kernel never waits for this one: if the resolver finds no wave slots until the path
-// kernel has ended, it adds all passes then (what k_resolve_samples does for a batch launch).
+// Workgroup 0 watches the path waves and publishes the count (one workgroup scanning: 64 of them polling the chunk counter and 7 000 words
+// each slowed the path kernel from 25.8 to 33.5 ms); the others add the passes, each for a fixed share of the pixels.  The path kernel
+// never waits for this one: if the resolver finds no wave slots until the path kernel has ended, it adds all passes then (what
+// k_resolve_samples does for a batch launch).
 // progress_host[workgroup] = epoch << 16 | passes in the film of ALL its pixels (host-mapped; the host takes the minimum: currentSample_).
 // ------------------------------------------------------------------------------------------------
 namespace jtx {
 constexpr int RESOLVE_BLOCK = 256;
+constexpr unsigned RESOLVE_LAST = 0x80000000u;      // prog word 2: bit 31 = this count is final (every chunk dealt, every wave gone)
+
+// pixel slot -> its pixel; false for the padding slots of tiles that overhang the frame
+JD bool resolveSlot(const RenderParams &p, int pslot, size_t &pix) {
+    if (pslot >= p.rad_stride) return false;
+    const int owned = pslot >> 10, sub = (pslot >> 6) & 15, l = pslot & 63;
+    const int tile = p.tile_rank + owned * p.tile_world;
+    const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
+    const int row = trow * 32 + (sub >> 2) * 8 + (l >> 3);
+    const int col = tcol * 32 + (sub & 3) * 8 + (l & 7);
+    pix = (size_t) row * p.width + col;
+    return row < p.height && col < p.width;
+}
+JD void resolveStore(const RenderParams &p, size_t pix, f3 acc, int sB) {
+    p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
+    if (p.img) {                                                         // write-through: the host copies previews while the launch runs
+        const float inv = (float) sB;                                    // currSample + 1 of the last pass added (camera.cpp:115)
+        unsigned char *q = p.img + 3 * pix;
+        __hip_atomic_store(q, toByte(acc.x / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, toByte(acc.y / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 2, toByte(acc.z / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderParams p, int num_path_waves, unsigned *started_host, unsigned *progress_host, unsigned epoch) {
-    __shared__ unsigned shDealt, shOldest[RESOLVE_BLOCK / 64];
+    __shared__ unsigned shWord, shOldest[RESOLVE_BLOCK / 64];
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     if (tid == 0) __hip_atomic_store(started_host + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int nchunks = p.num_subblocks * p.num_groups;
-    int done = 0;                                                       // passes this workgroup has added for all its pixels
-    unsigned dealtSeen = 0u;
-    while (true) {
-        // ---- how many passes are complete? ----
-        if (tid == 0) {
-            const unsigned wk = atomicAdd(p.work, 0u);                  // (an atomic: performed where the path waves' fetches are)
-            unsigned dealt;
-            unsigned known = 0x80000000u;                               // bit 31: `dealt` is final once every wave is gone
-            if (wk < 0x40000000u) { dealt = wk < (unsigned) nchunks ? wk : (unsigned) nchunks; if (wk < (unsigned) nchunks) known = 0u; }
-            else {                                                      // closed by a cancellation: the wave that closed it says at what count
-                const unsigned ca = atomicOr(p.prog_closed_at, 0u);
-                if (ca == PROG_NONE) { dealt = dealtSeen; known = 0u; } else dealt = ca < (unsigned) nchunks ? ca : (unsigned) nchunks;
+    unsigned *leaderWord = p.prog_leader;
+    if (wg == 0 && nwg > 1) {
+        // ---- the leader: how many passes are complete?  (One workgroup watches the path waves, the others watch its word.) ----
+        unsigned dealtSeen = 0u, published = 0u;
+        if (tid == 0) __hip_atomic_store(progress_host + wg, (epoch << 16) | (unsigned) p.num_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (no pixels of its own: never the minimum)
+        while (true) {
+            if (tid == 0) {
+                const unsigned wk = atomicAdd(p.work, 0u);               // (one workgroup, once a round: nothing beside the waves' fetches)
+                unsigned dealt, known = RESOLVE_LAST;                    // bit 31: `dealt` is final once every wave is gone
+                if (wk < 0x40000000u) { dealt = wk < (unsigned) nchunks ? wk : (unsigned) nchunks; if (wk < (unsigned) nchunks) known = 0u; }
+                else {                                                  // closed by a cancellation: the wave that closed it says at what count
+                    const unsigned ca = atomicOr(p.prog_closed_at, 0u);
+                    if (ca == PROG_NONE) { dealt = dealtSeen; known = 0u; } else dealt = ca < (unsigned) nchunks ? ca : (unsigned) nchunks;
+                }
+                shWord = dealt | known;
             }
-            shDealt = dealt | known;
+            __syncthreads();
+            const unsigned dealt = shWord & ~RESOLVE_LAST;
+            const bool dealtFinal = (shWord & RESOLVE_LAST) != 0u;
+            dealtSeen = dealt;
+            unsigned m = PROG_NONE;
+            // the words as they are in memory NOW: atomics.  (sc1 loads were served from this XCD's L2 for ~9 ms after a wave on another XCD
+            // had rewritten a word -- a stale word is a smaller one, so nothing was wrong, but every preview came three passes late.)
+            for (int i = tid; i < num_path_waves; i += RESOLVE_BLOCK) { const unsigned v = atomicOr(p.prog_slots + i, 0u); m = v < m ? v : m; }
+            for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(m, off, 64); m = o < m ? o : m; }
+            if ((tid & 63) == 0) shOldest[tid >> 6] = m;
+            __syncthreads();
+            unsigned oldest = shOldest[0];
+            for (int i = 1; i < RESOLVE_BLOCK / 64; ++i) oldest = shOldest[i] < oldest ? shOldest[i] : oldest;
+            __syncthreads();                                            // (shWord / shOldest are rewritten in the next round)
+            const bool allGone = oldest == PROG_NONE;
+            int complete = (int) (dealt / (unsigned) p.num_subblocks);
+            if (!allGone) { const int byWaves = (int) oldest > p.sample_begin ? ((int) oldest - p.sample_begin) / p.strata_per_group : 0; complete = byWaves < complete ? byWaves : complete; }
+            if (complete >= p.num_groups) complete = p.num_groups;
+            else complete = complete / p.prog_groups_per_pass * p.prog_groups_per_pass;    // whole passes only (a cancellation may end the launch inside one)
+            const bool last = allGone && dealtFinal;
+            const unsigned word = (unsigned) complete | (last ? RESOLVE_LAST : 0u);
+            if (word != published) {
+                if (tid == 0) atomicExch(leaderWord, word);
+#ifdef JTX_DBG_PROG
+                if (tid == 0) { unsigned *lg = leaderWord + 16; const unsigned i = lg[0]; if (i < 14) { lg[1 + 3 * i] = (unsigned) (__builtin_amdgcn_s_memrealtime() / 100); lg[2 + 3 * i] = dealt / (unsigned) p.num_subblocks; lg[3 + 3 * i] = allGone ? 9999u : (oldest - p.sample_begin) / p.strata_per_group; lg[0] = i + 1; } }
+#endif
+                published = word;
+            }
+            if (last) break;
+            __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);      // ~15 us a round: a few hundred rounds per pass of C2
         }
+        return;
+    }
+    // ---- the workers: passes [done, complete) into the film of this workgroup's pixels ----
+    const int nworkers = nwg > 1 ? nwg - 1 : 1, me = nwg > 1 ? wg - 1 : 0;
+    int done = 0;                                                       // passes this workgroup has added for all its pixels
+    while (true) {
+        // (an atomic: the word as it is in memory now -- on a cache line of its own, never the chunk counter's)
+        if (tid == 0) shWord = atomicOr(leaderWord, 0u);
         __syncthreads();
-        const unsigned dealtWord = shDealt;
-        const unsigned dealt = dealtWord & 0x7fffffffu;
-        const bool dealtFinal = (dealtWord & 0x80000000u) != 0u;
-        dealtSeen = dealt;
-        unsigned m = PROG_NONE;
-        for (int i = tid; i < num_path_waves; i += RESOLVE_BLOCK) {
-            const unsigned v = __hip_atomic_load(p.prog_slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m = v < m ? v : m;
-        }
-        for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(m, off, 64); m = o < m ? o : m; }
-        if ((tid & 63) == 0) shOldest[tid >> 6] = m;
+        const unsigned word = shWord;
         __syncthreads();
-        unsigned oldest = shOldest[0];
-        for (int i = 1; i < RESOLVE_BLOCK / 64; ++i) oldest = shOldest[i] < oldest ? shOldest[i] : oldest;
-        __syncthreads();                                                // (shDealt / shOldest are rewritten in the next round)
-        const bool allGone = oldest == PROG_NONE;
-        int complete = (int) (dealt / (unsigned) p.num_subblocks);
-        if (!allGone) { const int byWaves = ((int) oldest - p.sample_begin) / p.strata_per_group; complete = byWaves < complete ? byWaves : complete; }
-        if (complete > p.num_groups) complete = p.num_groups;
-        // the last round: every chunk is dealt (or the counter is closed and says how many were) and no wave holds a path
-        const bool last = allGone && dealtFinal;
+        const int complete = (int) (word & ~RESOLVE_LAST);
         if (complete > done) {
-            // ---- passes [done, complete) into the film of this workgroup's pixels ----
             const int sA = p.sample_begin + done * p.strata_per_group;
             int sB = p.sample_begin + complete * p.strata_per_group; if (sB > p.sample_end) sB = p.sample_end;
-            for (int pslot = wg * RESOLVE_BLOCK + tid; pslot < p.rad_stride; pslot += nwg * RESOLVE_BLOCK) {
-                const int owned = pslot >> 10, sub = (pslot >> 6) & 15, l = pslot & 63;
-                const int tile = p.tile_rank + owned * p.tile_world;
-                const int trow = tile / p.tiles_x, tcol = tile - trow * p.tiles_x;
-                const int row = trow * 32 + (sub >> 2) * 8 + (l >> 3);
-                const int col = tcol * 32 + (sub & 3) * 8 + (l & 7);
-                if (row >= p.height || col >= p.width) continue;
-                const size_t pix = (size_t) row * p.width + col;
-                f3 acc = mk3(0.0f);
-                if (sA > 0) acc = mk3(p.acc[3 * pix], p.acc[3 * pix + 1], p.acc[3 * pix + 2]);
-                const float4 *r = p.rad + ((size_t) (sA - p.sample_begin) * p.rad_stride + pslot);
+            // two pixels per round and thread, the loads of both in flight together; the sums in sample order (image.hpp:82-86)
+            for (int pslot = me * RESOLVE_BLOCK + tid; pslot < p.rad_stride; pslot += 2 * nworkers * RESOLVE_BLOCK) {
+                size_t pixA = 0, pixB = 0;
+                const int pslotB = pslot + nworkers * RESOLVE_BLOCK;
+                const bool inA = resolveSlot(p, pslot, pixA), inB = resolveSlot(p, pslotB, pixB);
+                f3 accA = mk3(0.0f), accB = mk3(0.0f);
+                if (sA > 0) {
+                    if (inA) accA = mk3(p.acc[3 * pixA], p.acc[3 * pixA + 1], p.acc[3 * pixA + 2]);
+                    if (inB) accB = mk3(p.acc[3 * pixB], p.acc[3 * pixB + 1], p.acc[3 * pixB + 2]);
+                }
+                // (slots of the padding are loaded too: the buffer has them; slot B of the last round may lie behind it: the first slot then)
+                const float4 *rA = p.rad + ((size_t) (sA - p.sample_begin) * p.rad_stride + pslot);
+                const float4 *rB = p.rad + ((size_t) (sA - p.sample_begin) * p.rad_stride + (pslotB < p.rad_stride ? pslotB : pslot));
                 int s = sA;
-                for (; s + 4 <= sB; s += 4, r += (size_t) 4 * p.rad_stride) {             // four loads in flight, the sums in sample order
-                    u32x4 c0, c1, c2, c3;
+                for (; s + 2 <= sB; s += 2, rA += (size_t) 2 * p.rad_stride, rB += (size_t) 2 * p.rad_stride) {
+                    u32x4 a0, a1, b0, b1;
                     asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
                                  "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
-                                 : "v"(r), "v"(r + p.rad_stride), "v"(r + (size_t) 2 * p.rad_stride), "v"(r + (size_t) 3 * p.rad_stride) : "memory");
-                    acc = acc + mk3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
-                    acc = acc + mk3(__uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z));
-                    acc = acc + mk3(__uint_as_float(c2.x), __uint_as_float(c2.y), __uint_as_float(c2.z));
-                    acc = acc + mk3(__uint_as_float(c3.x), __uint_as_float(c3.y), __uint_as_float(c3.z));
+                                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+                                 : "v"(rA), "v"(rA + p.rad_stride), "v"(rB), "v"(rB + p.rad_stride) : "memory");
+                    accA = accA + mk3(__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z));
+                    accA = accA + mk3(__uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z));
+                    accB = accB + mk3(__uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z));
+                    accB = accB + mk3(__uint_as_float(b1.x), __uint_as_float(b1.y), __uint_as_float(b1.z));
                 }
-                for (; s < sB; ++s, r += p.rad_stride) {
-                    u32x4 c0;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(c0) : "v"(r) : "memory");
-                    acc = acc + mk3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z));
+                for (; s < sB; ++s, rA += p.rad_stride, rB += p.rad_stride) {
+                    u32x4 a0, b0;
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(a0), "=&v"(b0) : "v"(rA), "v"(rB) : "memory");
+                    accA = accA + mk3(__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z));
+                    accB = accB + mk3(__uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z));
                 }
-                p.acc[3 * pix] = acc.x; p.acc[3 * pix + 1] = acc.y; p.acc[3 * pix + 2] = acc.z;
-                if (p.img) {                                             // write-through: the host copies previews while the launch runs
-                    const float inv = (float) sB;                        // currSample + 1 of the last pass added (camera.cpp:115)
-                    unsigned char *q = p.img + 3 * pix;
-                    __hip_atomic_store(q, toByte(acc.x / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(q + 1, toByte(acc.y / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(q + 2, toByte(acc.z / inv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (inA) resolveStore(p, pixA, accA, sB);
+                if (inB) resolveStore(p, pixB, accB, sB);
             }
             done = complete;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                            // every pixel of the workgroup: then the host may hear of it
             if (tid == 0) __hip_atomic_store(progress_host + wg, (epoch << 16) | (unsigned) done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if (last) break;
-        else __builtin_amdgcn_s_sleep(32);
+        } else if (word & RESOLVE_LAST) break;
+        else __builtin_amdgcn_s_sleep(127);
     }
 }
 } // namespace jtx

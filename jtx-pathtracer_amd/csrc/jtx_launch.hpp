@@ -46,6 +46,8 @@ struct RenderParams {
     // cancellation the number of chunks that were dealt (the counter's value when it was closed), else 0xffffffff.
     unsigned *prog_slots;
     unsigned *prog_closed_at;
+    unsigned *prog_leader;         // the resolver's own: complete passes | bit 31 when final, from its watching workgroup to the others
+    int prog_groups_per_pass;      // the resolver adds whole passes only: strata groups in multiples of this (1 unless a long pass is cut into several groups)
 };
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
@@ -129,12 +131,13 @@ hipError_t jtx_wf_resolve(const jtx::WfParams &p, int s0, int nstrata, int write
 
 hipError_t jtx_launch_render_pixels(const jtx::RenderParams &p, int num_owned_tiles, bool count, hipStream_t stream);
 hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_tiles, int num_cus, hipStream_t stream, int share = 1, bool progressive = false,
-                                   int leave_workgroups = 0);
+                                   int leave_waves = 0);
+int jtx_resolve_progressive_waves(int num_workgroups);    // wave slots the resolver takes
 // the resolver of a progressive launch (beside k_render_paths<.., PROG>, on a stream of its own): num_path_waves words in p.prog_slots; every workgroup
 // writes its word of started_host when it runs and of progress_host (epoch << 16 | groups in the film of its pixels) as it goes
 hipError_t jtx_launch_resolve_progressive(const jtx::RenderParams &p, int num_owned_tiles, int num_path_waves, int num_workgroups, unsigned *started_host,
                                           unsigned *progress_host, unsigned epoch, hipStream_t stream);
-int jtx_render_paths_waves(const jtx::RenderParams &p, int num_cus, int share, int leave_workgroups);   // waves jtx_launch_render_paths starts for p
+int jtx_render_paths_waves(const jtx::RenderParams &p, int num_cus, int share, int leave_waves);   // waves jtx_launch_render_paths starts for p
 int jtx_render_paths_grid(const jtx::DevScene &sc, int num_cus, int *block_size);   // workgroups the persistent grid holds (host only)
 hipError_t jtx_launch_render_alt(const jtx::RenderParams &p, int num_owned_tiles, bool count, int li, hipStream_t stream);
 hipError_t jtx_launch_radiance_samples_alt(const jtx::DevScene &sc, const jtx::DCam &cam, int maxDepth, int li, int n, const int *row,

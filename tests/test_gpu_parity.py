@@ -1996,7 +1996,7 @@ def test_cancellation_with_passes_in_flight_leaves_a_prefix_of_the_strata(gpu, m
     24-pass render, one stratum per pass, plus one from the callback."""
     import threading, time
     data, sc, osc = mixed_pair
-    W, H = 480, 270
+    W, H = 1280, 720                                                          # (one launch for all 24 passes takes ~10 ms at this size: room for the timers)
     refs = {}
 
     def ref(n):
@@ -2007,12 +2007,14 @@ def test_cancellation_with_passes_in_flight_leaves_a_prefix_of_the_strata(gpu, m
             refs[n] = (c.acc_.copy(), c.img_.copy())
         return refs[n]
     full = gpu.StaticCamera(W, H, data.camera, 6, 4, 6); full.samplesPerPass_ = 1
+    full.render(sc, progress=lambda c, t: None)                               # (page-locks its film, loads the kernels)
     t0 = time.perf_counter(); full.render(sc, progress=lambda c, t: None); t_full = time.perf_counter() - t0
     assert full.currentSample_ == 24
     assert_same_f32(full.acc_, ref(24)[0], "24 passes, one launch")
     seen = set()
     for k in range(12):
         cam = gpu.StaticCamera(W, H, data.camera, 6, 4, 6); cam.samplesPerPass_ = 1
+        cam._pin()                                                            # (before the clock runs)
         timer = threading.Timer(t_full * (0.05 + 0.08 * k), cam.terminateRender)
         timer.start(); cam.render(sc, progress=lambda c, t: None); timer.join()
         n = cam.currentSample_
@@ -2027,6 +2029,58 @@ def test_cancellation_with_passes_in_flight_leaves_a_prefix_of_the_strata(gpu, m
     n = cam.currentSample_
     assert 5 <= n <= 24                                                       # (the launch does not wait for the callback: passes behind the 5th may be in)
     assert_same_f32(cam.acc_, ref(n)[0], f"film after a callback cancel at 5 that left {n} strata")
+
+
+def test_progressive_launch_of_a_tile_shard_with_previews(gpu, cornell_pair):
+    """a tile-sharded progressive render (tile_world = 3, one stratum per pass, a callback) must deliver exact zeros in the tiles
+    it does not own -- in every preview and in the final image -- and its own tiles bit for bit (round 5's three preview buffers came
+    uninitialised from hipMalloc; round 6 renders all passes in one launch into ONE preview buffer, cleared per call).  Also: an odd pass
+    size that does not divide the strata, and the per-pass loop (JTX_PROGRESSIVE_LAUNCH=0 semantics are covered by the counted renders)."""
+    data, sc, osc = cornell_pair
+    W, H = 200, 120
+    whole = gpu.StaticCamera(W, H, data.camera, 4, 3, 4); whole.render(sc)
+    owner = (np.arange(H)[:, None] // 32) * ((W + 31) // 32) + np.arange(W)[None, :] // 32
+    for rank in range(3):
+        mine = (owner % 3) == rank
+        cam = gpu.StaticCamera(W, H, data.camera, 4, 3, 4); cam.samplesPerPass_ = 1
+        previews = []
+        cam.render(sc, tile_rank=rank, tile_world=3, progress=lambda c, t: previews.append((c, cam.img_.copy())))
+        assert [c for c, _ in previews] == list(range(1, 13))
+        for c, img in previews:
+            assert not img[~mine].any(), f"preview {c} of shard {rank}: bytes in tiles it does not own"
+        assert not cam.img_[~mine].any() and not cam.acc_[~mine].any()
+        assert_same_f32(cam.acc_[mine], whole.acc_[mine], f"shard {rank} of 3, progressive")
+        assert (cam.img_[mine] == whole.img_[mine]).all()
+    odd = gpu.StaticCamera(W, H, data.camera, 4, 3, 4); odd.samplesPerPass_ = 5
+    seen = []
+    odd.render(sc, progress=lambda c, t: seen.append(c))
+    assert seen == [5, 10, 12]
+    assert_same_f32(odd.acc_, whole.acc_, "passes of 5 strata, the last one shorter"); assert (odd.img_ == whole.img_).all()
+
+
+def test_frame_slot_memory_is_accounted_and_can_be_released(gpu, cornell_pair):
+    """VERDICT r5 missing 5: the frame slots' working memory (the per-path radiance records of the persistent path kernel) is reported
+    (scene_info.frame_slot_bytes, not part of device_bytes), capped per launch by opts.max_record_mb, and given back by
+    jtx_mi_scene_release_frames; the next render allocates it again and gives the same film."""
+    data, _, osc = cornell_pair
+    sc = gpu.Scene(data); sc.buildBVH()
+    assert sc.info()["frame_slot_bytes"] == 0
+    cam = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); cam.render(sc)
+    held = sc.info()["frame_slot_bytes"]
+    tiles = ((320 + 31) // 32) * ((200 + 31) // 32)
+    assert held >= tiles * 1024 * 16 * 16                                    # 16 strata x the owned pixel slots x 16 B
+    ref = cam.acc_.copy()
+    sc.releaseFrames()
+    assert sc.info()["frame_slot_bytes"] == 0
+    cam.render(sc)
+    assert_same_f32(cam.acc_, ref, "frame after release_frames")
+    assert sc.info()["frame_slot_bytes"] >= tiles * 1024 * 16 * 16
+    # the cap as a field of the options: 1 MB holds 0.9 strata of this frame -> one stratum per launch, the same film
+    sc.releaseFrames()
+    capped = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); capped.render(sc, max_record_mb=2)
+    assert_same_f32(capped.acc_, ref, "frame under a 2 MB record cap")
+    assert sc.info()["frame_slot_bytes"] <= (2 << 20) + 65536
+    sc.destroy()
 
 
 def test_headline_frame_against_the_oracle_in_every_pixel(gpu, cornell_pair):
