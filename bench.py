@@ -2,9 +2,10 @@
 """bench.py -- Mrays/s of the JTX path-tracing hot path on MI355X (BASELINE.json metric).
 
 A "step" is one whole frame of the workload: BASELINE config 2, Cornell box 1920x1080, 64 spp (8x8
-strata), maxDepth 8, through jtx_mi_render_device (scene already resident in HBM).  With N > 1
-ranks the frame's 32x32 pixel tiles are interleaved over the ranks and one RCCL reduce per frame
-sums the disjoint shards onto rank 0 (strong scaling: the frame is fixed).
+strata), maxDepth 8, through jtx_mi_render_device (scene already resident in HBM), three frames in flight,
+EVERY FILM DELIVERED TO THE HOST (acc + img in page-locked memory: SURVEY 8d's "last byte on the host"; round 6).
+With N > 1 ranks the frame's 32x32 pixel tiles are interleaved over the ranks and one RCCL exchange per frame
+brings the disjoint shards to rank 0, which delivers the assembled frame (strong scaling: the frame is fixed).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -107,7 +108,8 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup, int
         img = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
         if integrator is None:
             integrator = scene.info()["auto_integrator"]
-        pipe = jtx.distributed.ShardPipeline(scene, cam, 0, 1, dev, None, integrator=integrator, frames_in_flight=frames_in_flight())
+        pipe = jtx.distributed.ShardPipeline(scene, cam, 0, 1, dev, None, integrator=integrator, frames_in_flight=frames_in_flight(),
+                                             deliver_to_host=True)
 
         def frame(count=False, last=False):
             if count:
@@ -134,7 +136,7 @@ def time_workload(jtx, torch, dev, tstream, name, data, dims, steps, warmup, int
         kernel_ms = serial_kernel_ms(jtx, torch, lib, scene, cam, 0, 1, dev, integrator, frames=min(3, steps))
         info = scene.info()
         out = {"ms_per_step": round(elapsed / steps * 1e3, 3), "kernel_ms": round(kernel_ms, 4), "steps": steps, "warmup": warmup,
-               "frames_in_flight": len(pipe.rstreams),
+               "frames_in_flight": len(pipe.rstreams), "timed_region": "film delivered to host",
                "value": round(rays * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "rays_per_frame": rays,
                "scene_triangles": data.num_triangles, "integrator": integrator}
         if integrator == 1:
@@ -548,7 +550,50 @@ def self_launch(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")                # (what torchrun would set, without its warning on stderr)
-    return subprocess.run(cmd, env=env).returncode
+    # every rank leaves a note (rank, device, how far it came) in this directory: if the ranks fail, the ONE JSON line this parent prints
+    # says how many of them were seen and on which devices, not only "rc != 0" (a driver-run record diagnoses itself)
+    import tempfile
+    diag = tempfile.mkdtemp(prefix="jtx_bench_ranks_")
+    env["JTX_BENCH_DIAG_DIR"] = diag
+    proc = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True)
+    tail = []
+    for line in proc.stderr:                              # relayed as it comes; the end of it kept for the record
+        sys.stderr.write(line); sys.stderr.flush()
+        tail.append(line); del tail[:-40]
+    rc = proc.wait()
+    if rc != 0:
+        print(json.dumps(rank_failure_record(n, rc, diag, "".join(tail))), flush=True)
+    import shutil
+    shutil.rmtree(diag, ignore_errors=True)
+    return rc
+
+
+def rank_note(stage, **kw):
+    """(a rank of a self-launched run) where this rank is: one small file per rank in JTX_BENCH_DIAG_DIR, rewritten at every stage"""
+    d = os.environ.get("JTX_BENCH_DIAG_DIR")
+    if not d:
+        return
+    try:
+        rank = int(os.environ.get("RANK", "0"))
+        with open(os.path.join(d, f"rank{rank}.json"), "w") as f:
+            json.dump(dict(rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")), pid=os.getpid(), stage=stage, **kw), f)
+    except OSError:
+        pass
+
+
+def rank_failure_record(n, rc, diag_dir, stderr_tail):
+    """the line a failed `bench.py --gpus N` prints instead of a measurement"""
+    import glob
+    ranks = []
+    for f in sorted(glob.glob(os.path.join(diag_dir, "rank*.json"))):
+        try:
+            ranks.append(json.load(open(f)))
+        except (OSError, ValueError):
+            pass
+    return {"metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline", "value": None, "unit": "Mrays/s", "n_gpus": n,
+            "error": f"the {n} ranks started by bench.py exited with code {rc}", "returncode": rc,
+            "nranks_seen": len(ranks), "ranks": sorted(ranks, key=lambda r: r.get("rank", 0)),
+            "stderr_tail": stderr_tail[-2000:]}
 
 
 def main():
@@ -594,8 +639,10 @@ def main():
     backend = os.environ.get("JTX_DIST_BACKEND", "nccl")
     if os.environ.get("JTX_ALL_RANKS_ON_DEVICE") is not None:
         local_rank = int(os.environ["JTX_ALL_RANKS_ON_DEVICE"])
+    rank_note("started", devices_visible=torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rank_note("device set", device=local_rank, devices_visible=torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -603,6 +650,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     jtx._capi.check(jtx._capi.load().jtx_mi_set_device(local_rank))
+    rank_note("process group up", device=local_rank, backend=backend if world > 1 else None)
 
     wl_name, data, (W, H, xs, ys, depth) = load_workload(jtx, args.workload, args.atrium_tris, args.scene, args.camera)
     t0 = time.perf_counter()
@@ -637,7 +685,7 @@ def main():
     pipe = None
     if (gatherer is not None and os.environ.get("JTX_PIPELINE_EXCHANGE", "1") != "0") or (world == 1 and frames_in_flight() > 1):
         pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, gatherer, integrator=integrator, timing=world > 1,
-                                             frames_in_flight=frames_in_flight())
+                                             frames_in_flight=frames_in_flight(), deliver_to_host=True)
 
     xtimed = []                                              # serial exchange: (event before, event after) per frame, on the render stream
 
@@ -717,6 +765,13 @@ def main():
         step(last=(i == args.steps - 1))
     fence()
     elapsed = time.perf_counter() - t
+    rank_note("timed region done", device=local_rank, steps=args.steps)
+    delivered = pipe is not None and getattr(pipe, "deliver", False)
+    if delivered:                                            # the copies arrived: the last frame, word for word
+        nbuf = len(pipe.accs); lastb = (pipe.n - 1) % nbuf
+        src_acc, src_img = (pipe.accs[lastb], pipe.imgs[lastb]) if pipe.gatherer is None else (pipe.frame_acc, pipe.frame_img)
+        if not (torch.equal(pipe.host_acc[lastb], src_acc.cpu()) and torch.equal(pipe.host_img[lastb], src_img.cpu())):
+            raise SystemExit("bench: the host copy of the last frame differs from the device film")
     jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
     kernel_ms_timed = ms.value / max(1, nl.value)          # launches of the timed region: start-to-end, overlapping when frames are in flight
     in_flight = len(pipe.rstreams) if pipe is not None else 1
@@ -748,58 +803,60 @@ def main():
                                  "exchange_ms": None if r[4] < 0 else round(float(r[4]), 4)}
                                 for r in (x.tolist() for x in rows)]}
 
-    # N = 1: the same frames DELIVERED TO HOST buffers (jtx_mi_render: SURVEY 8d's wall time, first launch to last byte of
-    # acc / img on the host), reported beside the HBM-resident figure (never as `value`)
-    host_ms = host_pipe_ms = None
+    # N = 1, beside the headline: (a) the same loop WITHOUT the host copies (round 5's timed region: film buffers resident in HBM); (b) the same
+    # frame through the blocking jtx_mi_render (the reference's API shape: Camera::render returns with the film on the host; one frame at
+    # a time); (c) the frame as the reference's UI renders it -- a callback after every pass of samplesPerPass_ strata (camera.hpp:181:
+    # the default is 1) -- through jtx_mi_render's progressive launch
+    device_ms = host_ms = None
+    progressive = {}
     if world == 1:
         import numpy as np
+        if integrator == 1 and pipe is not None:
+            dpipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, None, integrator=integrator, frames_in_flight=frames_in_flight())
+            nd = max(1, min(args.steps, 10))
+            for _ in range(len(dpipe.accs)):
+                dpipe.step()
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for i in range(nd):
+                dpipe.step(last=(i == nd - 1))
+            torch.cuda.synchronize()
+            device_ms = (time.perf_counter() - td) / nd * 1e3
+            del dpipe
         hacc = np.zeros(H * W * 3, np.float32); himg = np.zeros(H * W * 3, np.uint8)
         for a in (hacc, himg):                        # page-locked like Camera::acc_ / img_ in the host mirrors (jtx_mi_pin_host)
             lib.jtx_mi_pin_host(a.ctypes.data_as(C.c_void_p), a.nbytes)
         o = jtx._capi.RenderOpts(); o.integrator = integrator
-        def host_frame():
+
+        def host_frame(cb=jtx._capi.PROGRESS_CB(0)):
             jtx._capi.check(lib.jtx_mi_render(scene.handle, C.byref(cam), C.byref(o), hacc.ctypes.data_as(C.POINTER(C.c_float)),
-                                              himg.ctypes.data_as(C.POINTER(C.c_uint8)), jtx._capi.PROGRESS_CB(0), None))
+                                              himg.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None))
         host_frame()
         th = time.perf_counter()
         nh = max(1, min(args.steps, 5))
         for _ in range(nh):
             host_frame()
         host_ms = (time.perf_counter() - th) / nh * 1e3
+        if integrator == 1 and not args.headline_only:
+            ncb = [0]
+            cbf = jtx._capi.PROGRESS_CB(lambda cur, tot, user: (ncb.__setitem__(0, ncb[0] + 1), 0)[1])
+            for spp_pass in (1, 8):
+                o.samples_per_tick = spp_pass
+                host_frame(cbf)
+                ncb[0] = 0
+                th = time.perf_counter()
+                for _ in range(nh):
+                    host_frame(cbf)
+                pms = (time.perf_counter() - th) / nh * 1e3
+                progressive[f"{wl_name}@spp_per_pass_{spp_pass}"] = {
+                    "ms_per_step": round(pms, 3), "value": round(rays_frame / pms / 1e3, 2), "unit": "Mrays/s", "steps": nh,
+                    "samples_per_pass": spp_pass, "callbacks_per_frame": ncb[0] // nh, "rays_per_frame": rays_frame,
+                    "timed_region": "jtx_mi_render with a callback per pass: one launch for all passes, a resolver kernel beside it; the preview "
+                                    "and, at the end, the film delivered to page-locked host buffers"}
+            o.samples_per_tick = 0
         for a in (hacc, himg):
             lib.jtx_mi_unpin_host(a.ctypes.data_as(C.c_void_p))
         jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))     # drop those events
-        # ... and what a host that keeps frames IN FLIGHT gets (the blocking call above is the reference's API shape: Camera::render returns
-        # with the film on the host): the pipelined loop of the timed region with every frame's film and image copied to page-locked host
-        # buffers on a copy stream, a frame slot reused only when its copy is done -- PCIe-inclusive, never `value` either
-        if pipe is not None and len(pipe.rstreams) > 1:
-            nb = len(pipe.accs)
-            pacc = [torch.empty(H * W * 3, dtype=torch.float32, pin_memory=True) for _ in range(nb)]
-            pimg = [torch.empty(H * W * 3, dtype=torch.uint8, pin_memory=True) for _ in range(nb)]
-            cstream = torch.cuda.Stream(device=dev)
-            copied = [torch.cuda.Event() for _ in range(nb)]
-
-            def host_pipe_frame(last):
-                bslot = pipe.n % nb
-                pipe.rstreams[bslot % len(pipe.rstreams)].wait_event(copied[bslot])     # the slot's previous frame has left for the host
-                pipe.step(last=last)
-                cstream.wait_event(pipe.rendered[bslot])
-                with torch.cuda.stream(cstream):
-                    pacc[bslot].copy_(pipe.accs[bslot], non_blocking=True)
-                    pimg[bslot].copy_(pipe.imgs[bslot], non_blocking=True)
-                    copied[bslot].record(cstream)
-            for _ in range(nb):
-                host_pipe_frame(False)
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            for i in range(args.steps):
-                host_pipe_frame(i == args.steps - 1)
-            torch.cuda.synchronize()
-            host_pipe_ms = (time.perf_counter() - th) / args.steps * 1e3
-            last_slot = (pipe.n - 1) % nb                                               # the copies arrived: the last frame, word for word
-            if not (torch.equal(pacc[last_slot], pipe.accs[last_slot].cpu()) and torch.equal(pimg[last_slot], pipe.imgs[last_slot].cpu())):
-                raise SystemExit("bench: the pipelined host copy of the last frame differs from the device film")
-            jtx._capi.check(lib.jtx_mi_kernel_time(scene.handle, C.byref(ms), C.byref(nl)))
 
     if rank == 0:
         value = rays_frame * args.steps / elapsed / 1e6
@@ -815,9 +872,24 @@ def main():
             kernel_name = names[dom]
             launches_per_frame = max(1, kind_ms[dom][1])
             kernel_ms = kind_ms[dom][0] / launches_per_frame          # average launch duration of that kernel
-        roof = roofline_block(wl_name if world == 1 else wl_name + f"@{world}", sinfo, roof_counters, kernel_name,
-                              kernel_ms, launches_per_frame, info["num_cus"])
-        if in_flight > 1 and integrator == 1:
+        key = wl_name if world == 1 else wl_name + f"@{world}"
+        roof = roofline_block(key, sinfo, roof_counters, kernel_name, kernel_ms, launches_per_frame, info["num_cus"])
+        if in_flight > 1 and integrator == 1 and world == 1:
+            # ONE self-consistent pair: `value` and the roofline on the SAME time -- the wall time per frame of the timed
+            # region (frames in flight: a frame's share of the chip; kernel_ms <= ms_per_step by construction).  The figures of a LONE launch
+            # (HIP events, one frame in flight: what the committed rocprofv3 kernel statistics show) ride under `lone`.
+            lone = roof
+            roof = roofline_block(key, sinfo, roof_counters, kernel_name, elapsed / args.steps * 1e3, launches_per_frame, info["num_cus"])
+            roof["time_basis"] = ("wall time per frame of the timed region: %d frames in flight, every film delivered to the host -- the chip runs nothing "
+                                  "but these frames, so a frame's share of it is the time between two frames" % in_flight)
+            roof["frames_in_flight"] = in_flight
+            roof["launch_ms_start_to_end"] = round(kernel_ms_timed, 3)
+            roof["lone"] = {k: lone[k] for k in ("kernel_ms", "frac", "achieved", "useful_frac", "useful_frac_attainable", "issue_model", "wait_share",
+                                                 "vector_memory", "lane_util", "fp32_lane_frac") if k in lone}
+            roof["lone"]["hbm_measured_frac"] = lone["hbm"].get("measured_frac")
+            roof["lone"]["note"] = ("the same numerators over the average duration of a launch with ONE frame in flight (HIP events on the launch stream; "
+                                    "`JTX_FRAMES_IN_FLIGHT=1 bench.py` times these, profiles/ holds their rocprofv3 statistics)")
+        elif in_flight > 1 and integrator == 1:
             roof["in_flight"] = in_flight_block(roof, in_flight, elapsed / args.steps * 1e3, kernel_ms_timed)
         out = {
             "metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline",
@@ -833,17 +905,18 @@ def main():
                        "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": info["lds_resident"],
                        "wide_bvh_bytes": info["wide_bytes"],
                        "frames_in_flight": in_flight,
-                       "timed_region": "frames rendered into HBM-resident film buffers (jtx_mi_render_device), incl. the resolve pass"},
+                       "timed_region": ("frames in flight; every film (accumulation buffer + RGB8 image) delivered to page-locked host memory"
+                                        if delivered else "frames rendered into HBM-resident film buffers (jtx_mi_render_device), incl. the resolve pass")},
             "roofline": roof,
         }
         if ranks_diag is not None:
             out["ranks"] = ranks_diag
+        if device_ms is not None:
+            out["ms_per_step_device"] = round(device_ms, 3)                 # the same loop, films left in HBM (round 5's timed region)
+            out["value_device"] = round(rays_frame / device_ms / 1e3, 2)
         if host_ms is not None:
-            out["ms_per_step_host"] = round(host_ms, 3)
-            out["value_host"] = round(rays_frame / host_ms / 1e3, 2)        # Mrays/s with the film delivered to host memory (PCIe-inclusive)
-            if host_pipe_ms is not None:
-                out["ms_per_step_host_pipelined"] = round(host_pipe_ms, 3)  # frames in flight, every film copied to page-locked host memory
-                out["value_host_pipelined"] = round(rays_frame / host_pipe_ms / 1e3, 2)
+            out["ms_per_step_host_blocking"] = round(host_ms, 3)            # jtx_mi_render: one frame at a time, returns with the film on the host
+            out["value_host_blocking"] = round(rays_frame / host_ms / 1e3, 2)
         if world == 1 and not args.headline_only and args.scene is None:
             # the other BASELINE.json workloads, a few frames each (C3 / C5 / C1 belong in the driver-written record);
             # outside `value`, `steps`, `ms_per_step`, which stay the headline's
@@ -874,6 +947,15 @@ def main():
                         os.environ.pop("JTX_WF_SORT_SHADE", None)
                     else:
                         os.environ["JTX_WF_SORT_SHADE"] = prev
+            for wfname, steps_wf in (("cornell_1920x1080_64spp_d8", 5), ("atrium_1920x1080_64spp_d8", 2)):      # (current figures)
+                try:
+                    n2, d2, dims2 = load_workload(jtx, wfname, args.atrium_tris)
+                    e = time_workload(jtx, torch, dev, tstream, n2, d2, dims2, steps_wf, 1, integrator=2)
+                    e["integrator_name"] = "hbm-wavefront"
+                    extras[f"{n2}@wavefront"] = e
+                except Exception as e:                    # report, never hide
+                    extras[f"{wfname}@wavefront"] = {"failed": f"{type(e).__name__}: {e}"}
+            extras.update(progressive)
             out["workloads"] = extras
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -40,8 +40,10 @@ def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count
                  sample_begin=0, sample_end=0, integrator=0, profile_kernels=False, frame_slot=0, sequence_end=False):
     """Launch this rank's share of the frame into device tensors `acc` (H*W*3 f32) / `img` (H*W*3 u8).
 
-    Asynchronous on `stream` (an int hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).  `frame_slot` 0 / 1: two frames of
-    one scene may be in flight, one per slot, on two streams and into two pairs of film buffers (jtx_mi.h: jtx_mi_render_opts).
+    Asynchronous on `stream` (an int hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).  `frame_slot` 0 .. FRAME_SLOTS - 1: that
+    many frames of one scene may be in flight, one per slot, each on a stream and into a pair of film buffers of its own (jtx_mi.h:
+    jtx_mi_render_opts).  Launches that use the scene's singletons instead of a slot's working memory -- count_rays, the wavefront
+    integrator, the alternate Li, JTX_DYNAMIC_PATHS=0 -- are ordered against EVERY slot by the library.
     """
     lib = capi.load()
     o = capi.RenderOpts()
@@ -167,7 +169,8 @@ class ShardPipeline:
     of step k is in `accs[k % len(accs)]` / `imgs[k % len(accs)]`.  `timing=True` (or start_timing()) keeps a pair of timing events per frame around
     the exchange for exchange_ms(); off by default -- a long-running loop must not pile up live events nobody reads."""
 
-    def __init__(self, scene, cam_desc, rank, world, device, gatherer=None, integrator=0, timing=False, frames_in_flight=FRAME_SLOTS):
+    def __init__(self, scene, cam_desc, rank, world, device, gatherer=None, integrator=0, timing=False, frames_in_flight=FRAME_SLOTS,
+                 deliver_to_host=False):
         import torch
         self.scene, self.cam, self.rank, self.world, self.integrator = scene, cam_desc, rank, world, integrator
         self.gatherer = gatherer
@@ -187,6 +190,16 @@ class ShardPipeline:
         self.timing = bool(timing)
         self.timed = []                  # (timing only) per frame: (event before, event after) the exchange on the side stream
         self._ms, self._nms = 0.0, 0
+        # deliver_to_host (a frame is done when the last byte of acc / img is on the HOST): every finished frame -- this rank's
+        # film (one rank) or the assembled frame (the gather's destination) -- is copied to page-locked host buffers, one pair per buffer
+        # set, on a copy stream of its own (one rank) or behind the exchange on its stream; a buffer set is rendered into again only when
+        # its copy has left.  Frame k is in host_acc[k % len(host_acc)] / host_img[...] once `copied[...]` has passed.
+        self.deliver = bool(deliver_to_host) and (gatherer is None or on_dst)
+        if self.deliver:
+            self.host_acc = [torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(nb)]
+            self.host_img = [torch.empty(n, dtype=torch.uint8, pin_memory=True) for _ in range(nb)]
+            self.cstream = torch.cuda.Stream(device=device) if gatherer is None else None
+            self.copied = [torch.cuda.Event() for _ in range(nb)]
 
     def prime(self):
         """one untimed frame per frame slot, then a synchronisation: every slot's radiance records (2 GB each for a 1080p x 64 spp frame)
@@ -233,10 +246,18 @@ class ShardPipeline:
         rs = self.rstreams[b % len(self.rstreams)]
         if self.gatherer is not None:
             rs.wait_event(self.exchanged[b])                 # the exchange two frames back has read this pair
+        elif self.deliver:
+            rs.wait_event(self.copied[b])                    # the frame that was in this pair has left for the host
         render_shard(self.scene, self.cam, self.rank, self.world, self.accs[b], self.imgs[b],
                      stream=rs.cuda_stream, integrator=self.integrator, frame_slot=b % len(self.rstreams), sequence_end=last)
         self.rendered[b].record(rs)
         if self.gatherer is None:
+            if self.deliver:
+                self.cstream.wait_event(self.rendered[b])
+                with torch.cuda.stream(self.cstream):
+                    self.host_acc[b].copy_(self.accs[b], non_blocking=True)
+                    self.host_img[b].copy_(self.imgs[b], non_blocking=True)
+                    self.copied[b].record(self.cstream)
             return
         with torch.cuda.stream(self.xstream):
             self.xstream.wait_event(self.rendered[b])
@@ -249,3 +270,7 @@ class ShardPipeline:
                 self.timed.append((t0, t1))
                 self._fold(keep=64)
             self.exchanged[b].record(self.xstream)
+            if self.deliver:                                 # the assembled frame, behind its exchange (the next exchange scatters into the same buffers)
+                self.host_acc[b].copy_(self.frame_acc, non_blocking=True)
+                self.host_img[b].copy_(self.frame_img, non_blocking=True)
+                self.copied[b].record(self.xstream)
