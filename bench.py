@@ -559,7 +559,7 @@ def self_launch(n):
     tail = []
     for line in proc.stderr:                              # relayed as it comes; the end of it kept for the record
         sys.stderr.write(line); sys.stderr.flush()
-        tail.append(line); del tail[:-40]
+        tail.append(line); del tail[:-120]
     rc = proc.wait()
     if rc != 0:
         print(json.dumps(rank_failure_record(n, rc, diag, "".join(tail))), flush=True)
@@ -593,7 +593,7 @@ def rank_failure_record(n, rc, diag_dir, stderr_tail):
     return {"metric": "Mrays/s at 1920x1080x64spp; achieved HBM GB/s vs roofline", "value": None, "unit": "Mrays/s", "n_gpus": n,
             "error": f"the {n} ranks started by bench.py exited with code {rc}", "returncode": rc,
             "nranks_seen": len(ranks), "ranks": sorted(ranks, key=lambda r: r.get("rank", 0)),
-            "stderr_tail": stderr_tail[-2000:]}
+            "stderr_tail": stderr_tail[-8000:]}
 
 
 def main():
@@ -615,7 +615,10 @@ def main():
     # loop falls back to "one kernel at a time" (C2: 27.2 ms per frame against 26.4; profiles/r05_frames_in_flight.md).  Read by the
     # runtime when it initialises, so it has to be set before torch is imported.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # JTX_BENCH_FORCE_DIST=1: the N > 1 code path with whatever N is -- also N = 1: the launcher child, an `nccl` process group of one rank,
+    # the per-frame exchange through RCCL, the rank diagnosis -- the first contact of that path with real RCCL on a one-GPU box
+    force_dist = os.environ.get("JTX_BENCH_FORCE_DIST", "0") not in ("", "0")
+    if (args.gpus > 1 or force_dist) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference needs no launcher either --
         # StaticCamera::render just spawns its workers, camera.cpp:81).  This parent has imported neither torch nor the library and
         # has not touched a GPU: the ranks are a CHILD process (torch.distributed.run), never an exec of a GPU-initialised one; its
@@ -632,6 +635,7 @@ def main():
         if world == 1 and args.gpus > 1:                    # (WORLD_SIZE=1 set by hand with --gpus N)
             raise SystemExit("--gpus N > 1 with WORLD_SIZE=1: unset WORLD_SIZE (bench.py then starts its own ranks) or launch with torch.distributed.run")
         args.gpus = world
+    rank_note("started", devices_visible=torch.cuda.device_count())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU fallback)")
     # JTX_DIST_BACKEND=gloo + JTX_ALL_RANKS_ON_DEVICE=0: rehearsal of the N > 1 code path on a one-GPU box (every
@@ -639,18 +643,18 @@ def main():
     backend = os.environ.get("JTX_DIST_BACKEND", "nccl")
     if os.environ.get("JTX_ALL_RANKS_ON_DEVICE") is not None:
         local_rank = int(os.environ["JTX_ALL_RANKS_ON_DEVICE"])
-    rank_note("started", devices_visible=torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rank_note("device set", device=local_rank, devices_visible=torch.cuda.device_count())
-    if world > 1:
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     jtx._capi.check(jtx._capi.load().jtx_mi_set_device(local_rank))
-    rank_note("process group up", device=local_rank, backend=backend if world > 1 else None)
+    rank_note("process group up", device=local_rank, backend=backend if dist_on else None)
 
     wl_name, data, (W, H, xs, ys, depth) = load_workload(jtx, args.workload, args.atrium_tris, args.scene, args.camera)
     t0 = time.perf_counter()
@@ -676,15 +680,15 @@ def main():
 
     # per-frame exchange: compact own-pixel slabs gathered to rank 0 (default) or one sum-reduce of the full buffers
     collective = os.environ.get("JTX_FRAME_COLLECTIVE", "gather")
-    gatherer = jtx.distributed.FrameGather(W, H, rank, world, dev) if (world > 1 and collective == "gather") else None
+    gatherer = jtx.distributed.FrameGather(W, H, rank, world, dev) if (dist_on and collective == "gather") else None
 
     # N > 1: the exchange of frame i runs on a side stream while frame i + 1 renders into the other pair of shard
     # buffers (rank 0 assembles frames in buffers of their own); every frame is complete before the closing fence
     # ... and, at every N, TWO FRAMES IN FLIGHT: frame i + 1 starts on the other render stream / frame slot while the last chunks and
     # the resolve pass of frame i still run (JTX_FRAMES_IN_FLIGHT=1: one render stream)
     pipe = None
-    if (gatherer is not None and os.environ.get("JTX_PIPELINE_EXCHANGE", "1") != "0") or (world == 1 and frames_in_flight() > 1):
-        pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, gatherer, integrator=integrator, timing=world > 1,
+    if (gatherer is not None and os.environ.get("JTX_PIPELINE_EXCHANGE", "1") != "0") or (not dist_on and frames_in_flight() > 1):
+        pipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, gatherer, integrator=integrator, timing=dist_on,
                                              frames_in_flight=frames_in_flight(), deliver_to_host=True)
 
     xtimed = []                                              # serial exchange: (event before, event after) per frame, on the render stream
@@ -695,20 +699,20 @@ def main():
             return
         jtx.distributed.render_shard(scene, cam, rank, world, acc, img, stream=stream, count_rays=count,
                                      integrator=integrator, profile_kernels=profile)
-        if world > 1:
+        if dist_on:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(tstream)
         if gatherer is not None:
             gatherer.collect(acc, img)
         else:
             jtx.distributed.reduce_frame(acc, img, dst=0)
-        if world > 1:
+        if dist_on:
             e1.record(tstream)
             xtimed.append((e0, e1))
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -736,7 +740,7 @@ def main():
     flat = flat_counters(mine)
     keys = sorted(flat)
     tot = torch.tensor([flat[k] for k in keys], dtype=torch.int64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tot)
     total = unflat_counters(dict(zip(keys, [int(v) for v in tot.tolist()])))
     rays_frame = total["n_closest"] + total["n_any"]
@@ -779,13 +783,13 @@ def main():
     kernel_ms = serial_kernel_ms(jtx, torch, lib, scene, cam, rank, world, dev, integrator, frames=min(3, args.steps)) if (in_flight > 1 and integrator == 1) else kernel_ms_timed
 
     tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
     # self-diagnosis of the first real multi-GPU run: how many ranks took part (an all-reduce of ones), which device each rank
     # rendered on and what its shard kernel took
     ranks_diag = None
-    if world > 1:
+    if dist_on:
         ddev = dev if backend == "nccl" else torch.device("cpu")          # (gloo rehearsals: host tensors)
         ones = torch.ones(1, dtype=torch.int32, device=ddev)
         dist.all_reduce(ones)
@@ -809,7 +813,7 @@ def main():
     # the default is 1) -- through jtx_mi_render's progressive launch
     device_ms = host_ms = None
     progressive = {}
-    if world == 1:
+    if not dist_on:
         import numpy as np
         if integrator == 1 and pipe is not None:
             dpipe = jtx.distributed.ShardPipeline(scene, cam, rank, world, dev, None, integrator=integrator, frames_in_flight=frames_in_flight())
@@ -874,7 +878,7 @@ def main():
             kernel_ms = kind_ms[dom][0] / launches_per_frame          # average launch duration of that kernel
         key = wl_name if world == 1 else wl_name + f"@{world}"
         roof = roofline_block(key, sinfo, roof_counters, kernel_name, kernel_ms, launches_per_frame, info["num_cus"])
-        if in_flight > 1 and integrator == 1 and world == 1:
+        if in_flight > 1 and integrator == 1 and not dist_on:
             # ONE self-consistent pair: `value` and the roofline on the SAME time -- the wall time per frame of the timed
             # region (frames in flight: a frame's share of the chip; kernel_ms <= ms_per_step by construction).  The figures of a LONE launch
             # (HIP events, one frame in flight: what the committed rocprofv3 kernel statistics show) ride under `lone`.
@@ -899,7 +903,7 @@ def main():
             "config": {"workload": wl_name, "scene_triangles": data.num_triangles, "width": W, "height": H,
                        "spp": xs * ys, "max_depth": depth, "rays_per_frame": rays_frame,
                        "rays_per_sample": round(rays_frame / max(1, total["n_camera"]), 4),
-                       "parallelism": (f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if world > 1 else "1 gpu")
+                       "parallelism": (f"pixel-tile shard x{world} + 1 {collective}/frame" + (" overlapped with the next frame" if pipe is not None and gatherer is not None else "") + ("" if backend == "nccl" else f" (REHEARSAL over {backend})") if dist_on else "1 gpu")
                                       + (f", {len(pipe.rstreams)} frames in flight" if pipe is not None and len(pipe.rstreams) > 1 else ""),
                        "scene_upload_ms": round(t_upload * 1e3, 2), "scene_create_warm_ms": warm_create_ms,
                        "integrator": INTEG_NAMES[integrator], "lds_resident_bvh": info["lds_resident"],
@@ -917,7 +921,7 @@ def main():
         if host_ms is not None:
             out["ms_per_step_host_blocking"] = round(host_ms, 3)            # jtx_mi_render: one frame at a time, returns with the film on the host
             out["value_host_blocking"] = round(rays_frame / host_ms / 1e3, 2)
-        if world == 1 and not args.headline_only and args.scene is None:
+        if not dist_on and not args.headline_only and args.scene is None:
             # the other BASELINE.json workloads, a few frames each (C3 / C5 / C1 belong in the driver-written record);
             # outside `value`, `steps`, `ms_per_step`, which stay the headline's
             extras = {}
@@ -957,13 +961,13 @@ def main():
                     extras[f"{wfname}@wavefront"] = {"failed": f"{type(e).__name__}: {e}"}
             extras.update(progressive)
             out["workloads"] = extras
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(data, W, H, xs, ys, depth)
             except Exception as e:                        # report, never hide
                 out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

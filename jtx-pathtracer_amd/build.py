@@ -62,14 +62,17 @@ def build_test_hooks(force=False):
     # GPU box, JTX_EXTRA_HIPCC_FLAGS moves the tag) -- compile what is missing or stale
     if not all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(os.path.join(CSRC, src)) for o, src in zip(objs, SOURCES)):
         build_all(force=True)
-    hook = os.path.join(objdir, f"jtx_capi.testhooks.{tag}.o")
-    newest = max(os.path.getmtime(os.path.join(CSRC, d)) for d in HEADERS + ["jtx_capi.hip"] if os.path.exists(os.path.join(CSRC, d)))
-    if force or not os.path.exists(hook) or os.path.getmtime(hook) < newest:
-        src, cmd, rc, out = _compile_one((cc, "jtx_capi.hip", hook, cflags + ["-DJTX_TEST_HOOKS=1"]))
-        if rc != 0:
-            raise RuntimeError("hipcc failed on jtx_capi.hip (test hooks):\n" + out)
-    if force or not os.path.exists(TEST_LIB) or os.path.getmtime(TEST_LIB) < max(os.path.getmtime(hook), os.path.getmtime(LIB)):
-        objs = [hook if os.path.basename(o).startswith("jtx_capi.") else o for o in objs]
+    hooked = {}                                    # sources with test hooks (fault injection of the rebuild; a refused peer access): recompiled -DJTX_TEST_HOOKS
+    for hsrc in ("jtx_capi.hip", "jtx_multi.hip"):
+        hook = os.path.join(objdir, f"{os.path.splitext(hsrc)[0]}.testhooks.{tag}.o")
+        newest = max(os.path.getmtime(os.path.join(CSRC, d)) for d in HEADERS + [hsrc] if os.path.exists(os.path.join(CSRC, d)))
+        if force or not os.path.exists(hook) or os.path.getmtime(hook) < newest:
+            src, cmd, rc, out = _compile_one((cc, hsrc, hook, cflags + ["-DJTX_TEST_HOOKS=1"]))
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {hsrc} (test hooks):\n" + out)
+        hooked[os.path.splitext(hsrc)[0] + "."] = hook
+    if force or not os.path.exists(TEST_LIB) or os.path.getmtime(TEST_LIB) < max([os.path.getmtime(h) for h in hooked.values()] + [os.path.getmtime(LIB)]):
+        objs = [next((h for k, h in hooked.items() if os.path.basename(o).startswith(k)), o) for o in objs]
         r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TEST_LIB] + objs, cwd=CSRC, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc (link, test hooks) failed:\n" + r.stdout + r.stderr)

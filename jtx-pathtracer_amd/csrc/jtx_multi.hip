@@ -15,6 +15,7 @@
 #include "jtx_host.hpp"
 #include "jtx_tiles.hpp"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -63,6 +64,12 @@ struct Shard {
     float *slab_acc = nullptr; unsigned char *slab_img = nullptr;  // on this device
     float *recv_acc = nullptr; unsigned char *recv_img = nullptr;  // on device 0
     size_t film_pixels = 0, slab_slots = 0;
+    // peer: this shard's device writes device 0's memory directly (the same device, or peer access granted: hipMemcpyPeerAsync over xGMI).
+    // Otherwise the slab goes through page-locked host memory of the library's own: device -> stage on this shard's stream, stage -> device 0
+    // on device 0's stream behind an event (a platform that refuses peer access -- IOMMU settings, a PCIe-only pair -- still renders).
+    bool peer = true;
+    float *stage_acc = nullptr; unsigned char *stage_img = nullptr; size_t stage_slots = 0;
+    hipEvent_t staged = nullptr;
 };
 
 struct SetDev { int prev = -1; explicit SetDev(int d) { (void) hipGetDevice(&prev); MHIPCHK(hipSetDevice(d)); } ~SetDev() { if (prev >= 0) (void) hipSetDevice(prev); } };
@@ -88,6 +95,9 @@ void releaseShard(Shard &s, int rootDevice) {
         if (s.slab_img) (void) hipFree(s.slab_img);
         if (s.scene) jtx_mi_scene_destroy(s.scene);
         if (s.stream) (void) hipStreamDestroy(s.stream);
+        if (s.staged) (void) hipEventDestroy(s.staged);
+        if (s.stage_acc) (void) hipHostFree(s.stage_acc);
+        if (s.stage_img) (void) hipHostFree(s.stage_img);
     }
     if (hipSetDevice(rootDevice) == hipSuccess) {
         if (s.recv_acc) (void) hipFree(s.recv_acc);
@@ -117,6 +127,17 @@ void ensureBuffers(jtx_mi_multi &m, int width, int height) {
             if (s.recv_acc) (void) hipFree(s.recv_acc); if (s.recv_img) (void) hipFree(s.recv_img);
             s.recv_acc = nullptr; s.recv_img = nullptr;
             if (slots) { MHIPCHK(hipMalloc((void **) &s.recv_acc, slots * 3 * sizeof(float))); MHIPCHK(hipMalloc((void **) &s.recv_img, slots * 3)); }
+        }
+        if (r > 0 && !s.peer && s.stage_slots != slots) {
+            SetDev sd(s.device);
+            if (s.stage_acc) (void) hipHostFree(s.stage_acc); if (s.stage_img) (void) hipHostFree(s.stage_img);
+            s.stage_acc = nullptr; s.stage_img = nullptr; s.stage_slots = 0;
+            if (slots) {
+                MHIPCHK(hipHostMalloc((void **) &s.stage_acc, slots * 3 * sizeof(float), hipHostMallocPortable));
+                MHIPCHK(hipHostMalloc((void **) &s.stage_img, slots * 3, hipHostMallocPortable));
+            }
+            if (!s.staged) MHIPCHK(hipEventCreateWithFlags(&s.staged, hipEventDisableTiming));
+            s.stage_slots = slots;
         }
         s.film_pixels = npix; s.slab_slots = slots;
     }
@@ -155,13 +176,20 @@ int jtx_mi_multi_create(const jtx_mi_scene_desc *desc, const int32_t *devices, i
         // peer access to device 0 for the slab pushes (a no-op between shards of one device; not fatal when the platform
         // refuses it: hipMemcpyPeerAsync then stages through the host)
         for (int r = 1; r < n_devices; ++r) {
-            if (m->shards[r].device == m->shards[0].device) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, m->shards[r].device, m->shards[0].device) == hipSuccess && can) {
-                MHIPCHK(hipSetDevice(m->shards[r].device));
-                hipError_t e = hipDeviceEnablePeerAccess(m->shards[0].device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void) hipGetLastError();
+            Shard &s = m->shards[r];
+            s.peer = s.device == m->shards[0].device;
+            if (!s.peer) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, s.device, m->shards[0].device) == hipSuccess && can) {
+                    MHIPCHK(hipSetDevice(s.device));
+                    const hipError_t e = hipDeviceEnablePeerAccess(m->shards[0].device, 0);
+                    s.peer = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                    if (!s.peer) (void) hipGetLastError();
+                }
             }
+#ifdef JTX_TEST_HOOKS       /* libjtx_mi_testhooks.so only: the refusal, on a box where no pair of devices refuses */
+            if (getenv("JTX_TEST_REFUSE_PEER_ACCESS")) s.peer = false;
+#endif
         }
         if (prev >= 0) (void) hipSetDevice(prev);
         *out = m;
@@ -242,9 +270,17 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
                 hipLaunchKernelGGL(k_pack_shard, dim3((nslots + 255) / 256), dim3(256), 0, s.stream, s.acc, img_rgb ? s.img : nullptr, s.slab_acc,
                                    s.slab_img, nslots, r, n, W, H);
                 MHIPCHK(hipGetLastError());
-                if (r > 0) {
+                if (r > 0 && s.peer) {
                     MHIPCHK(hipMemcpyPeerAsync(s.recv_acc, root.device, s.slab_acc, s.device, s.slab_slots * 3 * sizeof(float), s.stream));
                     if (img_rgb) MHIPCHK(hipMemcpyPeerAsync(s.recv_img, root.device, s.slab_img, s.device, s.slab_slots * 3, s.stream));
+                } else if (r > 0) {                                                     // peer access refused: through the library's page-locked stage
+                    MHIPCHK(hipMemcpyAsync(s.stage_acc, s.slab_acc, s.slab_slots * 3 * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+                    if (img_rgb) MHIPCHK(hipMemcpyAsync(s.stage_img, s.slab_img, s.slab_slots * 3, hipMemcpyDeviceToHost, s.stream));
+                    MHIPCHK(hipEventRecord(s.staged, s.stream));
+                    SetDev sr(root.device);
+                    MHIPCHK(hipStreamWaitEvent(root.stream, s.staged, 0));
+                    MHIPCHK(hipMemcpyAsync(s.recv_acc, s.stage_acc, s.slab_slots * 3 * sizeof(float), hipMemcpyHostToDevice, root.stream));
+                    if (img_rgb) MHIPCHK(hipMemcpyAsync(s.recv_img, s.stage_img, s.slab_slots * 3, hipMemcpyHostToDevice, root.stream));
                 }
             }
             // ---- all shards in; a pass that any shard abandoned is void everywhere ----

@@ -6,6 +6,7 @@ produces for tile_rank/tile_world (the GPU test test_render_tile_sharding checks
 product's reduce_frame() sums the shards over torch.distributed.  Rank 0 must end up with the 1-rank
 frame bit for bit.
 """
+import json
 import os
 import socket
 import sys
@@ -115,7 +116,9 @@ def test_python_and_cpp_tile_maps_agree():
 def test_bench_self_launch_relays_the_ranks_return_code():
     """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (as a child process of a parent that has not
     imported torch).  Without a GPU the two ranks stop with bench.py's "needs an MI355X" (there is no CPU fallback): the parent relays
-    that failure as ITS return code, and the message shows that both ranks got as far as bench.py's main()."""
+    that failure as ITS return code, and the message shows that both ranks got as far as bench.py's main().  Round 6:
+    a failed launch leaves ONE JSON line -- the error, how many ranks were seen and how far each came -- so that a driver-run record of a
+    failed multi-GPU run diagnoses itself."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["HIP_VISIBLE_DEVICES"] = ""                          # (were this ever run on a GPU box: still the no-device branch)
@@ -123,4 +126,10 @@ def test_bench_self_launch_relays_the_ranks_return_code():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert "needs an MI355X" in r.stderr and "launch N>1 with" not in r.stderr
-    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and rec["n_gpus"] == 2 and rec["returncode"] == r.returncode and "exited with code" in rec["error"]
+    assert rec["nranks_seen"] == 2 and [x["rank"] for x in rec["ranks"]] == [0, 1]
+    assert all(x["stage"] == "started" and x["devices_visible"] == 0 for x in rec["ranks"])      # both ranks came up; neither found a device
+    assert "needs an MI355X" in rec["stderr_tail"]

@@ -1776,6 +1776,65 @@ def test_bench_starts_its_own_ranks(gpu):
     assert sum(x["shard_rays"] for x in line["ranks"]["ranks"]) == line["config"]["rays_per_frame"] == 727984390
 
 
+def test_bench_self_launch_with_rccl_at_one_rank(gpu):
+    """the path the driver's multi-GPU run takes -- bench.py starting its own ranks as a torch.distributed.run child, an
+    `nccl` (= RCCL) process group, the per-frame gather through RCCL overlapped with the next frame, host delivery on the destination rank,
+    the rank diagnosis -- with ONE rank (JTX_BENCH_FORCE_DIST=1), which is what a one-GPU box can run of it for real (the two-rank
+    rehearsal above goes over gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "JTX_DIST_BACKEND", "JTX_ALL_RANKS_ON_DEVICE")}
+    env.update(JTX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["ranks"]["nranks_seen"] == 1 and "REHEARSAL" not in line["config"]["parallelism"]
+    assert "gather/frame overlapped" in line["config"]["parallelism"] and "delivered to page-locked host memory" in line["config"]["timed_region"]
+    assert line["ranks"]["ranks"][0]["shard_rays"] == line["config"]["rays_per_frame"] == 727984390
+    assert line["ranks"]["ranks"][0]["exchange_ms"] is not None and 20.0 < line["ms_per_step"] < 40.0
+
+
+_REFUSED_PEER_CHILD = r"""
+import numpy as np
+import jtx_pathtracer_amd as gpu
+gpu._capi.check(gpu._capi.load().jtx_mi_set_device(0))
+data = gpu.scenes.cornell()
+sc = gpu.Scene(data); sc.buildBVH()
+ref = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4); ref.render(sc)
+ms = gpu.MultiScene(data, [0, 0, 0])
+cam = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
+seen = []
+assert ms.render(cam, progress=lambda c, t: seen.append(c), samples_per_tick=3)
+assert seen == [3, 6, 8]
+assert np.array_equal(cam.acc_.view(np.uint32), ref.acc_.view(np.uint32)) and np.array_equal(cam.img_, ref.img_)
+ms.destroy(); sc.destroy()
+print("refused-peer: ok")
+"""
+
+
+def test_multi_device_exchange_when_peer_access_is_refused(gpu, tmp_path):
+    """jtx_mi_multi_create on a platform that refuses peer access (hipDeviceCanAccessPeer -> 0): the slabs then travel
+    through the library's page-locked stage (device -> host on the shard's stream, host -> device 0 behind an event) instead of
+    hipMemcpyPeerAsync -- a branch no box of this pool takes by itself.  The refusal is injected by a hook that only
+    libjtx_mi_testhooks.so carries (jtx_multi.hip -DJTX_TEST_HOOKS), in a child process; three shards, previews per pass, the one-device
+    frame bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "jtx-pathtracer_amd", "libjtx_mi_testhooks.so")
+    assert os.path.exists(lib), "build it with __graft_entry__.build() (jtx.build_test_hooks)"
+    script = tmp_path / "refused_peer_child.py"
+    script.write_text(_REFUSED_PEER_CHILD)
+    env = dict(os.environ, JTX_MI_LIB=lib, JTX_TEST_REFUSE_PEER_ACCESS="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "refused-peer: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 # ---- per-ray parity THROUGH THE TRAVERSALS THAT SHIP (VERDICT r4 missing 4 / weak 2): jtx_mi_closest_hit_batch_via / any_hit_batch_via
 # with JTX_MI_TRAVERSAL_PRODUCTION run traverseLeaves (Cornell: the flat leaf list, scalar-operand boxes), the LDS copy (scenes that
 # are LDS-resident but have more than 32 leaves) or traverseWide (HBM-resident scenes: the 8-ary quantised nodes, wideNodePend, the
