@@ -1,9 +1,10 @@
 """bench.py's roofline arithmetic on recorded inputs (no GPU): the useful-work fraction is reference-algorithm lane-operations over
 the fp32 lane peak, the issue model prices the instruction mix with the measured per-class rates and is
-calibrated on the kernels' own loop bodies, stale counters are withheld -- recomputed here from profiles/r05_bench*.json,
-profiles/r05_pmc.json and profiles/r05_issue_replay.txt the way a reader would.  The line carries the other BASELINE workloads too
-(`workloads`), and they re-derive the same way.  Round 5: the timed region keeps three frames in flight; the roofline's kernel_ms is
-measured on launches with ONE frame in flight and agrees with the rocprofv3 kernel statistics of `JTX_FRAMES_IN_FLIGHT=1 bench.py`."""
+calibrated on the kernels' own loop bodies, stale counters are withheld -- recomputed here from profiles/r06_bench*.json,
+profiles/r06_pmc.json and profiles/r06_issue_replay.txt the way a reader would.  The line carries the other BASELINE workloads too
+(`workloads`), and they re-derive the same way.  Round 6: `value` and the roofline share ONE time -- the wall time per frame of the timed
+region (three frames in flight, every film delivered to the host); the figures of a lone launch (HIP events, one frame in flight) ride
+under `roofline.lone` and agree with the rocprofv3 kernel statistics of `JTX_FRAMES_IN_FLIGHT=1 bench.py`."""
 import json
 import os
 import re
@@ -11,7 +12,7 @@ import re
 import bench
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PMC = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))["workloads"]
+PMC = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc.json")))["workloads"]
 
 
 def _line(name):
@@ -20,7 +21,7 @@ def _line(name):
 
 def _replay():
     out = {}
-    for l in open(os.path.join(ROOT, "profiles", "r05_issue_replay.txt")):
+    for l in open(os.path.join(ROOT, "profiles", "r06_issue_replay.txt")):
         m = re.match(r"(\w+): .*measured / model = ([0-9.]+)", l)
         if m:
             out[m.group(1)] = float(m.group(2))
@@ -43,13 +44,13 @@ def _check(workload, kernel_ms, cus, lane_ops, useful_frac, frac, busy, busy_cal
     # profiles/r05_issue_replay.txt), the 8-ary traversal on its two node steps
     cal = rp["c2_phase_a_box"] if workload.startswith("cornell") else 0.5 * (rp["c3_node_closest"] + rp["c3_node_any"])
     assert abs(priced * cal / (cus * 4 * t * 2.4e9) - busy_cal) < 3e-3
-    assert 0.65 <= busy_cal <= 1.06 < busy                                     # the class prices ADD what the two pipes do side by side
+    assert 0.65 <= busy_cal <= 1.09 < busy                                     # the class prices ADD what the two pipes do side by side
     if co is not None:
         # round 5's two-pipe view (profiles/r05_box_rates.txt): every instruction takes an issue slot of 2.13 cycles, the half-rate and
         # transcendental ones their own pipe besides; the larger share binds, and neither exceeds what the SIMDs have
         assert abs(pmc["SQ_INSTS_VALU"] * 2.13 / (cus * 4 * t * 2.4e9) - co["issue_slots_busy"]) < 2e-3
         assert abs(((pmc["SQ_INSTS_VALU"] - fast - trans) * 4.4 + trans * 8.4) / (cus * 4 * t * 2.4e9) - co["half_rate_pipe_busy"]) < 2e-3
-        assert 0.6 < max(co["issue_slots_busy"], co["half_rate_pipe_busy"]) < 0.95
+        assert 0.6 < max(co["issue_slots_busy"], co["half_rate_pipe_busy"]) < 0.97
         assert (co["issue_slots_busy"] > co["half_rate_pipe_busy"]) == workload.startswith("cornell")     # leaf list: issue; 8-ary nodes: the half-rate pipe
     assert abs((2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024 - traffic) < 1e6
 
@@ -74,7 +75,7 @@ def test_useful_ops_table():
 
 
 def test_recorded_bench_line_is_reproducible_from_profiles():
-    line = _line("r05_bench.json")
+    line = _line("r06_bench.json")
     r = line["roofline"]
     _check(line["config"]["workload"], r["kernel_ms"], r["num_cus"], r["useful"]["lane_ops_per_launch"], r["useful_frac"], r["frac"],
            r["issue_model"]["busy"], r["issue_model"]["busy_calibrated"], r["traffic"], r["issue_model"]["co_issue"])
@@ -86,52 +87,75 @@ def test_recorded_bench_line_is_reproducible_from_profiles():
     # useful_frac_attainable: the same operations priced by issue class over the SIMD cycles of the launch
     assert abs(u["issue_cycles_at_least"] / (r["num_cus"] * 4 * r["kernel_ms"] * 1e-3 * 2.4e9) - r["useful_frac_attainable"]) < 2e-4
     assert r["useful_frac"] < r["useful_frac_attainable"] < 2.2 * r["useful_frac"]
-    # three frames in flight in the timed region: a frame takes LESS wall time than a lone launch + its resolve pass, and the fractions
-    # restated on that time are the higher ones
-    f = r["in_flight"]
-    assert line["config"]["frames_in_flight"] == f["frames_in_flight"] == 3
-    assert f["ms_per_frame"] == line["ms_per_step"] < r["kernel_ms"] and f["useful_frac"] > r["useful_frac"] and f["frac"] > r["frac"]
-    assert abs(u["lane_ops_per_launch"] / (f["ms_per_frame"] * 1e-3) / (r["num_cus"] * 128 * 2.4e9) - f["useful_frac"]) < 2e-4
+    # ONE self-consistent pair: the roofline's time IS the step time of the timed region -- three frames in flight, every
+    # film delivered to the host --, never longer; a lone launch takes longer than a frame's share of the pipelined loop, and the fractions on it
+    # are the lower ones
+    lone = r["lone"]
+    assert line["config"]["frames_in_flight"] == r["frames_in_flight"] == 3 and "delivered to page-locked host memory" in line["config"]["timed_region"]
+    assert r["kernel_ms"] <= line["ms_per_step"] + 5e-4 and abs(r["kernel_ms"] - line["ms_per_step"]) < 1e-3
+    assert lone["kernel_ms"] > r["kernel_ms"] and lone["useful_frac"] < r["useful_frac"] and lone["frac"] < r["frac"]
+    assert abs(u["lane_ops_per_launch"] / (lone["kernel_ms"] * 1e-3) / (r["num_cus"] * 128 * 2.4e9) - lone["useful_frac"]) < 2e-4
+    # the host copies cost nothing: the same loop with the films left in HBM (round 5's timed region) takes the same time
+    assert abs(line["ms_per_step_device"] - line["ms_per_step"]) / line["ms_per_step"] < 0.02
+    assert line["ms_per_step_host_blocking"] > line["ms_per_step"]                      # one frame at a time, the film on the host before the call returns
     # the kernel's average duration in the rocprofv3 --kernel-trace --stats summary of `JTX_FRAMES_IN_FLIGHT=1 bench.py` (the launches the
-    # roofline is measured on) agrees with the HIP events; in the default command's summary launches overlap and last longer than a frame takes
+    # lone figures are measured on) agrees with the HIP events; in the default command's summary launches overlap and last longer than a frame takes
     import csv
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_stats.csv"))))
     row = next(x for x in rows if "k_render_paths" in x["Name"])
-    assert abs(float(row["AverageNs"]) / 1e6 - r["kernel_ms"]) / r["kernel_ms"] < 0.01
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_kernel_stats_in_flight.csv"))))
+    assert abs(float(row["AverageNs"]) / 1e6 - lone["kernel_ms"]) / lone["kernel_ms"] < 0.01
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_stats_in_flight.csv"))))
     row = next(x for x in rows if "k_render_paths" in x["Name"])
-    assert float(row["AverageNs"]) / 1e6 > 1.2 * line["ms_per_step"] and float(row["MinNs"]) / 1e6 > 0.98 * r["kernel_ms"] * 0.99
+    assert float(row["AverageNs"]) / 1e6 > 1.2 * line["ms_per_step"] and float(row["MinNs"]) / 1e6 > 0.98 * lone["kernel_ms"] * 0.99
 
 
 def test_the_other_workloads_ride_in_the_same_line_and_re_derive():
-    """C3, C5 and C1 in the driver-written record; round 5: and the wavefront integrator north_star names, on C5, as a current figure"""
-    line = _line("r05_bench.json")
+    """C3, C5 and C1 in the driver-written record; the wavefront integrator north_star names on C2, C3 and C5 as current figures; round 6:
+    the frame as the reference's UI renders it (a callback per pass, samplesPerPass_ 1 and 8) through the progressive launch"""
+    line = _line("r06_bench.json")
     w = line["workloads"]
     assert set(w) == {"atrium_1920x1080_64spp_d8", "mixed_1920x1080_128spp_d8", "cornell_512x512_16spp_d4",
-                      "mixed_1920x1080_128spp_d8@wavefront", "mixed_1920x1080_128spp_d8@wavefront_sorted"}
+                      "mixed_1920x1080_128spp_d8@wavefront", "mixed_1920x1080_128spp_d8@wavefront_sorted",
+                      "cornell_1920x1080_64spp_d8@wavefront", "atrium_1920x1080_64spp_d8@wavefront",
+                      "cornell_1920x1080_64spp_d8@spp_per_pass_1", "cornell_1920x1080_64spp_d8@spp_per_pass_8"}
     for name in ("atrium_1920x1080_64spp_d8", "mixed_1920x1080_128spp_d8"):
         e = w[name]
         _check(name, e["kernel_ms"], e["num_cus"], e["useful_lane_ops_per_launch"], e["useful_frac"], e["frac"], e["issue_model"]["busy"],
                e["issue_model"]["busy_calibrated"], e["traffic"], e["issue_model"]["co_issue"])
         assert abs(e["value"] - e["rays_per_frame"] / (e["ms_per_step"] * 1e-3) / 1e6) / e["value"] < 1e-3
         assert e["vector_memory"]["ta_busy"] > 0.75                         # the second ceiling of the HBM-resident kernels (DESIGN.md section 6)
-        assert e["frames_in_flight"] == 3 and e["ms_per_step"] < e["kernel_ms"] * 1.01
+        assert e["frames_in_flight"] == 3 and e["ms_per_step"] < e["kernel_ms"] * 1.01 and e["timed_region"] == "film delivered to host"
     c1 = w["cornell_512x512_16spp_d4"]
     assert c1["frac"] is None and 0.1 < c1["useful_frac"] < 0.25             # no counters were collected for C1: only the counter-free fraction
-    assert c1["ms_per_step"] < 0.95 * c1["kernel_ms"]                        # a 1.3 ms launch gains most from frames in flight
+    assert c1["ms_per_step"] < 0.95 * c1["kernel_ms"]                        # a 1.1 ms launch gains most from frames in flight
     # the HBM wavefront (integrator 2) renders the same C5 frame 1.4x slower than the integrator that ships; one shade launch per
-    # material type (the material-sorted queues) slower still
+    # material type (the material-sorted queues) slower still; C2 3.6x, C3 1.4x (current figures: VERDICT r5 next 6)
     shipped, wf, wfs = w["mixed_1920x1080_128spp_d8"], w["mixed_1920x1080_128spp_d8@wavefront"], w["mixed_1920x1080_128spp_d8@wavefront_sorted"]
     assert wf["integrator"] == wfs["integrator"] == 2 and shipped["integrator"] == 1 and wf["rays_per_frame"] == shipped["rays_per_frame"]
     assert 1.2 * shipped["ms_per_step"] < wf["ms_per_step"] < wfs["ms_per_step"]
+    assert 3.0 * line["ms_per_step"] < w["cornell_1920x1080_64spp_d8@wavefront"]["ms_per_step"] < 5.0 * line["ms_per_step"]
+    assert 1.25 * w["atrium_1920x1080_64spp_d8"]["ms_per_step"] < w["atrium_1920x1080_64spp_d8@wavefront"]["ms_per_step"]
+    assert w["cornell_1920x1080_64spp_d8@wavefront"]["rays_per_frame"] == line["config"]["rays_per_frame"]
+    # the progressive launch: one callback per pass, and the frame within 15 % of the batch frame whatever the pass size (round 5: 46.5 ms
+    # at one stratum per pass against 21.9 -- 2.1 x)
+    p1, p8 = w["cornell_1920x1080_64spp_d8@spp_per_pass_1"], w["cornell_1920x1080_64spp_d8@spp_per_pass_8"]
+    assert p1["callbacks_per_frame"] == 64 and p8["callbacks_per_frame"] == 8 and p1["rays_per_frame"] == line["config"]["rays_per_frame"]
+    assert p8["ms_per_step"] <= p1["ms_per_step"] * 1.02 and p1["ms_per_step"] < 1.15 * line["ms_per_step"] and p1["ms_per_step"] <= 27.0
     # ... and agree with the same workloads benched on their own
-    for name, f in (("atrium_1920x1080_64spp_d8", "r05_bench_c3_atrium.json"), ("mixed_1920x1080_128spp_d8", "r05_bench_c5_mixed.json")):
+    for name, f in (("atrium_1920x1080_64spp_d8", "r06_bench_c3_atrium.json"), ("mixed_1920x1080_128spp_d8", "r06_bench_c5_mixed.json")):
         alone = _line(f)
-        assert abs(alone["roofline"]["kernel_ms"] - w[name]["kernel_ms"]) / w[name]["kernel_ms"] < 0.02
+        assert abs(alone["roofline"]["lone"]["kernel_ms"] - w[name]["kernel_ms"]) / w[name]["kernel_ms"] < 0.02
         assert alone["config"]["rays_per_frame"] == w[name]["rays_per_frame"]
     # C5's numerator now counts what its vertices are: the per-class tallies of the counting pass sum to the shading events
-    c5 = _line("r05_bench_c5_mixed.json")["roofline"]["useful"]
+    c5 = _line("r06_bench_c5_mixed.json")["roofline"]["useful"]
     assert c5["lane_ops_per_launch"] > 0 and len(c5["sample_by_class"]) == 8
+    # the progressive launch in the rocprofv3 record: ONE path-kernel launch per frame and the resolver beside it for as long
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_stats_progressive_spp1.csv"))))
+    paths = next(x for x in rows if "k_render_paths" in x["Name"] and "true" in x["Name"])
+    res = next(x for x in rows if "k_resolve_progressive" in x["Name"])
+    assert paths["Calls"] == res["Calls"] and not any("k_resolve_samples" in x["Name"] for x in rows)
+    assert abs(float(res["AverageNs"]) - float(paths["AverageNs"])) / float(paths["AverageNs"]) < 0.05
 
 
 def test_stale_counters_are_withheld(monkeypatch):
@@ -164,7 +188,7 @@ def test_build_flags_are_part_of_the_profile_stamp(tmp_path, monkeypatch):
     assert "-fno-slp-vectorize" in build.FLAGS and "-ffp-contract=off" in build.FLAGS and "--offload-arch=gfx950" in build.FLAGS
     assert not any(f.startswith("-ffast-math") or f == "-Ofast" for f in build.FLAGS)
     h0 = bench.source_hash()
-    assert h0 == json.load(open(os.path.join(ROOT, "profiles", "r05_pmc.json")))["source_hash"]        # the committed counters are this build's
+    assert h0 == json.load(open(os.path.join(ROOT, "profiles", "r06_pmc.json")))["source_hash"]        # the committed counters are this build's
     real_open = open
     def fake_open(path, *a, **k):
         f = real_open(path, *a, **k)
