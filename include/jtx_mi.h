@@ -366,6 +366,28 @@ int jtx_mi_radiance_samples_li(jtx_mi_scene *scene, const jtx_mi_camera_desc *ca
 int jtx_mi_rng_stream(uint32_t x, uint32_t y, uint32_t n, int32_t count, uint32_t *out_u32, float *out_f32);
 int jtx_mi_sincos_batch(const float *x, int32_t n, float *out_sin, float *out_cos);
 
+/* ---- environment variables the library reads (each once, at first use; none is needed: defaults in brackets) ----------------------
+ * Choice of code path (all paths give the same film bit for bit):
+ *   JTX_INTEGRATOR=1|2           what opts.integrator == 0 resolves to [the measured policy: 1]
+ *   JTX_DYNAMIC_PATHS=0          uncounted integrator-1 renders through the one-lane-per-pixel kernel instead of the persistent path kernel [1]
+ *   JTX_LEAF_WALK=0              LDS-resident scenes with <= 32 leaves walk the LDS copy of the binary records instead of the flat leaf list [1]
+ *   JTX_NO_WIDE=1                scenes that do not fit LDS walk the binary records instead of the 8-ary quantised nodes [unset]
+ *   JTX_WIDE_SAH_CUT=0           8-ary nodes cut by depth instead of by summed box area [1]
+ *   JTX_WF_SORT_SHADE=1          integrator 2: one shade launch per Material::type (the material-sorted queues) [0]
+ *   JTX_PROGRESSIVE_LAUNCH=0     jtx_mi_render with a callback goes pass by pass (a launch per pass) instead of one launch for all passes [1]
+ * Tuning (measured defaults; DESIGN.md / EXPERIMENTS.md say where they come from):
+ *   JTX_STRATA_GROUPS=n          strata groups per 8x8 pixel block of a k_render_paths launch [by frame size: ~250 k chunks per lone launch]
+ *   JTX_MAX_RAD_MB=n             opts.max_record_mb for callers that pass no opts [8192]
+ *   JTX_WF_BATCH=n               integrator 2: strata per batch [by frame size]
+ *   JTX_RESOLVER_WGS=n           workgroups of the progressive resolver, 2 .. 128 [64]
+ *   JTX_PROG_MIN_STRATA=n        progressive launches group passes shorter than n strata into chunks of >= n [4]
+ *   JTX_BVH_THREADS=n            host threads of jtx_mi_bvh_build / jtx_mi_scene_create's build [hardware threads, at most 32]
+ * Developer aids (stderr / a file; no effect on results):
+ *   JTX_TRACE_CREATE, JTX_TRACE_RENDER   host-side phase times of scene creation / of jtx_mi_render
+ *   JTX_ABORT_LOG=<file>         a back trace into <file> when the process aborts or terminates on an uncaught exception
+ * (libjtx_mi_testhooks.so -- test infrastructure, never the product -- also reads JTX_FAIL_REBUILD_BEFORE_COMMIT, JTX_TEST_REFUSE_PEER_ACCESS and
+ *  JTX_TEST_PROGRESSIVE_ONE_STREAM.) */
+
 #ifdef __cplusplus
 }
 #endif

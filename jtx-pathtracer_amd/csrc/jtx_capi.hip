@@ -1068,6 +1068,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 q.num_groups = (se - sb + prog->spg - 1) / prog->spg;
                 q.num_subblocks = owned * 16;
                 prog->groups = q.num_groups;
+                if (q.num_groups > 32767) throw std::runtime_error("progressive launch: more than 32767 strata groups (raise samples_per_tick)");
                 q.prog_groups_per_pass = prog->tick > prog->spg ? prog->tick / prog->spg : 1;
                 const int leave = jtx_resolve_progressive_waves(prog->resolver_wgs);
                 const int nwaves = jtx_render_paths_waves(q, s.num_cus, 1, leave);
@@ -1082,7 +1083,11 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 HIPCHK(hipMemsetAsync(s.prog_ctl.p + kLeader, 0, (kSlots - kLeader) * sizeof(unsigned), stream));
                 q.work = s.prog_ctl.p; q.prog_closed_at = s.prog_ctl.p + kClosedAt; q.prog_leader = s.prog_ctl.p + kLeader; q.prog_slots = s.prog_ctl.p + kSlots;
                 rec.last_work = nullptr;                                   // (progress comes from the resolver's words, not from a chunk counter)
-                if (!s.resolve_stream) HIPCHK(hipStreamCreateWithFlags(&s.resolve_stream, hipStreamNonBlocking));
+                if (!s.resolve_stream) {
+                    int least = 0, greatest = 0;
+                    (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+                    HIPCHK(hipStreamCreateWithPriority(&s.resolve_stream, hipStreamNonBlocking, greatest));
+                }
                 for (hipEvent_t *e : {&s.prog_ready, &s.prog_paths_done, &s.prog_resolved}) if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
                 if (!s.prog_host) {
                     HIPCHK(hipHostMalloc((void **) &s.prog_host, 2 * kResolverMax * sizeof(unsigned), hipHostMallocMapped));
@@ -1091,26 +1096,23 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 }
                 prog->epoch = (++s.prog_epoch & 0x7fffu) + 1u;
                 const int nr = prog->resolver_wgs;
-                // the resolver first, and not before the film and the control words stand; the path kernel once the resolver's workgroups
-                // have their wave slots (they say so in host memory; a resolver that finds none yet still gives the right film, later)
+                // The PATH KERNEL FIRST, then the resolver on its own stream (not before the film and the control words stand).  The path grid
+                // leaves the resolver's wave slots free, so the resolver starts beside it at once -- when the two streams run side by side.
+                // HIP promises no such thing (streams may share a hardware queue whose packets run in order), and the order of the two launches
+                // is what makes that harmless: the path kernel waits for nobody, so a resolver that only gets to run AFTER it adds all passes
+                // then -- the right film, previews late.  (Round 6's first version launched the resolver first and waited for it to check in:
+                // tools/soak.py met the mapping where the path kernel then queued BEHIND the resolver, which waited for it -- a minute, its
+                // bounded wait, then an error.)  The resolver's stream is a high-priority one: a queue of its own where the runtime has one.
                 HIPCHK(hipEventRecord(s.prog_ready, stream));
-                HIPCHK(hipStreamWaitEvent(s.resolve_stream, s.prog_ready, 0));
-                HIPCHK(jtx_launch_resolve_progressive(q, owned, nwaves, nr, s.prog_host_dev, s.prog_host_dev + kResolverMax, prog->epoch, s.resolve_stream));
-                HIPCHK(hipEventRecord(s.prog_resolved, s.resolve_stream));
-                {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    while (true) {
-                        int in = 0;
-                        for (int w = 0; w < nr; ++w) in += __atomic_load_n(s.prog_host + w, __ATOMIC_ACQUIRE) == prog->epoch ? 1 : 0;
-                        if (in == nr) break;
-                        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
-                            if (getenv("JTX_TRACE_RENDER")) fprintf(stderr, "[jtx_mi_render] resolver check-in timed out: %d of %d workgroups\n", in, nr);
-                            break;
-                        }
-                        std::this_thread::yield();
-                    }
-                }
-                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, leave));
+                if (const hipError_t le = jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, leave))
+                    throw std::runtime_error(std::string("k_render_paths (progressive): ") + hipGetErrorString(le));
+                hipStream_t rstream = s.resolve_stream;
+#ifdef JTX_TEST_HOOKS       /* libjtx_mi_testhooks.so only: both kernels on ONE stream -- the serialised case, on a box whose streams do run side by side */
+                if (getenv("JTX_TEST_PROGRESSIVE_ONE_STREAM")) rstream = stream;
+#endif
+                if (rstream != stream) HIPCHK(hipStreamWaitEvent(rstream, s.prog_ready, 0));
+                HIPCHK(jtx_launch_resolve_progressive(q, owned, nwaves, nr, s.prog_host_dev, s.prog_host_dev + kResolverMax, prog->epoch, rstream));
+                HIPCHK(hipEventRecord(s.prog_resolved, rstream));
                 HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true;
                 HIPCHK(hipEventRecord(s.prog_paths_done, stream));
                 HIPCHK(hipStreamWaitEvent(stream, s.prog_resolved, 0));    // the stream (and the slot's fence) stands for both kernels from here on
@@ -1763,7 +1765,11 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
             // added, the pass after them leaves no trace.
             // A range whose records exceed the cap goes in several such launches, one after the other.
             if (!s->copy_stream) HIPCHK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-            if (!s->resolve_stream) HIPCHK(hipStreamCreateWithFlags(&s->resolve_stream, hipStreamNonBlocking));
+            if (!s->resolve_stream) {
+                int least = 0, greatest = 0;
+                (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+                HIPCHK(hipStreamCreateWithPriority(&s->resolve_stream, hipStreamNonBlocking, greatest));
+            }
             Drain drain{s->stream, s->resolve_stream, s->copy_stream};
             const int world = o.tile_world > 1 ? o.tile_world : 1, rank = o.tile_world > 1 ? o.tile_rank : 0;
             const int tiles = ((cam->width + 31) / 32) * ((cam->height + 31) / 32);
@@ -1796,11 +1802,13 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                 jtx_mi_render_opts o2 = o; o2.frame_slot = 0; o2.sequence_end = 1;
                 launchRender(*s, *cam, o2, b0, e0, s->film_acc.p, dimg, s->stream, &pl);
                 lap("enqueue");
+                bool resolverGaveUp = false;
                 auto completed = [&] {                                          // strata of this launch that are in the film of every pixel: whole passes
-                    unsigned g = 0xffffu;
+                    unsigned g = 0x7fffu;
                     for (int w = 0; w < nr; ++w) {
                         const unsigned v = __atomic_load_n(s->prog_host + kResolverMax + w, __ATOMIC_ACQUIRE);
-                        const unsigned gw = (v >> 16) == pl.epoch ? (v & 0xffffu) : 0u;
+                        const unsigned gw = (v >> 16) == pl.epoch ? (v & 0x7fffu) : 0u;
+                        if ((v >> 16) == pl.epoch && (v & 0x8000u)) resolverGaveUp = true;
                         g = gw < g ? gw : g;
                     }
                     if (owned == 0) g = (unsigned) pl.groups;
@@ -1832,7 +1840,11 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                     if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield();
                 }
                 HIPCHK(hipStreamSynchronize(s->stream));
-                if (getenv("JTX_DBG_PROG")) { unsigned h[48]; HIPCHK(hipMemcpy(h, s->prog_ctl.p + 64 + 16, sizeof h, hipMemcpyDeviceToHost)); for (unsigned i = 0; i < h[0] && i < 14; ++i) fprintf(stderr, "[leader] t %8.3f ms dealt groups %u by waves %u\n", (h[1 + 3 * i] - h[1]) / 1000.0, h[2 + 3 * i], h[3 + 3 * i]); }
+                (void) completed();
+                if (resolverGaveUp) throw std::runtime_error("progressive launch: the resolver waited a minute for the path kernel and gave up (the film holds the passes added so far)");
+#ifdef JTX_DBG_PROG      /* diagnostic build: the resolver leader's log of (time, groups dealt, groups out of every wave's hands) */
+                { unsigned h[48]; HIPCHK(hipMemcpy(h, s->prog_ctl.p + 64 + 16, sizeof h, hipMemcpyDeviceToHost)); for (unsigned i = 0; i < h[0] && i < 14; ++i) fprintf(stderr, "[leader] t %8.3f ms dealt groups %u by waves %u\n", (h[1 + 3 * i] - h[1]) / 1000.0, h[2 + 3 * i], h[3 + 3 * i]); }
+#endif
                 done = completed();
                 if (done < e0 || stopAsked) cancelled = true;
                 b0 = e0;

@@ -10,6 +10,8 @@
 //  k_render_paths    : the timed kernel.  Persistent waves fetch (8x8 pixel block, strata group) chunks and hand
 //                      their paths to whichever lane is free; per-path radiance -> rad[stratum][pixel].
 //  k_resolve_samples : adds the per-path radiances to the film in sample order (same float sums).
+//  k_resolve_progressive : the same for a PROGRESSIVE launch (k_render_paths<.., PROG>: all passes of a frame in one launch), pass after pass,
+//                      beside the path kernel.
 //  k_*_batch         : per-ray / per-sample entry points used by the parity tests.
 //
 // Compiled with -ffp-contract=off: results must equal the CPU oracle bit for bit.
@@ -641,9 +643,7 @@ int jtx_render_paths_grid(const DevScene &sc, int num_cus, int *block_size) {
     return (int) (((long) num_cus * 4 * (wide ? JTX_WIDE_OCC : JTX_RP_OCC) * 64 + bs - 1) / bs);
 }
 
-// share: this launch takes 1 / share of the wave slots (jtx_mi_render with `share` passes in flight: together they fill the chip, every
-// wave of a small pass gets `share` times as many chunks -- its end, where lanes wait for the longest of the last paths, weighs less --
-// and the resolve of a finished pass finds free slots at once)
+// share: this launch takes 1 / share of the wave slots (several small launches that fill the chip together)
 // leave_waves: wave slots left to a kernel that runs beside it (the progressive resolver)
 constexpr int RESOLVE_BLOCK_HOST = 256;            // = jtx::RESOLVE_BLOCK (k_resolve_progressive)
 static long renderPathsWaves(const RenderParams &p, int num_cus, int share, int leave_waves, int *bsOut) {
@@ -704,7 +704,9 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, i
 // ------------------------------------------------------------------------------------------------
 namespace jtx {
 constexpr int RESOLVE_BLOCK = 256;
-constexpr unsigned RESOLVE_LAST = 0x80000000u;      // prog word 2: bit 31 = this count is final (every chunk dealt, every wave gone)
+constexpr unsigned RESOLVE_LAST = 0x80000000u;      // the leader's word: bit 31 = this count is final (every chunk dealt, every wave gone)
+constexpr unsigned RESOLVE_GAVE_UP = 0x40000000u;   // ... bit 30 = the leader gave up: nothing moved for RESOLVE_PATIENCE (the path kernel never came)
+constexpr unsigned long long RESOLVE_PATIENCE = 60ull * 100000000ull;   // s_memrealtime ticks (100 MHz): a minute without a chunk fetched or a wave's word moving
 
 // pixel slot -> its pixel; false for the padding slots of tiles that overhang the frame
 JD bool resolveSlot(const RenderParams &p, int pslot, size_t &pix) {
@@ -736,7 +738,8 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
     unsigned *leaderWord = p.prog_leader;
     if (wg == 0 && nwg > 1) {
         // ---- the leader: how many passes are complete?  (One workgroup watches the path waves, the others watch its word.) ----
-        unsigned dealtSeen = 0u, published = 0u;
+        unsigned dealtSeen = 0u, published = 0u, sigBefore = 0xffffffffu;
+        unsigned long long tMoved = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) __hip_atomic_store(progress_host + wg, (epoch << 16) | (unsigned) p.num_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (no pixels of its own: never the minimum)
         while (true) {
             if (tid == 0) {
@@ -768,8 +771,15 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
             if (!allGone) { const int byWaves = (int) oldest > p.sample_begin ? ((int) oldest - p.sample_begin) / p.strata_per_group : 0; complete = byWaves < complete ? byWaves : complete; }
             if (complete >= p.num_groups) complete = p.num_groups;
             else complete = complete / p.prog_groups_per_pass * p.prog_groups_per_pass;    // whole passes only (a cancellation may end the launch inside one)
-            const bool last = allGone && dealtFinal;
-            const unsigned word = (unsigned) complete | (last ? RESOLVE_LAST : 0u);
+            bool last = allGone && dealtFinal;
+            // a bounded wait: the resolver runs BEFORE the path kernel is launched; should that launch never come (the host then closes the
+            // counter itself) or nothing move for a minute, it ends -- with the passes it has -- and says so
+            const unsigned sig = shWord ^ (oldest * 0x9e3779b9u);
+            const unsigned long long tNow = __builtin_amdgcn_s_memrealtime();
+            if (sig != sigBefore) { sigBefore = sig; tMoved = tNow; }
+            const bool gaveUp = !last && tNow - tMoved > RESOLVE_PATIENCE;
+            if (gaveUp) last = true;
+            const unsigned word = (unsigned) complete | (last ? RESOLVE_LAST : 0u) | (gaveUp ? RESOLVE_GAVE_UP : 0u);
             if (word != published) {
                 if (tid == 0) atomicExch(leaderWord, word);
 #ifdef JTX_DBG_PROG
@@ -791,7 +801,11 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
         __syncthreads();
         const unsigned word = shWord;
         __syncthreads();
-        const int complete = (int) (word & ~RESOLVE_LAST);
+        const int complete = (int) (word & ~(RESOLVE_LAST | RESOLVE_GAVE_UP));
+        if (word & RESOLVE_GAVE_UP) {                                   // (the host reads it in every workgroup's word: bit 15 of the count)
+            if (tid == 0) __hip_atomic_store(progress_host + wg, (epoch << 16) | 0x8000u | (unsigned) done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         if (complete > done) {
             const int sA = p.sample_begin + done * p.strata_per_group;
             int sB = p.sample_begin + complete * p.strata_per_group; if (sB > p.sample_end) sB = p.sample_end;

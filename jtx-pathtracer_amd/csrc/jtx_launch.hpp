@@ -33,11 +33,10 @@ struct RenderParams {
     // the film as the last completed pass left it
     const unsigned *stop;
     // k_resolve_samples only (at the END of the block: the path kernels' argument offsets stay where they were):
-    // prev_work: jtx_mi_render with several passes in flight -- the chunk counter of the pass BEFORE this one, or null.  The resolve leaves
-    //   the film alone, and marks its own pass abandoned, when that pass was abandoned: passes enter the film in order or not at all.
-    // abandoned: a host-mapped word of this launch; the resolve sets it when the pass was abandoned, so that the host learns it from its
-    //   own memory after the stream has drained -- a 4-byte device-to-host copy is a blit KERNEL, and waits a millisecond for a wave slot
-    //   while the next pass's persistent waves fill the chip (round 5 timeline: profiles/r05_progressive.md).
+    // prev_work: a pass split into several launches (radiance record cap) -- the chunk counter of the launch BEFORE this one, or null.  The
+    //   resolve leaves the film alone, and marks its own launch abandoned, when that one was: strata enter the film in order or not at all.
+    // abandoned: a host-mapped word of this launch; the resolve sets it when the launch was abandoned, so that the host learns it from its
+    //   own memory after the stream has drained -- a 4-byte device-to-host copy is a blit KERNEL, and waits for a wave slot.
     unsigned *prev_work;
     unsigned *abandoned;
     // PROGRESSIVE launches (round 6: jtx_mi_render with a callback; k_render_paths<.., PROG = true> beside k_resolve_progressive): one

@@ -136,6 +136,8 @@ public:
     void reserveRebuild() { if (handle_) check(jtx_mi_scene_reserve_rebuild(handle_)); }
     // ... and given back when the editing is over (jtx_mi_scene_release_rebuild: about the geometry's device memory once more)
     void releaseRebuild() { if (handle_) check(jtx_mi_scene_release_rebuild(handle_)); }
+    // the frame slots' working memory (per-path radiance records of the renders so far: jtx_mi_scene_info::frame_slot_bytes) back to the device
+    void releaseFrames() { if (handle_) check(jtx_mi_scene_release_frames(handle_)); }
     void rebuildBVHOnDevice(int maxPrimsInNode = 1) {
         if (!handle_) { buildBVH(maxPrimsInNode); return; }
         for (size_t i = 0; i < meshes.size(); ++i) check(jtx_mi_scene_set_transform(handle_, (int) i, &meshes[i].transform.m[0][0]));

@@ -2071,8 +2071,10 @@ def test_cancellation_with_passes_in_flight_leaves_a_prefix_of_the_strata(gpu, m
     assert full.currentSample_ == 24
     assert_same_f32(full.acc_, ref(24)[0], "24 passes, one launch")
     seen = set()
-    for k in range(12):
+    cams = []                                                                 # (kept alive: releasing a camera's page-locked film -- hipHostUnregister --
+    for k in range(12):                                                       #  right before the next render delays that render's start by milliseconds)
         cam = gpu.StaticCamera(W, H, data.camera, 6, 4, 6); cam.samplesPerPass_ = 1
+        cams.append(cam)
         cam._pin()                                                            # (before the clock runs)
         timer = threading.Timer(t_full * (0.05 + 0.08 * k), cam.terminateRender)
         timer.start(); cam.render(sc, progress=lambda c, t: None); timer.join()
@@ -2115,6 +2117,45 @@ def test_progressive_launch_of_a_tile_shard_with_previews(gpu, cornell_pair):
     odd.render(sc, progress=lambda c, t: seen.append(c))
     assert seen == [5, 10, 12]
     assert_same_f32(odd.acc_, whole.acc_, "passes of 5 strata, the last one shorter"); assert (odd.img_ == whole.img_).all()
+
+
+_ONE_STREAM_CHILD = r"""
+import numpy as np
+import jtx_pathtracer_amd as gpu
+gpu._capi.check(gpu._capi.load().jtx_mi_set_device(0))
+data = gpu.scenes.cornell()
+sc = gpu.Scene(data); sc.buildBVH()
+ref = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); ref.render(sc)
+for spp_pass in (1, 3, 8):
+    cam = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); cam.samplesPerPass_ = spp_pass
+    seen = []
+    cam.render(sc, progress=lambda c, t: seen.append(c))
+    assert seen == list(range(spp_pass, 16, spp_pass)) + [16], seen
+    assert np.array_equal(cam.acc_.view(np.uint32), ref.acc_.view(np.uint32)) and np.array_equal(cam.img_, ref.img_)
+sc.destroy()
+print("one-stream: ok")
+"""
+
+
+def test_progressive_launch_when_the_two_kernels_cannot_run_side_by_side(gpu, tmp_path):
+    """The progressive launch is two kernels on two streams, and HIP does not promise that streams run side by side (they may share a
+    hardware queue: tools/soak.py met that mapping in round 6 -- with the resolver launched FIRST the path kernel queued behind it and the
+    resolver waited for it).  The path kernel is launched first and waits for nobody, so the serialised case is merely late with its
+    previews: here both kernels are put on ONE stream (a hook only libjtx_mi_testhooks.so carries) -- same film bit for bit, every
+    callback delivered, no wait."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "jtx-pathtracer_amd", "libjtx_mi_testhooks.so")
+    assert os.path.exists(lib), "build it with __graft_entry__.build() (jtx.build_test_hooks)"
+    script = tmp_path / "one_stream_child.py"
+    script.write_text(_ONE_STREAM_CHILD)
+    env = dict(os.environ, JTX_MI_LIB=lib, JTX_TEST_PROGRESSIVE_ONE_STREAM="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "one-stream: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert time.perf_counter() - t0 < 50.0                                      # (the resolver's bounded wait is a minute: it was never needed)
 
 
 def test_frame_slot_memory_is_accounted_and_can_be_released(gpu, cornell_pair):

@@ -323,6 +323,21 @@ def test_capi_exports_every_declared_symbol():
     assert C.sizeof(jtx._capi.BvhNode) == 32 and C.sizeof(jtx._capi.TriRef) == 8
 
 
+def test_every_environment_variable_the_library_reads_is_in_the_header():
+    """the tuning switches of the product library (getenv in csrc/) are documented where its interface is -- the list in
+    include/jtx_mi.h is exactly what the sources read (diagnostic / test-hook reads sit behind #ifdef and are named there as such)."""
+    csrc = os.path.join(ROOT, "jtx-pathtracer_amd", "csrc")
+    read = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            read |= set(re.findall(r'getenv\("(JTX_[A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    header = open(os.path.join(ROOT, "include", "jtx_mi.h")).read()
+    env = header[header.index("environment variables the library reads"):]
+    documented = set(re.findall(r"\b(JTX_[A-Z0-9_]+)\b", env))
+    assert read - documented == set(), read - documented
+    assert documented - read - {"JTX_MI_H"} == set(), documented - read
+
+
 def test_ctypes_structs_match_the_header(tmp_path):
     """the C-ABI's structs as a C compiler lays them out (gcc on include/jtx_mi.h: a plain C header) against the ctypes mirrors of
     _capi.py -- sizes and the offsets of the fields rounds 5 and 6 added (frame_slot, sequence_end, the per-class tallies, the spare-set bytes; max_record_mb, frame_slot_bytes)"""

@@ -6,8 +6,8 @@ library-owned page-locked staging and by film buffers outside the malloc heap, a
 Each iteration is what Display::renderScene does after an edit (display.cpp:902-905: rebuild if dirty, then render), from scratch:
     Scene(data) -> buildBVH (host build + upload through the staging buffer) -> StaticCamera with page-locked film buffers -> render
     (uncounted kernel, film delivered to the host) -> film checked against the first iteration's -> transform edit -> rebuildBVH on the
-    device -> render -> [every 5th: the frame again with a preview per pass -- three passes in flight -- and as four frames in flight on
-    three streams / frame slots] -> destroy; scene, size and strata vary with the iteration, so allocations do not simply recycle.
+    device -> render -> the frame again with a callback per pass (one progressive launch; every third iteration cancelled from another
+    thread) -> [every 5th: four frames in flight on three streams / frame slots] -> destroy; scene, size and strata vary with the iteration, so allocations do not simply recycle.
 Every 50th iteration: the two-process rehearsal (two ranks sharing the card: their own contexts, IPC-free gloo exchange).
 JTX_ABORT_LOG is armed: a runtime abort leaves its reason and a native backtrace there.
 
@@ -74,13 +74,27 @@ def main():
         crc = zlib.crc32(np.ascontiguousarray(cam.acc_).tobytes())
         if first.setdefault(key2, crc) != crc:
             print(f"MISMATCH at iteration {it}: {key2} film differs from its first render"); sys.exit(2)
+        # round 6: the same frame through a callback per pass -- ONE progressive launch (k_render_paths<PROG> + k_resolve_progressive), the pass
+        # size varying -- and, every third iteration, cancelled from another thread at a varying moment: the film must then be exactly the
+        # strata [0, currentSample_) (a render of that range, bit for bit)
+        prog = jtx.StaticCamera(W, H, data.camera, xs, 2, 4); prog.samplesPerPass_ = 1 + it % 2
+        seen = []
+        prog.render(sc, count_rays=False, progress=lambda c, t: seen.append(c))
+        if zlib.crc32(np.ascontiguousarray(prog.acc_).tobytes()) != crc or seen[-1] != 2 * xs:
+            print(f"MISMATCH at iteration {it}: {key2} progressive film differs"); sys.exit(2)
+        if it % 3 == 2:
+            import threading
+            timer = threading.Timer(0.0002 * (1 + it % 11), prog.terminateRender)
+            timer.start(); prog.render(sc, count_rays=False, progress=lambda c, t: None); timer.join()
+            n = prog.currentSample_
+            part = jtx.StaticCamera(W, H, data.camera, xs, 2, 4)
+            if n:
+                part.render(sc, count_rays=False, sample_begin=0, sample_end=n)
+            if not (np.array_equal(prog.acc_.view(np.uint32), part.acc_.view(np.uint32)) and np.array_equal(prog.img_, part.img_)):
+                print(f"MISMATCH at iteration {it}: {key2} cancelled progressive film is not the strata [0, {n})"); sys.exit(2)
+            part._unpin(); del part
+        prog._unpin(); del prog
         if it % 5 == 4:
-            # the same frame through a preview per pass (three passes in flight, per-residue streams and preview buffers) ...
-            prog = jtx.StaticCamera(W, H, data.camera, xs, 2, 4); prog.samplesPerPass_ = 1
-            prog.render(sc, count_rays=False, progress=lambda c, t: None)
-            if zlib.crc32(np.ascontiguousarray(prog.acc_).tobytes()) != crc:
-                print(f"MISMATCH at iteration {it}: {key2} progressive film differs"); sys.exit(2)
-            prog._unpin()
             # ... and four frames in flight on three streams / frame slots, the scene destroyed right behind them
             dev = torch.device("cuda", 0)
             pipe = jtx.distributed.ShardPipeline(sc, data.camera_desc(W, H, xs, 2, 4), 0, 1, dev, None, integrator=1)
