@@ -1753,7 +1753,10 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         bool cancelled = false;
         int done = sb;                                                          // strata whose sums are in the film of every pixel
         static const int progressiveOn = [] { const char *e = getenv("JTX_PROGRESSIVE_LAUNCH"); return e ? atoi(e) : 1; }();
-        if (cb && tick < se - sb && progressiveOn && usesPathKernel(*s, o)) {
+        const int tilesAll = ((cam->width + 31) / 32) * ((cam->height + 31) / 32);
+        const int shardWorld = o.tile_world > 1 ? o.tile_world : 1, shardRank = o.tile_world > 1 ? o.tile_rank : 0;
+        const bool ownsTiles = shardRank >= 0 && shardRank < tilesAll;                // (a shard without tiles launches nothing: pass by pass below)
+        if (cb && tick < se - sb && progressiveOn && ownsTiles && usesPathKernel(*s, o)) {
             // ---- PROGRESSIVE (round 6): ONE launch for all passes, whatever samplesPerPass_ is (before: a launch, a resolve, a preview copy and
             // a host turn-around per pass -- 46.5 ms per C2 frame at samplesPerPass_ = 1 for a 22.7 ms kernel).  k_render_paths<.., PROG> traces
             // pass after pass; k_resolve_progressive, beside it, adds every pass that is complete to the film and the preview and says, in
@@ -1771,8 +1774,7 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                 HIPCHK(hipStreamCreateWithPriority(&s->resolve_stream, hipStreamNonBlocking, greatest));
             }
             Drain drain{s->stream, s->resolve_stream, s->copy_stream};
-            const int world = o.tile_world > 1 ? o.tile_world : 1, rank = o.tile_world > 1 ? o.tile_rank : 0;
-            const int tiles = ((cam->width + 31) / 32) * ((cam->height + 31) / 32);
+            const int world = shardWorld, rank = shardRank, tiles = tilesAll;
             const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
             size_t maxRad = kMaxRadBytes;
             { const char *e = getenv("JTX_MAX_RAD_MB"); if (e && atol(e) > 0) maxRad = (size_t) atol(e) << 20; }

@@ -2112,6 +2112,11 @@ def test_progressive_launch_of_a_tile_shard_with_previews(gpu, cornell_pair):
         assert not cam.img_[~mine].any() and not cam.acc_[~mine].any()
         assert_same_f32(cam.acc_[mine], whole.acc_[mine], f"shard {rank} of 3, progressive")
         assert (cam.img_[mine] == whole.img_[mine]).all()
+    # a shard WITHOUT tiles (more ranks than 32x32 tiles: 28 tiles here, rank 30 of 32): nothing to launch, every callback, an empty film
+    none = gpu.StaticCamera(W, H, data.camera, 4, 3, 4); none.samplesPerPass_ = 4
+    seen = []
+    none.render(sc, tile_rank=30, tile_world=32, progress=lambda c, t: seen.append(c))
+    assert seen == [4, 8, 12] and not none.acc_.any() and not none.img_.any()
     odd = gpu.StaticCamera(W, H, data.camera, 4, 3, 4); odd.samplesPerPass_ = 5
     seen = []
     odd.render(sc, progress=lambda c, t: seen.append(c))
