@@ -2122,6 +2122,19 @@ def test_progressive_launch_of_a_tile_shard_with_previews(gpu, cornell_pair):
     odd.render(sc, progress=lambda c, t: seen.append(c))
     assert seen == [5, 10, 12]
     assert_same_f32(odd.acc_, whole.acc_, "passes of 5 strata, the last one shorter"); assert (odd.img_ == whole.img_).all()
+    # a RESUMED progressive render (the film of strata [0, 5) uploaded, [5, 12) in passes of 2) and one whose records do not fit the cap
+    # (1 MB holds two strata of this frame: four progressive launches, one after the other)
+    res = gpu.StaticCamera(W, H, data.camera, 4, 3, 4); res.samplesPerPass_ = 2
+    res.render(sc, sample_begin=0, sample_end=5)
+    seen = []
+    res.render(sc, sample_begin=5, sample_end=12, progress=lambda c, t: seen.append(c))
+    assert seen == [7, 9, 11, 12]
+    assert_same_f32(res.acc_, whole.acc_, "resumed progressive render"); assert (res.img_ == whole.img_).all()
+    cap = gpu.StaticCamera(W, H, data.camera, 4, 3, 4); cap.samplesPerPass_ = 1
+    seen = []
+    cap.render(sc, progress=lambda c, t: seen.append(c), max_record_mb=1)
+    assert seen == list(range(1, 13))
+    assert_same_f32(cap.acc_, whole.acc_, "progressive render under a 1 MB record cap"); assert (cap.img_ == whole.img_).all()
 
 
 _ONE_STREAM_CHILD = r"""
