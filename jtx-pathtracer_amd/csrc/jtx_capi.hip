@@ -924,9 +924,6 @@ void launchWavefront(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_m
     kt.collect();
 }
 
-// One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
-// beforeResolve (jtx_mi_render, several passes in flight): the event behind the previous pass's resolve -- this pass's resolve adds to the same
-// film and must follow it; prevWork: that pass's chunk counter (RenderParams::prev_work).
 // Does this render go through the persistent path kernel (working memory per frame slot)?  Everything else -- counting launches, the alternate
 // Li, integrator 2, JTX_DYNAMIC_PATHS=0 -- uses per-scene singletons.
 bool usesPathKernel(const jtx_mi_scene &s, const jtx_mi_render_opts &o) {
@@ -936,12 +933,12 @@ bool usesPathKernel(const jtx_mi_scene &s, const jtx_mi_render_opts &o) {
     return !alt && integ == 1 && dynamicPaths && o.count_rays == 0;
 }
 
+// One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
 // prog != nullptr: a PROGRESSIVE launch -- all passes of [sb, se) in one k_render_paths<.., PROG> launch on `stream`, k_resolve_progressive beside it
 // on the scene's resolver stream (the caller has checked that the persistent path kernel takes this render and that the range's records fit)
 struct ProgLaunch { int tick = 1; int resolver_wgs = 0; int spg = 1, groups = 0; unsigned epoch = 0; };     // in: tick, resolver_wgs, spg; out: groups, epoch
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
                   float *d_acc, unsigned char *d_img, hipStream_t stream, ProgLaunch *prog = nullptr) {
-    hipEvent_t beforeResolve = nullptr; unsigned *prevWork = nullptr; const int gridShare = 1;
     const int slot = o.frame_slot;
     if (slot < 0 || slot >= JTX_MI_FRAME_SLOTS) throw std::runtime_error("frame_slot: 0 .. " + std::to_string(JTX_MI_FRAME_SLOTS - 1));
     if (o.integrator < 0 || o.integrator > 2) throw std::runtime_error("integrator: 0 (auto), 1 (pixel-persistent) or 2 (HBM wavefront)");
@@ -1130,12 +1127,11 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 HIPCHK(hipMemsetAsync(q.work, 0, sizeof(unsigned), stream));
                 s.abandon_host[ring] = 0u;                                 // (this launch's resolve is the only writer, and it has not been enqueued yet)
                 q.abandoned = s.abandon_dev + ring;
-                q.prev_work = rec.parts.empty() ? prevWork : rec.parts.back().work;
+                q.prev_work = rec.parts.empty() ? nullptr : rec.parts.back().work;      // (a pass split by the record cap: its launches enter the film in order or not at all)
                 rec.last_work = q.work;
                 rec.parts.push_back({q.work, s.abandon_host + ring, q.sample_begin, q.sample_end});
-                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream, gridShare));
+                HIPCHK(jtx_launch_render_paths(q, owned, s.num_cus, stream));
                 if (q.sample_end == se) { HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true; }   // kernel_time: without the last resolve
-                if (beforeResolve && b0 == sb) HIPCHK(hipStreamWaitEvent(stream, beforeResolve, 0));      // the film: behind the previous pass's resolve
                 HIPCHK(jtx_launch_resolve_samples(q, owned, stream));
             }
         } else if (groups > 1) {
