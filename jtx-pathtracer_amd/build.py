@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libjtx_mi.so")
 SOURCES = ["jtx_kernels.hip", "jtx_alt.hip", "jtx_wavefront.hip", "jtx_capi.hip", "jtx_multi.hip", "jtx_refit.hip", "jtx_build_dev.hip", "jtx_bvh_build.cpp", "jtx_jpeg.cpp", "jtx_exr.cpp", "jtx_png.cpp"]
-HEADERS = ["jtx_device_math.hpp", "jtx_bxdf.hpp", "jtx_scene_dev.hpp", "jtx_launch.hpp", "jtx_host.hpp", "jtx_tiles.hpp", "jtx_wide_quant.hpp", "jtx_inflate.hpp", "jtx_profile.hpp", "jtx_profile_readers.hpp",
+HEADERS = ["jtx_device_math.hpp", "jtx_bxdf.hpp", "jtx_scene_dev.hpp", "jtx_launch.hpp", "jtx_host.hpp", "jtx_tiles.hpp", "jtx_wide_quant.hpp", "jtx_inflate.hpp", "jtx_profile.hpp", "jtx_profile_readers.hpp", "jtx_progressive.hpp",
            os.path.join("..", "..", "include", "jtx_mi.h")]
 # -ffp-contract=off: device results must equal the strict-fp32 CPU oracle bit for bit.
 # -fno-slp-vectorize: the SLP vectoriser turns pairs of fp32 operations into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32.  On gfx950 a packed

@@ -6,6 +6,7 @@
 #include "jtx_host.hpp"
 #include "jtx_launch.hpp"
 #include "jtx_wide_quant.hpp"
+#include "jtx_progressive.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -936,7 +937,7 @@ bool usesPathKernel(const jtx_mi_scene &s, const jtx_mi_render_opts &o) {
 // One launch of the integrator over [sb, se) on `stream`, bracketed by HIP events on that stream.
 // prog != nullptr: a PROGRESSIVE launch -- all passes of [sb, se) in one k_render_paths<.., PROG> launch on `stream`, k_resolve_progressive beside it
 // on the scene's resolver stream (the caller has checked that the persistent path kernel takes this render and that the range's records fit)
-struct ProgLaunch { int tick = 1; int resolver_wgs = 0; int spg = 1, groups = 0; unsigned epoch = 0; };     // in: tick, resolver_wgs, spg; out: groups, epoch
+struct ProgLaunch { int tick = 1; int resolver_wgs = 0; int spg = 1, groups = 0; unsigned epoch = 0; int extra_leave_waves = 0; };     // in: tick, resolver_wgs, spg, extra_leave_waves; out: groups, epoch
 void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int sb, int se,
                   float *d_acc, unsigned char *d_img, hipStream_t stream, ProgLaunch *prog = nullptr) {
     const int slot = o.frame_slot;
@@ -1067,7 +1068,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 prog->groups = q.num_groups;
                 if (q.num_groups > 32767) throw std::runtime_error("progressive launch: more than 32767 strata groups (raise samples_per_tick)");
                 q.prog_groups_per_pass = prog->tick > prog->spg ? prog->tick / prog->spg : 1;
-                const int leave = jtx_resolve_progressive_waves(prog->resolver_wgs);
+                const int leave = jtx_resolve_progressive_waves(prog->resolver_wgs) + prog->extra_leave_waves;
                 const int nwaves = jtx_render_paths_waves(q, s.num_cus, 1, leave);
                 // the chunk counter, the closed-at word, the resolver leader's word and the waves' words on cache lines of their own: the
                 // counter takes every fetch of every wave, and a poll of a word on ITS line queues up with them
@@ -1153,6 +1154,79 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
 }
 
 } // namespace
+
+// ---- one progressive launch (jtx_progressive.hpp): shared by jtx_mi_render and jtx_mi_multi_render ----
+bool jtx_prog_usable(jtx_mi_scene *s, const jtx_mi_render_opts &o) {
+    static const int progressiveOn = [] { const char *e = getenv("JTX_PROGRESSIVE_LAUNCH"); return e ? atoi(e) : 1; }();
+    return progressiveOn && usesPathKernel(*s, o);
+}
+
+static int progOwnedTiles(const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o) {
+    const int tiles = ((cam.width + 31) / 32) * ((cam.height + 31) / 32);
+    const int world = o.tile_world > 1 ? o.tile_world : 1, rank = o.tile_world > 1 ? o.tile_rank : 0;
+    return (rank >= 0 && tiles > rank) ? (tiles - rank + world - 1) / world : 0;
+}
+
+long jtx_prog_span(jtx_mi_scene *, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int tick) {
+    const int owned = progOwnedTiles(cam, o);
+    size_t maxRad = kMaxRadBytes;
+    { const char *e = getenv("JTX_MAX_RAD_MB"); if (e && atol(e) > 0) maxRad = (size_t) atol(e) << 20; }
+    if (o.max_record_mb > 0) maxRad = (size_t) o.max_record_mb << 20;
+    const size_t rowBytes = (size_t) (owned > 0 ? owned : 1) * 1024 * sizeof(float4);
+    const long perLaunch = (long) (maxRad / rowBytes) / tick * tick;          // whole passes
+    if (perLaunch < tick) throw std::runtime_error("one pass of " + std::to_string(tick) + " strata does not fit the radiance-record cap: raise max_record_mb or lower samples_per_tick");
+    return perLaunch;
+}
+
+void jtx_prog_begin(jtx_mi_scene *s, const jtx_mi_camera_desc &cam, const jtx_mi_render_opts &o, int b0, int e0, int tick, float *d_acc, unsigned char *d_img,
+                    hipStream_t stream, int extra_leave_waves, bool locked, JtxProgRun &run) {
+    std::unique_lock<std::mutex> lk(s->mu, std::defer_lock);
+    if (locked) lk.lock();
+    DeviceGuard dg(s->device);
+    const int owned = progOwnedTiles(cam, o);
+    run = JtxProgRun{};
+    run.begin = b0; run.end = e0; run.tick = tick;
+    if (owned == 0) { run.nothing = true; return; }
+    static const int resolverEnv = [] { const char *e = getenv("JTX_RESOLVER_WGS"); return e ? atoi(e) : 0; }();
+    int nr = resolverEnv > 0 ? resolverEnv : 64;                        // one watches the path waves, the others add passes
+    if (nr > kResolverMax) nr = kResolverMax;
+    if (nr > owned * 4 + 1) nr = owned * 4 + 1;                         // (a worker per 256 pixel slots at most)
+    if (nr < 2) nr = 2;
+    ProgLaunch pl; pl.tick = tick; pl.resolver_wgs = nr; pl.extra_leave_waves = extra_leave_waves;
+    // strata per group (= per chunk of an 8x8 block, and the step in which the film advances): a pass; a whole fraction of one
+    // when passes are long and the launch would have few chunks; SEVERAL short passes when a pass alone makes chunks too small
+    // for the persistent waves (C2, one stratum per chunk: kernel 25.2 ms against 22.7 at eight) -- the callback still runs
+    // once per pass, the film and the preview then advance every few passes (at C2's 0.36 ms per pass, far above any display
+    // rate: the reference's UI polls currentSample_ once per frame it draws, display.cpp:700-706)
+    static const int minStrata = [] { const char *e = getenv("JTX_PROG_MIN_STRATA"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+    pl.spg = tick;
+    if ((e0 - b0) % tick == 0) while (pl.spg % 2 == 0 && pl.spg >= 16 && (long) owned * 16 * ((e0 - b0) / pl.spg) < 250000) pl.spg /= 2;
+    while (pl.spg < minStrata && pl.spg * 2 <= e0 - b0) pl.spg += tick;
+    launchRender(*s, cam, o, b0, e0, d_acc, d_img, stream, &pl);
+    run.spg = pl.spg; run.groups = pl.groups; run.resolver_wgs = nr; run.epoch = pl.epoch;
+}
+
+int jtx_prog_completed(jtx_mi_scene *s, const JtxProgRun &run, bool *gave_up) {
+    if (run.nothing) return run.end;
+    unsigned g = 0x7fffu;
+    for (int w = 0; w < run.resolver_wgs; ++w) {
+        const unsigned v = __atomic_load_n(s->prog_host + kResolverMax + w, __ATOMIC_ACQUIRE);
+        const bool mine = (v >> 16) == run.epoch;
+        const unsigned gw = mine ? (v & 0x7fffu) : 0u;
+        if (mine && (v & 0x8000u) && gave_up) *gave_up = true;
+        g = gw < g ? gw : g;
+    }
+    const long d = (long) run.begin + (long) g * run.spg;               // (the resolver adds whole passes only)
+    return d < run.end ? (int) d : run.end;
+}
+
+bool jtx_prog_finished(jtx_mi_scene *s) {
+    if (!s->prog_resolved || !s->prog_paths_done) return true;
+    DeviceGuard dg(s->device);
+    const bool f = hipEventQuery(s->prog_resolved) == hipSuccess && hipEventQuery(s->prog_paths_done) == hipSuccess;
+    (void) hipGetLastError();
+    return f;
+}
 
 extern "C" {
 
@@ -1748,11 +1822,9 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
         auto lap = [&](const char *what) { if (trace) { const double t = now(); fprintf(stderr, "[jtx_mi_render] %-18s %8.3f ms\n", what, t - tMark); tMark = t; } };
         bool cancelled = false;
         int done = sb;                                                          // strata whose sums are in the film of every pixel
-        static const int progressiveOn = [] { const char *e = getenv("JTX_PROGRESSIVE_LAUNCH"); return e ? atoi(e) : 1; }();
-        const int tilesAll = ((cam->width + 31) / 32) * ((cam->height + 31) / 32);
-        const int shardWorld = o.tile_world > 1 ? o.tile_world : 1, shardRank = o.tile_world > 1 ? o.tile_rank : 0;
-        const bool ownsTiles = shardRank >= 0 && shardRank < tilesAll;                // (a shard without tiles launches nothing: pass by pass below)
-        if (cb && tick < se - sb && progressiveOn && ownsTiles && usesPathKernel(*s, o)) {
+        jtx_mi_render_opts oSlot0 = o; oSlot0.frame_slot = 0; oSlot0.sequence_end = 1;
+        const bool ownsTiles = progOwnedTiles(*cam, o) > 0;                           // (a shard without tiles launches nothing: pass by pass below)
+        if (cb && tick < se - sb && ownsTiles && jtx_prog_usable(s, o)) {
             // ---- PROGRESSIVE (round 6): ONE launch for all passes, whatever samplesPerPass_ is (before: a launch, a resolve, a preview copy and
             // a host turn-around per pass -- 46.5 ms per C2 frame at samplesPerPass_ = 1 for a 22.7 ms kernel).  k_render_paths<.., PROG> traces
             // pass after pass; k_resolve_progressive, beside it, adds every pass that is complete to the film and the preview and says, in
@@ -1770,54 +1842,19 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                 HIPCHK(hipStreamCreateWithPriority(&s->resolve_stream, hipStreamNonBlocking, greatest));
             }
             Drain drain{s->stream, s->resolve_stream, s->copy_stream};
-            const int world = shardWorld, rank = shardRank, tiles = tilesAll;
-            const int owned = tiles > rank ? (tiles - rank + world - 1) / world : 0;
-            size_t maxRad = kMaxRadBytes;
-            { const char *e = getenv("JTX_MAX_RAD_MB"); if (e && atol(e) > 0) maxRad = (size_t) atol(e) << 20; }
-            if (o.max_record_mb > 0) maxRad = (size_t) o.max_record_mb << 20;
-            const size_t rowBytes = (size_t) (owned > 0 ? owned : 1) * 1024 * sizeof(float4);
-            long perLaunch = (long) (maxRad / rowBytes) / tick * tick;          // whole passes
-            if (perLaunch < tick) throw std::runtime_error("one pass of " + std::to_string(tick) + " strata does not fit the radiance-record cap: raise max_record_mb or lower samples_per_tick");
-            static const int resolverEnv = [] { const char *e = getenv("JTX_RESOLVER_WGS"); return e ? atoi(e) : 0; }();
-            int nr = resolverEnv > 0 ? resolverEnv : 64;                        // one watches the path waves, the others add passes
-            if (nr > kResolverMax) nr = kResolverMax;
-            if (nr > owned * 4 + 1) nr = owned * 4 + 1;                         // (a worker per 256 pixel slots at most)
-            if (nr < 2) nr = 2;
+            const long perLaunch = jtx_prog_span(s, *cam, o, tick);
             int reported = sb;                                                  // strata the callback has been told of
             bool stopAsked = false;
             for (int b0 = sb; b0 < se && !cancelled; ) {
                 const int e0 = (long) b0 + perLaunch < se ? b0 + (int) perLaunch : se;
-                ProgLaunch pl; pl.tick = tick; pl.resolver_wgs = nr;
-                // strata per group (= per chunk of an 8x8 block, and the step in which the film advances): a pass; a whole fraction of one
-                // when passes are long and the launch would have few chunks; SEVERAL short passes when a pass alone makes chunks too small
-                // for the persistent waves (C2, one stratum per chunk: kernel 25.2 ms against 22.7 at eight) -- the callback still runs
-                // once per pass, the film and the preview then advance every few passes (at C2's 0.36 ms per pass, far above any display
-                // rate: the reference's UI polls currentSample_ once per frame it draws, display.cpp:700-706)
-                static const int minStrata = [] { const char *e = getenv("JTX_PROG_MIN_STRATA"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
-                pl.spg = tick;
-                if ((e0 - b0) % tick == 0) while (pl.spg % 2 == 0 && pl.spg >= 16 && (long) owned * 16 * ((e0 - b0) / pl.spg) < 250000) pl.spg /= 2;
-                while (pl.spg < minStrata && pl.spg * 2 <= e0 - b0) pl.spg += tick;
-                jtx_mi_render_opts o2 = o; o2.frame_slot = 0; o2.sequence_end = 1;
-                launchRender(*s, *cam, o2, b0, e0, s->film_acc.p, dimg, s->stream, &pl);
+                JtxProgRun run;
+                jtx_prog_begin(s, *cam, oSlot0, b0, e0, tick, s->film_acc.p, dimg, s->stream, 0, false, run);
                 lap("enqueue");
                 bool resolverGaveUp = false;
-                auto completed = [&] {                                          // strata of this launch that are in the film of every pixel: whole passes
-                    unsigned g = 0x7fffu;
-                    for (int w = 0; w < nr; ++w) {
-                        const unsigned v = __atomic_load_n(s->prog_host + kResolverMax + w, __ATOMIC_ACQUIRE);
-                        const unsigned gw = (v >> 16) == pl.epoch ? (v & 0x7fffu) : 0u;
-                        if ((v >> 16) == pl.epoch && (v & 0x8000u)) resolverGaveUp = true;
-                        g = gw < g ? gw : g;
-                    }
-                    if (owned == 0) g = (unsigned) pl.groups;
-                    const long d = (long) b0 + (long) g * pl.spg;               // (the resolver adds whole passes only)
-                    return d < e0 ? (int) d : e0;
-                };
                 unsigned idle = 0;
                 while (true) {
-                    const bool finished = hipEventQuery(s->prog_resolved) == hipSuccess && hipEventQuery(s->prog_paths_done) == hipSuccess;   // (first: the words read below are then final)
-                    (void) hipGetLastError();
-                    const int have = completed();
+                    const bool finished = jtx_prog_finished(s);                 // (first: the words read below are then final)
+                    const int have = jtx_prog_completed(s, run, &resolverGaveUp);
                     if (have > reported && !stopAsked) {
                         idle = 0;
                         if (img_rgb) {                                          // the preview as it stands, to (pinned) host memory
@@ -1838,12 +1875,11 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                     if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield();
                 }
                 HIPCHK(hipStreamSynchronize(s->stream));
-                (void) completed();
+                done = jtx_prog_completed(s, run, &resolverGaveUp);
                 if (resolverGaveUp) throw std::runtime_error("progressive launch: the resolver waited a minute for the path kernel and gave up (the film holds the passes added so far)");
 #ifdef JTX_DBG_PROG      /* diagnostic build: the resolver leader's log of (time, groups dealt, groups out of every wave's hands) */
                 { unsigned h[48]; HIPCHK(hipMemcpy(h, s->prog_ctl.p + 64 + 16, sizeof h, hipMemcpyDeviceToHost)); for (unsigned i = 0; i < h[0] && i < 14; ++i) fprintf(stderr, "[leader] t %8.3f ms dealt groups %u by waves %u\n", (h[1 + 3 * i] - h[1]) / 1000.0, h[2 + 3 * i], h[3 + 3 * i]); }
 #endif
-                done = completed();
                 if (done < e0 || stopAsked) cancelled = true;
                 b0 = e0;
                 lap("launch");
