@@ -310,7 +310,10 @@ int jtx_mi_get_counters(jtx_mi_scene *scene, jtx_mi_counters *out);  /* of the l
  * than once, its shards then share it).  jtx_mi_multi_render is jtx_mi_render over all of them: shard r renders the
  * 32x32 tiles k % n == r, pushes its own pixels to devices[0] over xGMI (one hipMemcpyPeerAsync pair per shard and pass)
  * and devices[0] assembles the frame -- the same bytes one device renders alone.  Same progress / cancellation contract
- * as jtx_mi_render (jtx_mi_multi_cancel from any thread); count_rays and sample_begin > 0 are not supported here. */
+ * as jtx_mi_render (jtx_mi_multi_cancel from any thread); count_rays and sample_begin > 0 are not supported here.
+ * With a callback every shard traces all passes in ONE progressive launch (as jtx_mi_render does); the frame's current_sample is the
+ * minimum over the shards, previews are exchanged when it has advanced, the exact film once at the end; after a stop the shards that
+ * ended behind the furthest one render on to it, so that every pixel of the frame holds the same strata [0, n). */
 typedef struct jtx_mi_multi jtx_mi_multi;
 int  jtx_mi_multi_create(const jtx_mi_scene_desc *desc, const int32_t *devices, int32_t n_devices, jtx_mi_multi **out);
 void jtx_mi_multi_destroy(jtx_mi_multi *m);

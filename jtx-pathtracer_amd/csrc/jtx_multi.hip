@@ -14,6 +14,9 @@
 // A device may be listed more than once (shards then share it): that is how the whole path runs on a one-GPU box.
 #include "jtx_host.hpp"
 #include "jtx_tiles.hpp"
+#include "jtx_progressive.hpp"
+#include <chrono>
+#include <thread>
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdexcept>
@@ -52,7 +55,7 @@ __global__ void __launch_bounds__(256) k_scatter_shard(const float *slab_acc, co
     int row, col;
     if (!jtx::slotToPixel(slot, rank, world, width, height, row, col)) return;
     const size_t pix = (size_t) row * width + col;
-    acc[3 * pix] = slab_acc[3 * (size_t) slot]; acc[3 * pix + 1] = slab_acc[3 * (size_t) slot + 1]; acc[3 * pix + 2] = slab_acc[3 * (size_t) slot + 2];
+    if (acc) { acc[3 * pix] = slab_acc[3 * (size_t) slot]; acc[3 * pix + 1] = slab_acc[3 * (size_t) slot + 1]; acc[3 * pix + 2] = slab_acc[3 * (size_t) slot + 2]; }
     if (img) { img[3 * pix] = slab_img[3 * (size_t) slot]; img[3 * pix + 1] = slab_img[3 * (size_t) slot + 1]; img[3 * pix + 2] = slab_img[3 * (size_t) slot + 2]; }
 }
 
@@ -60,6 +63,7 @@ struct Shard {
     int device = 0;
     jtx_mi_scene *scene = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t xstream = nullptr;                                 // progressive renders: packs and pushes previews while `stream` carries the launch
     float *acc = nullptr; unsigned char *img = nullptr;            // full-size film of this shard (own pixels, zero elsewhere)
     float *slab_acc = nullptr; unsigned char *slab_img = nullptr;  // on this device
     float *recv_acc = nullptr; unsigned char *recv_img = nullptr;  // on device 0
@@ -95,6 +99,7 @@ void releaseShard(Shard &s, int rootDevice) {
         if (s.slab_img) (void) hipFree(s.slab_img);
         if (s.scene) jtx_mi_scene_destroy(s.scene);
         if (s.stream) (void) hipStreamDestroy(s.stream);
+        if (s.xstream) { (void) hipStreamSynchronize(s.xstream); (void) hipStreamDestroy(s.xstream); }
         if (s.staged) (void) hipEventDestroy(s.staged);
         if (s.stage_acc) (void) hipHostFree(s.stage_acc);
         if (s.stage_img) (void) hipHostFree(s.stage_img);
@@ -172,6 +177,7 @@ int jtx_mi_multi_create(const jtx_mi_scene_desc *desc, const int32_t *devices, i
             MHIPCHK(hipSetDevice(s.device));
             MCHK(jtx_mi_scene_create(desc, &s.scene));                   // the scene is replicated
             MHIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            MHIPCHK(hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking));
         }
         // peer access to device 0 for the slab pushes (a no-op between shards of one device; not fatal when the platform
         // refuses it: hipMemcpyPeerAsync then stages through the host)
@@ -256,6 +262,140 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
           MHIPCHK(hipMemsetAsync(m->frame_img, 0, npix * 3, root.stream)); }
         bool cancelled = false;
         int done = sb;
+        bool progressive = cb && tick < se - sb;
+        for (int r = 0; r < n && progressive; ++r) progressive = jtx_prog_usable(m->shards[r].scene, o);
+        if (progressive) {
+            // ---- PROGRESSIVE (round 6): every shard traces ALL passes in one launch (k_render_paths<.., PROG> + its resolver, jtx_progressive.hpp) instead
+            // of 64 x {launch per shard, pack, push, wait for all, scatter}.  This thread watches the shards: the frame's currentSample_ is the
+            // minimum over them; when it has advanced, the shards' previews are packed and pushed on their exchange streams (the launch
+            // streams are busy), scattered on device 0 and copied to the host, and the callback runs once per pass.  The exact film crosses
+            // once, at the end.  A stop leaves the shards at different passes (each ends at a pass boundary of its own): strata can be added to
+            // a film, not taken out, so the shards that are behind render on to the furthest one -- the frame then holds exactly [0, n).
+            std::vector<JtxProgRun> runs(n);
+            auto exchange = [&](bool withFilm) {
+                for (int r = 0; r < n; ++r) {
+                    Shard &s = m->shards[r];
+                    if (!s.slab_slots) continue;
+                    SetDev sd(s.device);
+                    const int nslots = (int) s.slab_slots;
+                    hipLaunchKernelGGL(k_pack_shard, dim3((nslots + 255) / 256), dim3(256), 0, s.xstream, s.acc, img_rgb ? s.img : nullptr, s.slab_acc,
+                                       s.slab_img, nslots, r, n, W, H);
+                    MHIPCHK(hipGetLastError());
+                    if (r > 0 && s.peer) {
+                        if (withFilm) MHIPCHK(hipMemcpyPeerAsync(s.recv_acc, root.device, s.slab_acc, s.device, s.slab_slots * 3 * sizeof(float), s.xstream));
+                        if (img_rgb) MHIPCHK(hipMemcpyPeerAsync(s.recv_img, root.device, s.slab_img, s.device, s.slab_slots * 3, s.xstream));
+                    } else if (r > 0) {
+                        if (withFilm) MHIPCHK(hipMemcpyAsync(s.stage_acc, s.slab_acc, s.slab_slots * 3 * sizeof(float), hipMemcpyDeviceToHost, s.xstream));
+                        if (img_rgb) MHIPCHK(hipMemcpyAsync(s.stage_img, s.slab_img, s.slab_slots * 3, hipMemcpyDeviceToHost, s.xstream));
+                        MHIPCHK(hipStreamSynchronize(s.xstream));
+                        SetDev sr(root.device);
+                        if (withFilm) MHIPCHK(hipMemcpyAsync(s.recv_acc, s.stage_acc, s.slab_slots * 3 * sizeof(float), hipMemcpyHostToDevice, root.xstream));
+                        if (img_rgb) MHIPCHK(hipMemcpyAsync(s.recv_img, s.stage_img, s.slab_slots * 3, hipMemcpyHostToDevice, root.xstream));
+                    }
+                }
+                for (int r = 0; r < n; ++r) { SetDev sd(m->shards[r].device); MHIPCHK(hipStreamSynchronize(m->shards[r].xstream)); }
+                SetDev sd(root.device);
+                for (int r = 0; r < n; ++r) {
+                    Shard &s = m->shards[r];
+                    if (!s.slab_slots) continue;
+                    const int nslots = (int) s.slab_slots;
+                    hipLaunchKernelGGL(k_scatter_shard, dim3((nslots + 255) / 256), dim3(256), 0, root.xstream, r ? s.recv_acc : s.slab_acc,
+                                       r ? s.recv_img : s.slab_img, withFilm ? m->frame_acc : nullptr, img_rgb ? m->frame_img : nullptr, nslots, r, n, W, H);
+                    MHIPCHK(hipGetLastError());
+                }
+                if (img_rgb) jtx_capi_d2h(img_rgb, m->frame_img, 3 * npix, root.xstream);
+                MHIPCHK(hipStreamSynchronize(root.xstream));
+            };
+            long span = se - sb;
+            for (int r = 0; r < n; ++r) {
+                jtx_mi_render_opts q = o; q.tile_rank = r; q.tile_world = n;
+                const long sp = jtx_prog_span(m->shards[r].scene, *cam, q, tick);
+                span = sp < span ? sp : span;
+            }
+            int reported = sb;
+            bool stopAsked = false;
+            for (int b0 = sb; b0 < se && !cancelled; ) {
+                const int e0 = (long) b0 + span < se ? b0 + (int) span : se;
+                for (int r = 0; r < n; ++r) {
+                    Shard &s = m->shards[r];
+                    if (!s.slab_slots) { runs[r] = JtxProgRun{}; runs[r].begin = b0; runs[r].end = e0; runs[r].nothing = true; continue; }
+                    SetDev sd(s.device);
+                    if (b0 == sb) {                          // pixels of other shards read as exactly 0 (the slabs carry own pixels only; the films stay clean)
+                        MHIPCHK(hipMemsetAsync(s.acc, 0, npix * 3 * sizeof(float), s.stream));
+                        MHIPCHK(hipMemsetAsync(s.img, 0, npix * 3, s.stream));
+                    }
+                    jtx_mi_render_opts q = o; q.tile_rank = r; q.tile_world = n; q.frame_slot = 0; q.sequence_end = 1;
+                    jtx_prog_begin(s.scene, *cam, q, b0, e0, tick, s.acc, s.img, s.stream, 128, true, runs[r]);
+                }
+                bool gaveUp = false;
+                unsigned idle = 0;
+                while (true) {
+                    bool finished = true;
+                    for (int r = 0; r < n; ++r) if (!runs[r].nothing) finished = finished && jtx_prog_finished(m->shards[r].scene);     // (first: the words read below are then final)
+                    int have = e0;
+                    for (int r = 0; r < n; ++r) { const int d = jtx_prog_completed(m->shards[r].scene, runs[r], &gaveUp); have = d < have ? d : have; }
+                    if (have > reported && !stopAsked) {
+                        idle = 0;
+                        if (img_rgb) exchange(false);        // the previews as they stand
+                        while (reported < have && !stopAsked) {
+                            reported = reported + tick < have ? reported + tick : have;
+                            if (cb(reported, spp, user)) { stopAsked = true; for (int r = 0; r < n; ++r) jtx_mi_cancel(m->shards[r].scene); }
+                        }
+                    }
+                    if (finished) break;
+                    if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield();
+                }
+                for (int r = 0; r < n; ++r) { SetDev sd(m->shards[r].device); MHIPCHK(hipStreamSynchronize(m->shards[r].stream)); }
+                if (gaveUp) throw std::runtime_error("progressive launch: a shard's resolver waited a minute for its path kernel and gave up");
+                int lo = e0, hi = b0;
+                std::vector<int> at(n, e0);
+                for (int r = 0; r < n; ++r) {
+                    if (runs[r].nothing) continue;
+                    at[r] = jtx_prog_completed(m->shards[r].scene, runs[r], &gaveUp);
+                    lo = at[r] < lo ? at[r] : lo; hi = at[r] > hi ? at[r] : hi;
+                }
+                if (lo < e0 || stopAsked) {
+                    // stopped: the shards that are behind render on to the furthest one (batch launches on their resumed films; the stop word is
+                    // cleared for them -- a stop that arrives again meanwhile is honoured by the loop: they are rendered on until they stand)
+                    cancelled = true;
+                    if (hi < b0) hi = b0;
+                    for (int guard = 0; guard < 8; ++guard) {
+                        bool all = true;
+                        for (int r = 0; r < n; ++r) {
+                            Shard &s = m->shards[r];
+                            if (runs[r].nothing || at[r] >= hi) continue;
+                            all = false;
+                            SetDev sd(s.device);
+                            MCHK(jtx_mi_cancel_reset(s.scene));
+                            jtx_mi_render_opts q = o; q.tile_rank = r; q.tile_world = n; q.sample_begin = at[r]; q.sample_end = hi;
+                            MCHK(jtx_mi_render_device(s.scene, cam, &q, s.acc, s.img, s.stream));
+                        }
+                        if (all) break;
+                        for (int r = 0; r < n; ++r) {
+                            Shard &s = m->shards[r];
+                            if (runs[r].nothing || at[r] >= hi) continue;
+                            SetDev sd(s.device);
+                            MHIPCHK(hipStreamSynchronize(s.stream));
+                            int32_t flag = 0; MCHK(jtx_mi_cancel_pending(s.scene, &flag));
+                            if (flag != 2) at[r] = hi;       // (2: this catch-up launch was abandoned too -- once more)
+                        }
+                    }
+                    done = hi;
+                    break;
+                }
+                done = e0;
+                b0 = e0;
+            }
+            exchange(true);                                  // the exact film, once
+            {
+                SetDev sd(root.device);
+                jtx_capi_d2h(acc_rgb, m->frame_acc, sizeof(float) * 3 * npix, root.xstream);
+            }
+            for (int r = 0; r < n && r < 64; ++r) { float ms = 0; int32_t nl = 0; (void) jtx_mi_kernel_time(m->shards[r].scene, &ms, &nl); m->last_ms[r] = ms; }
+            m->last_completed = done;
+            if (prev >= 0) (void) hipSetDevice(prev);
+            return cancelled ? JTX_MI_CANCELLED : 0;
+        }
         for (int b = sb; b < se && !cancelled; b += tick) {
             const int e = b + tick < se ? b + tick : se;
             // ---- every device: its shard of this pass, pack, push to device 0 ----

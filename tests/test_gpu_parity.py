@@ -1108,12 +1108,21 @@ def test_multi_device_render_equals_one_device(gpu, cornell_pair, shards):
     assert ms.render(cam2, progress=lambda c, t: seen.append(c), samples_per_tick=3)
     assert seen == [3, 6, 8]
     assert_same_f32(cam2.acc_, ref.acc_, f"{shards} shards, 3 passes"); assert (cam2.img_ == ref.img_).all()
-    # cancellation by the callback after the first pass: the frame holds exactly that pass
+    # cancellation by the callback after the first pass: the frame holds exactly the strata it reports -- the pass of the callback, and whatever the
+    # shards' launches (round 6: every shard traces all passes in ONE progressive launch, which does not wait for the callback) had finished by
+    # then; shards that stopped behind the furthest one are rendered on to it, so that every pixel holds the same strata
     cam3 = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
     assert not ms.render(cam3, progress=lambda c, t: True, samples_per_tick=3)
-    part = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4); part.render(sc, sample_begin=0, sample_end=3)
-    assert cam3.currentSample_ == 3
-    assert_same_f32(cam3.acc_, part.acc_, "cancelled multi render"); assert (cam3.img_ == part.img_).all()
+    n = cam3.currentSample_
+    assert n in (3, 6, 8)
+    part = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4); part.render(sc, sample_begin=0, sample_end=n)
+    assert_same_f32(cam3.acc_, part.acc_, f"cancelled multi render ({n} strata)"); assert (cam3.img_ == part.img_).all()
+    # one stratum per pass (the reference's default): still one launch per shard
+    seen = []
+    cam4 = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
+    assert ms.render(cam4, progress=lambda c, t: seen.append(c), samples_per_tick=1)
+    assert seen == list(range(1, 9))
+    assert_same_f32(cam4.acc_, ref.acc_, f"{shards} shards, 8 passes"); assert (cam4.img_ == ref.img_).all()
     ms.destroy()
 
 
