@@ -37,13 +37,14 @@ def owned_tiles(width, height, rank, world):
 
 
 def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count_rays=False,
-                 sample_begin=0, sample_end=0, integrator=0, profile_kernels=False, frame_slot=0, sequence_end=False):
+                 sample_begin=0, sample_end=0, integrator=0, profile_kernels=False, frame_slot=0, sequence_end=False, max_record_mb=0):
     """Launch this rank's share of the frame into device tensors `acc` (H*W*3 f32) / `img` (H*W*3 u8).
 
     Asynchronous on `stream` (an int hipStream_t, e.g. torch.cuda.current_stream().cuda_stream).  `frame_slot` 0 .. FRAME_SLOTS - 1: that
     many frames of one scene may be in flight, one per slot, each on a stream and into a pair of film buffers of its own (jtx_mi.h:
     jtx_mi_render_opts).  Launches that use the scene's singletons instead of a slot's working memory -- count_rays, the wavefront
-    integrator, the alternate Li, JTX_DYNAMIC_PATHS=0 -- are ordered against EVERY slot by the library.
+    integrator, the alternate Li, JTX_DYNAMIC_PATHS=0 -- are ordered against EVERY slot by the library.  `max_record_mb`: the cap on one
+    launch's radiance records (0: 8 GiB; a frame above it goes in several launches of consecutive strata).
     """
     lib = capi.load()
     o = capi.RenderOpts()
@@ -54,6 +55,7 @@ def render_shard(scene, cam_desc, rank, world, acc, img=None, stream=None, count
     o.reserved = 1 if profile_kernels else 0
     o.frame_slot = frame_slot
     o.sequence_end = 1 if sequence_end else 0
+    o.max_record_mb = max_record_mb
     capi.check(lib.jtx_mi_render_device(scene.handle, C.byref(cam_desc), C.byref(o),
                                         C.c_void_p(acc.data_ptr()),
                                         C.c_void_p(img.data_ptr()) if img is not None else None,

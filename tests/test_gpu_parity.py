@@ -375,7 +375,7 @@ def _frame_on_device(gpu, sc, cam, integrator, **kw):
     st.wait_stream(torch.cuda.current_stream())      # the fills above ran on the default stream
     with torch.cuda.stream(st):
         gpu.distributed.render_shard(sc, cam, kw.get("rank", 0), kw.get("world", 1), acc, img, stream=st.cuda_stream,
-                                     integrator=integrator, count_rays=kw.get("count", False))
+                                     integrator=integrator, count_rays=kw.get("count", False), max_record_mb=kw.get("max_record_mb", 0))
     torch.cuda.synchronize()
     cnt = None
     if kw.get("count"):
@@ -1086,7 +1086,14 @@ def test_timed_launch_config4_shard_and_pass_split(gpu, atrium_full):
     rows2, cols2 = rs.randint(0, H, 16), rs.randint(0, W, 16)
     expect2 = _oracle_pixel_sums(osc, cam, rows2, cols2, spp)
     assert np.array_equal(acc_f[rows2, cols2].view(np.uint32), expect2.view(np.uint32))
-    del acc_s, acc_f
+    # (c) the same frame in ONE launch: the card holds the 34 GB of records (288 GB of HBM), the cap is the caller's to raise
+    #     (jtx_mi_render_opts.max_record_mb) -- the same film word for word, and the slot's memory is accounted and releasable
+    acc_1, img_1, _ = _frame_on_device(gpu, sc, cam, 1, max_record_mb=36 << 10)
+    assert np.array_equal(acc_1.view(np.uint32), acc_f.view(np.uint32)) and np.array_equal(img_1, img_f)
+    assert sc.info()["frame_slot_bytes"] >= W * H * spp * 16
+    sc.releaseFrames()
+    assert sc.info()["frame_slot_bytes"] == 0
+    del acc_s, acc_f, acc_1
     torch.cuda.empty_cache()
 
 
