@@ -772,8 +772,8 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
             if (complete >= p.num_groups) complete = p.num_groups;
             else complete = complete / p.prog_groups_per_pass * p.prog_groups_per_pass;    // whole passes only (a cancellation may end the launch inside one)
             bool last = allGone && dealtFinal;
-            // a bounded wait: the resolver runs BEFORE the path kernel is launched; should that launch never come (the host then closes the
-            // counter itself) or nothing move for a minute, it ends -- with the passes it has -- and says so
+            // a bounded wait: should nothing move for a minute -- no chunk fetched, no wave's word changed (a path launch that failed
+            // behind this one's enqueue, a path kernel that hangs) -- the resolver ends, with the passes it has, and says so
             const unsigned sig = shWord ^ (oldest * 0x9e3779b9u);
             const unsigned long long tNow = __builtin_amdgcn_s_memrealtime();
             if (sig != sigBefore) { sigBefore = sig; tMoved = tNow; }
