@@ -272,6 +272,7 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
             // once, at the end.  A stop leaves the shards at different passes (each ends at a pass boundary of its own): strata can be added to
             // a film, not taken out, so the shards that are behind render on to the furthest one -- the frame then holds exactly [0, n).
             std::vector<JtxProgRun> runs(n);
+            { SetDev sd(root.device); MHIPCHK(hipStreamSynchronize(root.stream)); }   // the frame is cleared before anything is scattered into it on the exchange stream
             auto exchange = [&](bool withFilm) {
                 for (int r = 0; r < n; ++r) {
                     Shard &s = m->shards[r];
@@ -380,6 +381,9 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
                             if (flag != 2) at[r] = hi;       // (2: this catch-up launch was abandoned too -- once more)
                         }
                     }
+                    for (int r = 0; r < n; ++r)
+                        if (!runs[r].nothing && at[r] < hi)
+                            throw std::runtime_error("jtx_mi_multi_render: stopped again during each of 8 attempts to bring the shards level; the frame is not consistent");
                     done = hi;
                     break;
                 }
