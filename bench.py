@@ -581,6 +581,17 @@ def rank_note(stage, **kw):
         pass
 
 
+def rank_wait_for_peers(world, seconds=10.0):
+    """(a rank about to stop with an error) give the other ranks time to write their first note: the launcher ends them as soon as one
+    rank has failed, and a rank still importing torch would then be missing from the failure record"""
+    d = os.environ.get("JTX_BENCH_DIAG_DIR")
+    if not d:
+        return
+    t0 = time.time()
+    while time.time() - t0 < seconds and not all(os.path.exists(os.path.join(d, f"rank{r}.json")) for r in range(world)):
+        time.sleep(0.05)
+
+
 def rank_failure_record(n, rc, diag_dir, stderr_tail):
     """the line a failed `bench.py --gpus N` prints instead of a measurement"""
     import glob
@@ -637,6 +648,7 @@ def main():
         args.gpus = world
     rank_note("started", devices_visible=torch.cuda.device_count())
     if not torch.cuda.is_available():
+        rank_wait_for_peers(world)
         raise SystemExit("bench.py needs an MI355X: no HIP device (there is no CPU fallback)")
     # JTX_DIST_BACKEND=gloo + JTX_ALL_RANKS_ON_DEVICE=0: rehearsal of the N > 1 code path on a one-GPU box (every
     # rank renders its shard on the same card, the exchange is staged through the host); never a measurement

@@ -1102,14 +1102,19 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 // tools/soak.py met the mapping where the path kernel then queued BEHIND the resolver, which waited for it -- a minute, its
                 // bounded wait, then an error.)  The resolver's stream is a high-priority one: a queue of its own where the runtime has one.
                 HIPCHK(hipEventRecord(s.prog_ready, stream));
-                if (const hipError_t le = jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, leave))
-                    throw std::runtime_error(std::string("k_render_paths (progressive): ") + hipGetErrorString(le));
+                bool launchPaths = true;
+                unsigned patienceMs = 0;                                   // (0: the resolver's default, a minute)
                 hipStream_t rstream = s.resolve_stream;
-#ifdef JTX_TEST_HOOKS       /* libjtx_mi_testhooks.so only: both kernels on ONE stream -- the serialised case, on a box whose streams do run side by side */
-                if (getenv("JTX_TEST_PROGRESSIVE_ONE_STREAM")) rstream = stream;
+#ifdef JTX_TEST_HOOKS       /* libjtx_mi_testhooks.so only */
+                if (getenv("JTX_TEST_PROGRESSIVE_ONE_STREAM")) rstream = stream;         // both kernels on ONE stream: the serialised case, on a box whose streams do run side by side
+                if (getenv("JTX_TEST_PROGRESSIVE_NO_PATH_KERNEL")) launchPaths = false;  // the path kernel never comes: the resolver's bounded wait ...
+                if (const char *e = getenv("JTX_TEST_RESOLVER_PATIENCE_MS")) patienceMs = (unsigned) atoi(e);      // ... shortened from a minute
 #endif
+                if (launchPaths)
+                    if (const hipError_t le = jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, leave))
+                        throw std::runtime_error(std::string("k_render_paths (progressive): ") + hipGetErrorString(le));
                 if (rstream != stream) HIPCHK(hipStreamWaitEvent(rstream, s.prog_ready, 0));
-                HIPCHK(jtx_launch_resolve_progressive(q, owned, nwaves, nr, s.prog_host_dev, s.prog_host_dev + kResolverMax, prog->epoch, rstream));
+                HIPCHK(jtx_launch_resolve_progressive(q, owned, nwaves, nr, s.prog_host_dev, s.prog_host_dev + kResolverMax, prog->epoch, rstream, patienceMs));
                 HIPCHK(hipEventRecord(s.prog_resolved, rstream));
                 HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true;
                 HIPCHK(hipEventRecord(s.prog_paths_done, stream));

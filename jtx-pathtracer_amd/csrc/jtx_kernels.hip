@@ -705,8 +705,8 @@ hipError_t jtx_launch_render_paths(const RenderParams &p, int num_owned_tiles, i
 namespace jtx {
 constexpr int RESOLVE_BLOCK = 256;
 constexpr unsigned RESOLVE_LAST = 0x80000000u;      // the leader's word: bit 31 = this count is final (every chunk dealt, every wave gone)
-constexpr unsigned RESOLVE_GAVE_UP = 0x40000000u;   // ... bit 30 = the leader gave up: nothing moved for RESOLVE_PATIENCE (the path kernel never came)
-constexpr unsigned long long RESOLVE_PATIENCE = 60ull * 100000000ull;   // s_memrealtime ticks (100 MHz): a minute without a chunk fetched or a wave's word moving
+constexpr unsigned RESOLVE_GAVE_UP = 0x40000000u;   // ... bit 30 = the leader gave up: nothing moved for the launch's patience (the path kernel never came)
+constexpr unsigned RESOLVE_PATIENCE_MS = 60000u;   // a minute without a chunk fetched or a wave's word moving (the launcher may pass another)
 
 // pixel slot -> its pixel; false for the padding slots of tiles that overhang the frame
 JD bool resolveSlot(const RenderParams &p, int pslot, size_t &pix) {
@@ -730,7 +730,7 @@ JD void resolveStore(const RenderParams &p, size_t pix, f3 acc, int sB) {
     }
 }
 
-__global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderParams p, int num_path_waves, unsigned *started_host, unsigned *progress_host, unsigned epoch) {
+__global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderParams p, int num_path_waves, unsigned *started_host, unsigned *progress_host, unsigned epoch, unsigned patience_ms) {
     __shared__ unsigned shWord, shOldest[RESOLVE_BLOCK / 64];
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     if (tid == 0) __hip_atomic_store(started_host + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
             const unsigned sig = shWord ^ (oldest * 0x9e3779b9u);
             const unsigned long long tNow = __builtin_amdgcn_s_memrealtime();
             if (sig != sigBefore) { sigBefore = sig; tMoved = tNow; }
-            const bool gaveUp = !last && tNow - tMoved > RESOLVE_PATIENCE;
+            const bool gaveUp = !last && tNow - tMoved > (unsigned long long) patience_ms * 100000ull;      // s_memrealtime ticks: 100 MHz
             if (gaveUp) last = true;
             const unsigned word = (unsigned) complete | (last ? RESOLVE_LAST : 0u) | (gaveUp ? RESOLVE_GAVE_UP : 0u);
             if (word != published) {
@@ -855,9 +855,10 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
 } // namespace jtx
 
 hipError_t jtx_launch_resolve_progressive(const RenderParams &p, int num_owned_tiles, int num_path_waves, int num_workgroups, unsigned *started_host,
-                                          unsigned *progress_host, unsigned epoch, hipStream_t stream) {
+                                          unsigned *progress_host, unsigned epoch, hipStream_t stream, unsigned patience_ms) {
     if (num_owned_tiles <= 0 || num_workgroups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_resolve_progressive, dim3((unsigned) num_workgroups), dim3(RESOLVE_BLOCK), 0, stream, p, num_path_waves, started_host, progress_host, epoch);
+    hipLaunchKernelGGL(k_resolve_progressive, dim3((unsigned) num_workgroups), dim3(RESOLVE_BLOCK), 0, stream, p, num_path_waves, started_host, progress_host, epoch,
+                       patience_ms ? patience_ms : RESOLVE_PATIENCE_MS);
     return hipGetLastError();
 }
 

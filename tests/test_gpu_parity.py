@@ -2192,6 +2192,55 @@ def test_progressive_launch_when_the_two_kernels_cannot_run_side_by_side(gpu, tm
     assert time.perf_counter() - t0 < 50.0                                      # (the resolver's bounded wait is a minute: it was never needed)
 
 
+_NO_PATH_KERNEL_CHILD = r"""
+import os, time
+import numpy as np
+import jtx_pathtracer_amd as gpu
+gpu._capi.check(gpu._capi.load().jtx_mi_set_device(0))
+data = gpu.scenes.cornell()
+sc = gpu.Scene(data); sc.buildBVH()
+ref = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); ref.samplesPerPass_ = 2
+ref.render(sc, progress=lambda c, t: None)
+os.environ["JTX_TEST_PROGRESSIVE_NO_PATH_KERNEL"] = "1"          # (read at every launch)
+os.environ["JTX_TEST_RESOLVER_PATIENCE_MS"] = "300"
+cam = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); cam.samplesPerPass_ = 2
+seen = []
+t0 = time.perf_counter()
+try:
+    cam.render(sc, progress=lambda c, t: seen.append(c))
+    raise SystemExit("the render without a path kernel returned success")
+except RuntimeError as e:
+    dt = time.perf_counter() - t0
+    assert "gave up" in str(e), str(e)
+assert seen == [] and 0.25 < dt < 10.0, (seen, dt)               # no pass was ever reported; the wait was the patience, not a minute
+del os.environ["JTX_TEST_PROGRESSIVE_NO_PATH_KERNEL"]
+again = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); again.samplesPerPass_ = 2
+seen = []
+again.render(sc, progress=lambda c, t: seen.append(c))
+assert seen == list(range(2, 17, 2)), seen
+assert np.array_equal(again.acc_.view(np.uint32), ref.acc_.view(np.uint32)) and np.array_equal(again.img_, ref.img_)
+sc.destroy()
+print("no-path-kernel: ok %.2f s" % dt)
+"""
+
+
+def test_progressive_resolver_gives_up_when_the_path_kernel_never_comes(gpu, tmp_path):
+    """The resolver of a progressive launch waits for a kernel it does not control; the wait is bounded (a minute without a chunk
+    fetched or a wave's word moving), it then ends with the passes it has and says so, and jtx_mi_render returns an error.  Exercised
+    with the hooks library: the path launch is skipped and the patience shortened to 0.3 s -- the error comes, no pass is reported,
+    nothing hangs, and the scene renders the right film afterwards."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "jtx-pathtracer_amd", "libjtx_mi_testhooks.so")
+    assert os.path.exists(lib), "build it with __graft_entry__.build() (jtx.build_test_hooks)"
+    script = tmp_path / "no_path_kernel_child.py"
+    script.write_text(_NO_PATH_KERNEL_CHILD)
+    env = dict(os.environ, JTX_MI_LIB=lib, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=200, env=env)
+    assert r.returncode == 0 and "no-path-kernel: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_frame_slot_memory_is_accounted_and_can_be_released(gpu, cornell_pair):
     """VERDICT r5 missing 5: the frame slots' working memory (the per-path radiance records of the persistent path kernel) is reported
     (scene_info.frame_slot_bytes, not part of device_bytes), capped per launch by opts.max_record_mb, and given back by
