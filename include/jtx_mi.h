@@ -258,7 +258,8 @@ int  jtx_mi_scene_get_wide(jtx_mi_scene *scene, uint32_t *granules_out, int64_t 
 /* StaticCamera::render(const Scene&) (camera.cpp:45-128), blocking.  acc_rgb: W*H*3 float sums
  * (AccumulationBuffer), img_rgb: W*H*3 u8 (RGB8Image); both HOST buffers owned by the caller.
  * With a callback, one pass = opts.samples_per_tick strata (samplesPerPass_, camera.hpp:181).  All passes of a frame go in ONE launch
- * of the persistent path kernel (integrateMIS; counting launches, the alternate Li and integrator 2 go pass by pass), a second kernel
+ * of the persistent path kernel (integrateMIS; counting launches, the alternate Li and integrator 2 go pass by pass; a range whose records
+ * exceed opts.max_record_mb, or of more than 32 767 passes, goes in several such launches, one after the other), a second kernel
  * beside it adding every finished pass to the film and the preview, in order.  cb(current_sample, total, user) runs once per pass, in
  * order, when that pass is in the film of EVERY pixel, while the launch goes on rendering; img_rgb then holds the preview as it
  * stood at that moment (what the UI uploads, display.cpp:702-703): every pixel shows at least current_sample strata, some already a

@@ -1178,7 +1178,8 @@ long jtx_prog_span(jtx_mi_scene *, const jtx_mi_camera_desc &cam, const jtx_mi_r
     { const char *e = getenv("JTX_MAX_RAD_MB"); if (e && atol(e) > 0) maxRad = (size_t) atol(e) << 20; }
     if (o.max_record_mb > 0) maxRad = (size_t) o.max_record_mb << 20;
     const size_t rowBytes = (size_t) (owned > 0 ? owned : 1) * 1024 * sizeof(float4);
-    const long perLaunch = (long) (maxRad / rowBytes) / tick * tick;          // whole passes
+    long perLaunch = (long) (maxRad / rowBytes) / tick * tick;                // whole passes
+    if (perLaunch > 32767l * tick) perLaunch = 32767l * tick;                 // (the resolver's words count groups in 15 bits; a group is at least a pass, or a whole fraction of a LONG one)
     if (perLaunch < tick) throw std::runtime_error("one pass of " + std::to_string(tick) + " strata does not fit the radiance-record cap: raise max_record_mb or lower samples_per_tick");
     return perLaunch;
 }

@@ -2151,6 +2151,16 @@ def test_progressive_launch_of_a_tile_shard_with_previews(gpu, cornell_pair):
     cap.render(sc, progress=lambda c, t: seen.append(c), max_record_mb=1)
     assert seen == list(range(1, 13))
     assert_same_f32(cap.acc_, whole.acc_, "progressive render under a 1 MB record cap"); assert (cap.img_ == whole.img_).all()
+    # very many passes: 190 x 190 strata at one per pass -- more than one launch's 15-bit pass counter holds, so two launches
+    many = gpu.StaticCamera(32, 32, data.camera, 190, 190, 3); many.samplesPerPass_ = 1
+    n = [0, 0]
+    def tick(c, t):
+        assert c == n[1] + 1
+        n[0] += 1; n[1] = c
+    many.render(sc, progress=tick)
+    batch = gpu.StaticCamera(32, 32, data.camera, 190, 190, 3); batch.render(sc)
+    assert n == [190 * 190, 190 * 190] and many.currentSample_ == 190 * 190
+    assert_same_f32(many.acc_, batch.acc_, "36 100 passes of one stratum"); assert (many.img_ == batch.img_).all()
 
 
 _ONE_STREAM_CHILD = r"""
