@@ -270,7 +270,11 @@ int  jtx_mi_scene_get_wide(jtx_mi_scene *scene, uint32_t *granules_out, int64_t 
  * flag when they fetch chunks of 64 x strata paths, so a running launch stops within microseconds of work per wave; a pass
  * that is unfinished then leaves no trace in the film.  Returns JTX_MI_CANCELLED then: acc_rgb / img_rgb hold EXACTLY the strata
  * [0, n) of every pixel -- what a render of sample_end = n gives, bit for bit -- and jtx_mi_last_completed_sample tells n (passes
- * that were already in flight when the stop arrived may be in it); 0 when the frame is complete. */
+ * that were already in flight when the stop arrived may be in it); 0 when the frame is complete.
+ * Threads: calls on ONE scene are serialised by the library, but the callback runs with the scene unlocked (it may call
+ * jtx_mi_cancel, jtx_mi_last_completed_sample, jtx_mi_scene_get_info): do not start another render or an edit of the same scene
+ * from it or beside it -- one blocking render per scene at a time (jtx_mi_render_device with opts.frame_slot is the interface for
+ * several frames of a scene in flight).  Different scenes are independent. */
 int jtx_mi_render(jtx_mi_scene *scene, const jtx_mi_camera_desc *cam, const jtx_mi_render_opts *opts,
                   float *acc_rgb, uint8_t *img_rgb, jtx_mi_progress_cb cb, void *user);
 int jtx_mi_cancel(jtx_mi_scene *scene);                                     /* Camera::terminateRender(); thread-safe */
