@@ -2301,6 +2301,13 @@ def test_headline_frame_against_the_oracle_in_every_pixel(gpu, cornell_pair):
     # ... and the counting kernel's tallies (the bench line's numerators) are the oracle's, the per-class ones included
     acc_c, img_c, cnt_g = _frame_on_device(gpu, sc, cam, 1, count=True)
     assert cnt_g == cnt and np.array_equal(acc_c.view(np.uint32), acc.view(np.uint32))
+    # ... and the frame as the reference's UI renders it -- a callback after every pass of ONE stratum (samplesPerPass_ = 1, camera.hpp:181):
+    # one progressive launch (k_render_paths<PROG> beside k_resolve_progressive), the same film in every pixel, 64 callbacks in order
+    ui = gpu.StaticCamera(W, H, data.camera, 8, 8, 8); ui.samplesPerPass_ = 1
+    seen = []
+    ui.render(sc, progress=lambda c, t: seen.append(c))
+    assert seen == list(range(1, 65))
+    assert np.array_equal(ui.acc_.view(np.uint32), acc.view(np.uint32)) and np.array_equal(ui.img_, img)
     assert t_oracle < 240
 
 
