@@ -1073,7 +1073,11 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 // the chunk counter, the closed-at word, the resolver leader's word and the waves' words on cache lines of their own: the
                 // counter takes every fetch of every wave, and a poll of a word on ITS line queues up with them
                 constexpr int kClosedAt = 32, kLeader = 64, kSlots = 128;
+#ifdef JTX_DBG_PROG
+                const size_t words = kSlots + 65536;                       // (+ the diagnostic build's per-wave fetch counts, hardware ids and the leader's snapshot)
+#else
                 const size_t words = kSlots + (size_t) nwaves;
+#endif
                 if (s.prog_ctl.n < words) { if (s.prog_ctl.p) HIPCHK(hipDeviceSynchronize()); s.prog_ctl.alloc(words + 1024); }
                 // closed-at and every wave's word: "none" (a wave that has not started holds no path); chunk counter and the resolver leader's word: 0
                 HIPCHK(hipMemsetAsync(s.prog_ctl.p, 0xff, words * sizeof(unsigned), stream));
@@ -1884,7 +1888,13 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                 done = jtx_prog_completed(s, run, &resolverGaveUp);
                 if (resolverGaveUp) throw std::runtime_error("progressive launch: the resolver waited a minute for the path kernel and gave up (the film holds the passes added so far)");
 #ifdef JTX_DBG_PROG      /* diagnostic build: the resolver leader's log of (time, groups dealt, groups out of every wave's hands) */
-                { unsigned h[48]; HIPCHK(hipMemcpy(h, s->prog_ctl.p + 64 + 16, sizeof h, hipMemcpyDeviceToHost)); for (unsigned i = 0; i < h[0] && i < 14; ++i) fprintf(stderr, "[leader] t %8.3f ms dealt groups %u by waves %u\n", (h[1 + 3 * i] - h[1]) / 1000.0, h[2 + 3 * i], h[3 + 3 * i]); }
+                { unsigned h[48]; HIPCHK(hipMemcpy(h, s->prog_ctl.p + 64 + 16, sizeof h, hipMemcpyDeviceToHost)); for (unsigned i = 0; i < h[0] && i < 14; ++i) fprintf(stderr, "[leader] t %8.3f ms dealt groups %u by waves %u\n", (h[1 + 3 * i] - h[1]) / 1000.0, h[2 + 3 * i], h[3 + 3 * i]);
+                  unsigned g[128]; HIPCHK(hipMemcpy(g, s->prog_ctl.p + 128 + 49152, sizeof g, hipMemcpyDeviceToHost));
+                  for (unsigned k = 0; k < 16; ++k) if (g[80 + k]) fprintf(stderr, "    SIMD wave slot %2u: %4u waves, mean fetches %6.2f, still holding group 0: %u\n", k, g[80 + k], (double) g[96 + k] / g[80 + k], g[112 + k]);
+                  fprintf(stderr, "[snapshot at 2 groups dealt, %.3f ms before the first line] waves seen %u, fetches min %u max %u mean %.2f; waves still holding group 0: %u (mean fetches %.2f)\n",
+                          (h[1] - g[7]) / 1000.0, g[5], g[2], g[3], g[5] ? (double) g[4] / g[5] : 0.0, g[0], g[0] ? (double) g[1] / g[0] : 0.0);
+                  for (unsigned i = 0; i < g[6] && i < 16; ++i) fprintf(stderr, "    wave %5u fetches %3u hw_id %08x (wave %u simd %u cu %u sh %u se %u) word %u\n", g[8 + 4 * i], g[9 + 4 * i], g[10 + 4 * i],
+                          g[10 + 4 * i] & 15u, (g[10 + 4 * i] >> 4) & 3u, (g[10 + 4 * i] >> 8) & 15u, (g[10 + 4 * i] >> 12) & 1u, (g[10 + 4 * i] >> 13) & 7u, g[11 + 4 * i]); }
 #endif
                 if (done < e0 || stopAsked) cancelled = true;
                 b0 = e0;

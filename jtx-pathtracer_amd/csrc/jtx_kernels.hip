@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     bool exhausted = false;
     int s = 0, slot = 0;                           // this lane's current path: stratum, pixel slot in the rank's frame
     bool alive = false, need = true;
+#ifdef JTX_DBG_PROG
+    int dbgFetches = 0;
+#endif
     while (true) {
         JTX_PROF_HANDOUT_BEGIN
         // ---- hand out paths to the lanes that need one ----
@@ -353,6 +356,14 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                 }
 #endif
                 c = __shfl(c, 0, 64);
+#ifdef JTX_DBG_PROG      /* diagnostic build: this wave's fetches so far and where it runs, beside its word (read by the resolver leader's snapshot) */
+                if constexpr (PROG) {
+                    ++dbgFetches;
+                    if (lane == 0) { const int w = (int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6);
+                                     __hip_atomic_store(p.prog_slots + 16384 + w, (unsigned) dbgFetches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                     if (dbgFetches == 1) __hip_atomic_store(p.prog_slots + 32768 + w, (unsigned) __builtin_amdgcn_s_getreg(63492), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                }
+#endif
                 if constexpr (PROG) {
                     int m = alive ? s : 0x7fffffff;                      // the oldest stratum this wave still has a path of ...
                     for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(m, off, 64); m = o < m ? o : m; }
@@ -739,6 +750,9 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
     if (wg == 0 && nwg > 1) {
         // ---- the leader: how many passes are complete?  (One workgroup watches the path waves, the others watch its word.) ----
         unsigned dealtSeen = 0u, published = 0u, sigBefore = 0xffffffffu;
+#ifdef JTX_DBG_PROG
+        bool dbgSnap = false;
+#endif
         unsigned long long tMoved = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) __hip_atomic_store(progress_host + wg, (epoch << 16) | (unsigned) p.num_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (no pixels of its own: never the minimum)
         while (true) {
@@ -766,6 +780,28 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
             unsigned oldest = shOldest[0];
             for (int i = 1; i < RESOLVE_BLOCK / 64; ++i) oldest = shOldest[i] < oldest ? shOldest[i] : oldest;
             __syncthreads();                                            // (shWord / shOldest are rewritten in the next round)
+#ifdef JTX_DBG_PROG      /* once, when two groups have been dealt: which waves still hold a path of group 0, how many chunks they and the others have fetched */
+            if (!dbgSnap && dealt >= 2u * (unsigned) p.num_subblocks) {
+                dbgSnap = true;
+                unsigned *dg = p.prog_slots + 49152;                     // [0] laggards [1] sum of their fetches [2] min fetches of all [3] max [4] sum of all [5] waves seen [6] entries, then (wave, fetches, hw id, word) x 16
+                if (tid < 48) dg[80 + tid] = 0u;
+                if (tid == 0) { dg[0] = dg[1] = dg[3] = dg[4] = dg[5] = dg[6] = 0u; dg[2] = 0xffffffffu; dg[7] = (unsigned) (__builtin_amdgcn_s_memrealtime() / 100); }
+                __threadfence(); __syncthreads();
+                for (int i = tid; i < num_path_waves; i += RESOLVE_BLOCK) {
+                    const unsigned v = atomicOr(p.prog_slots + i, 0u), f = atomicOr(p.prog_slots + 16384 + i, 0u), hw = atomicOr(p.prog_slots + 32768 + i, 0u);
+                    if (v == PROG_NONE && f == 0xffffffffu) continue;   // (never started)
+                    atomicAdd(dg + 5, 1u); atomicAdd(dg + 4, f); atomicMin(dg + 2, f); atomicMax(dg + 3, f);
+                    atomicAdd(dg + 80 + (hw & 15u), 1u); atomicAdd(dg + 96 + (hw & 15u), f);           // by the wave's slot in its SIMD
+                    if (v != PROG_NONE && (int) v < p.sample_begin + p.strata_per_group) atomicAdd(dg + 112 + (hw & 15u), 1u);
+                    if (v != PROG_NONE && (int) v < p.sample_begin + p.strata_per_group) {
+                        atomicAdd(dg + 0, 1u); atomicAdd(dg + 1, f);
+                        const unsigned e = atomicAdd(dg + 6, 1u);
+                        if (e < 16u) { dg[8 + 4 * e] = (unsigned) i; dg[9 + 4 * e] = f; dg[10 + 4 * e] = hw; dg[11 + 4 * e] = v; }
+                    }
+                }
+                __syncthreads();
+            }
+#endif
             const bool allGone = oldest == PROG_NONE;
             int complete = (int) (dealt / (unsigned) p.num_subblocks);
             if (!allGone) { const int byWaves = (int) oldest > p.sample_begin ? ((int) oldest - p.sample_begin) / p.strata_per_group : 0; complete = byWaves < complete ? byWaves : complete; }

@@ -28,6 +28,7 @@ unset JTX_FRAMES_IN_FLIGHT
 fi
 if [ $STAGE = progressive ] || [ $STAGE = all ]; then
 # round 6: the progressive launch (jtx_mi_render with a callback per pass): k_render_paths<.., PROG> beside k_resolve_progressive
+export JTX_PROBE_CHECK=0
 for spp in 1 8; do
   rm -rf gpurun_out/ks_r06_progressive_$spp
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_r06_progressive_$spp -- python3 tools/progressive_probe.py cornell $spp > gpurun_out/ks_r06_progressive_$spp.log 2>&1 || { echo "kstats progressive $spp failed"; tail -5 gpurun_out/ks_r06_progressive_$spp.log; exit 1; }
