@@ -1072,7 +1072,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 const int nwaves = jtx_render_paths_waves(q, s.num_cus, 1, leave);
                 // the chunk counter, the closed-at word, the resolver leader's word and the waves' words on cache lines of their own: the
                 // counter takes every fetch of every wave, and a poll of a word on ITS line queues up with them
-                constexpr int kClosedAt = 32, kLeader = 64, kSlots = 128;
+                constexpr int kClosedAt = jtx::PROG_CTL_CLOSED_AT, kLeader = jtx::PROG_CTL_LEADER, kSlots = jtx::PROG_CTL_SLOTS;
 #ifdef JTX_DBG_PROG
                 const size_t words = kSlots + 65536;                       // (+ the diagnostic build's per-wave fetch counts, hardware ids and the leader's snapshot)
 #else

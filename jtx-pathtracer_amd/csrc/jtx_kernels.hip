@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
         // before the first fetch: "this wave may hold paths of any stratum" (a wave that has not come this far holds none: its word
         // stays PROG_NONE, and every chunk it will ever fetch lies behind the counter)
         if ((threadIdx.x & 63) == 0)
-            __hip_atomic_store(p.prog_slots + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)), (unsigned) p.sample_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.work + PROG_CTL_SLOTS + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)), (unsigned) p.sample_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                     if (p.stop && (c & 63) == 0 && c < nchunks && __hip_atomic_load(p.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
                         if constexpr (PROG) {                            // the chunk in hand is traced: chunks [0, old) are all of the launch
                             const unsigned old = atomicMax(p.work, 0x40000000u);
-                            if (old < 0x40000000u) __hip_atomic_store(p.prog_closed_at, old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (old < 0x40000000u) __hip_atomic_store(p.work + PROG_CTL_CLOSED_AT, old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         } else { atomicMax(p.work, 0x40000000u); c = nchunks; }
                     }
                 }
@@ -360,8 +360,8 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                 if constexpr (PROG) {
                     ++dbgFetches;
                     if (lane == 0) { const int w = (int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6);
-                                     __hip_atomic_store(p.prog_slots + 16384 + w, (unsigned) dbgFetches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                     if (dbgFetches == 1) __hip_atomic_store(p.prog_slots + 32768 + w, (unsigned) __builtin_amdgcn_s_getreg(63492), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                                     __hip_atomic_store(p.work + PROG_CTL_SLOTS + 16384 + w, (unsigned) dbgFetches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                     if (dbgFetches == 1) __hip_atomic_store(p.work + PROG_CTL_SLOTS + 32768 + w, (unsigned) __builtin_amdgcn_s_getreg(63492), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 }
 #endif
                 if constexpr (PROG) {
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
                     const int first = c < nchunks ? p.sample_begin + (c / p.num_subblocks) * p.strata_per_group : 0x7fffffff;
                     m = first < m ? first : m;                           // ... or is about to start
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the records of the paths that have ended are out
-                    if (lane == 0) __hip_atomic_store(p.prog_slots + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)),
+                    if (lane == 0) __hip_atomic_store(p.work + PROG_CTL_SLOTS + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)),
                                                       m == 0x7fffffff ? PROG_NONE : (unsigned) m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (c >= nchunks) { exhausted = true; need = false; break; }
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(BS, SRC == SRC_WIDE ? JTX_WIDE_OCC : JTX_RP_OC
     }
     if constexpr (PROG) {                                               // gone: every record of this wave is out
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(p.prog_slots + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)), PROG_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(p.work + PROG_CTL_SLOTS + ((int) blockIdx.x * (BS / 64) + (int) (threadIdx.x >> 6)), PROG_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (SRC == SRC_WIDE) { JTX_PROF_WIDE_EXPORT(p, cnt) }
     JTX_PROF_PHASES_END(p, ps, lane, true)

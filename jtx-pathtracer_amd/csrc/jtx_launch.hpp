@@ -43,11 +43,15 @@ struct RenderParams {
     // launch for all passes.  prog_slots: one word per persistent wave -- the oldest stratum the wave still has a path of, or is about
     // to start (0xffffffff: not started yet / gone): every record below the minimum over all waves is written.  prog_closed_at: after a
     // cancellation the number of chunks that were dealt (the counter's value when it was closed), else 0xffffffff.
-    unsigned *prog_slots;
-    unsigned *prog_closed_at;
+    // All control words of a progressive launch are ONE allocation with the chunk counter (`work`) at its head, each on cache lines of its
+    // own (PROG_CTL_*): the path kernel addresses them from `work` -- two pointers fewer to keep in scalar registers across its loop.
+    unsigned *prog_slots;          // = work + PROG_CTL_SLOTS
+    unsigned *prog_closed_at;      // = work + PROG_CTL_CLOSED_AT
     unsigned *prog_leader;         // the resolver's own: complete passes | bit 31 when final, from its watching workgroup to the others
     int prog_groups_per_pass;      // the resolver adds whole passes only: strata groups in multiples of this (1 unless a long pass is cut into several groups)
 };
+
+constexpr int PROG_CTL_CLOSED_AT = 32, PROG_CTL_LEADER = 64, PROG_CTL_SLOTS = 128;      // words from the chunk counter
 
 // ---- wavefront integrator: slot-indexed SoA buffers in HBM (jtx_wavefront.hip) ----
 enum { WF_LIVE = 1, WF_TYPE_SHIFT = 8, WF_TYPE_MASK = 0xf00 };   // flags[]: extension ray pending / hit ready;
