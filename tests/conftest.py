@@ -19,6 +19,17 @@ def pytest_configure(config):
         os.environ.setdefault("JTX_ABORT_LOG", os.path.join(out, "jtx_abort.log"))
     except OSError:
         pass
+    # A fresh checkout running the CPU suite (-m "not gpu"): the host-side entry points these tests call (decoders, BVH builders, the
+    # export table) live in libjtx_mi.so and the oracle in oracle/_build -- build what is missing, as __graft_entry__.build() does.
+    # Never for the GPU tests: there a missing library is a failure, not something to paper over (fixture `gpu`).
+    if "not gpu" in (config.getoption("markexpr") or ""):
+        try:
+            import jtx_pathtracer_amd as jtx
+            if not jtx.lib_is_built() or not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libjtx_oracle.so")):
+                import __graft_entry__
+                __graft_entry__.build()
+        except Exception as e:                                # (the tests that need the library then say what is missing)
+            print("conftest: build of a fresh checkout failed:", e, file=sys.stderr)
 
 
 def _has_gpu():
