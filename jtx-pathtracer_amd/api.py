@@ -250,9 +250,9 @@ class MultiScene:
         check(self._lib.jtx_mi_multi_create(C.byref(desc), devs, len(devices), C.byref(h)))
         self._h, self.n = h, len(devices)
 
-    def render(self, cam, progress=None, samples_per_tick=0):
+    def render(self, cam, progress=None, samples_per_tick=0, max_record_mb=0):
         """jtx_mi_multi_render into cam.acc_ / cam.img_ (a StaticCamera); returns True when complete, False when cancelled."""
-        o = capi.RenderOpts(); o.samples_per_tick = samples_per_tick
+        o = capi.RenderOpts(); o.samples_per_tick = samples_per_tick; o.max_record_mb = max_record_mb
         cb = capi.PROGRESS_CB(lambda cur, tot, _u: 1 if (progress is not None and progress(cur, tot)) else 0)
         d = cam.desc()
         rc = self._lib.jtx_mi_multi_render(self._h, C.byref(d), C.byref(o), _fp(cam.acc_), cam.img_.ctypes.data_as(C.POINTER(C.c_uint8)), cb, None)

@@ -1129,6 +1129,12 @@ def test_multi_device_render_equals_one_device(gpu, cornell_pair, shards):
     cam4 = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
     assert ms.render(cam4, progress=lambda c, t: seen.append(c), samples_per_tick=1)
     assert seen == list(range(1, 9))
+    # ... and several launches per shard when the records of the range do not fit the cap (1 MB: a few strata of a shard of this frame)
+    seen = []
+    cam5 = gpu.StaticCamera(200, 100, data.camera, 4, 2, 4)
+    assert ms.render(cam5, progress=lambda c, t: seen.append(c), samples_per_tick=1, max_record_mb=1)
+    assert seen == list(range(1, 9))
+    assert_same_f32(cam5.acc_, ref.acc_, f"{shards} shards, capped records"); assert (cam5.img_ == ref.img_).all()
     assert_same_f32(cam4.acc_, ref.acc_, f"{shards} shards, 8 passes"); assert (cam4.img_ == ref.img_).all()
     ms.destroy()
 
