@@ -237,7 +237,17 @@ def test_pageable_caller_buffers_take_the_staged_path(gpu, cornell_pair, monkeyp
     plain.render(sc, sample_begin=3, sample_end=8)                             # the resumed accumulation is uploaded from pageable memory
     assert plain._pinned == []
     assert_same_f32(plain.acc_, pinned.acc_, "film through the staging buffers"); assert (plain.img_ == pinned.img_).all()
-    big_p = gpu.StaticCamera(1200, 800, data.camera, 1, 1, 3)                  # 11.5 MB of accumulation: two staging chunks
+    # ... and the previews of a progressive launch: copied to the library's page-locked buffer, then into the caller's pageable one
+    prog = gpu.StaticCamera(96, 64, data.camera, 4, 2, 4); prog.samplesPerPass_ = 2
+    seen, last_preview = [], []
+    def tick(c, t):
+        seen.append(c)
+        if c == t: last_preview.append(prog.img_.copy())
+    prog.render(sc, progress=tick)
+    assert prog._pinned == [] and seen == [2, 4, 6, 8]
+    assert_same_f32(prog.acc_, pinned.acc_, "progressive film through the staging buffers"); assert (prog.img_ == pinned.img_).all()
+    assert len(last_preview) == 1 and (last_preview[0] == pinned.img_).all()     # the preview of the last pass is the finished image
+    big_p =gpu.StaticCamera(1200, 800, data.camera, 1, 1, 3)                  # 11.5 MB of accumulation: two staging chunks
     big_u = gpu.StaticCamera(1200, 800, data.camera, 1, 1, 3)
     big_u.render(sc)
     monkeypatch.setenv("JTX_PIN_CAMERA_BUFFERS", "1")
