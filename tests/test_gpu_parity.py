@@ -2177,6 +2177,17 @@ def test_progressive_launch_of_a_tile_shard_with_previews(gpu, cornell_pair):
     batch = gpu.StaticCamera(32, 32, data.camera, 190, 190, 3); batch.render(sc)
     assert n == [190 * 190, 190 * 190] and many.currentSample_ == 190 * 190
     assert_same_f32(many.acc_, batch.acc_, "36 100 passes of one stratum"); assert (many.img_ == batch.img_).all()
+    # a caller without an RGB8 image (img_rgb = NULL, through the C-ABI directly): callbacks and the film as with one
+    import ctypes as C
+    capi = gpu._capi
+    acc_only = np.zeros((H, W, 3), np.float32)
+    o = capi.RenderOpts(); o.samples_per_tick = 5
+    seen = []
+    cb = capi.PROGRESS_CB(lambda cur, tot, _u: seen.append((cur, tot)) or 0)
+    d = whole.desc()
+    capi.check(capi.load().jtx_mi_render(sc.handle, C.byref(d), C.byref(o), acc_only.ctypes.data_as(C.POINTER(C.c_float)), None, cb, None))
+    assert seen == [(5, 12), (10, 12), (12, 12)]
+    assert_same_f32(acc_only, whole.acc_, "progressive render without an image buffer")
 
 
 _ONE_STREAM_CHILD = r"""
