@@ -2188,6 +2188,14 @@ def test_progressive_launch_of_a_tile_shard_with_previews(gpu, cornell_pair):
     capi.check(capi.load().jtx_mi_render(sc.handle, C.byref(d), C.byref(o), acc_only.ctypes.data_as(C.POINTER(C.c_float)), None, cb, None))
     assert seen == [(5, 12), (10, 12), (12, 12)]
     assert_same_f32(acc_only, whole.acc_, "progressive render without an image buffer")
+    # the smallest and a ragged frame (one pixel; 33 x 65: tiles that overhang on both sides)
+    for (w, h) in ((1, 1), (33, 65)):
+        a = gpu.StaticCamera(w, h, data.camera, 3, 3, 4); a.samplesPerPass_ = 2
+        seen = []
+        a.render(sc, progress=lambda c, t: seen.append(c))
+        b = gpu.StaticCamera(w, h, data.camera, 3, 3, 4); b.render(sc)
+        assert seen == [2, 4, 6, 8, 9]
+        assert_same_f32(a.acc_, b.acc_, f"progressive {w}x{h} frame"); assert (a.img_ == b.img_).all()
 
 
 _ONE_STREAM_CHILD = r"""
