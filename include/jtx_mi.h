@@ -394,7 +394,7 @@ int jtx_mi_sincos_batch(const float *x, int32_t n, float *out_sin, float *out_co
  *   JTX_TRACE_CREATE, JTX_TRACE_RENDER   host-side phase times of scene creation / of jtx_mi_render
  *   JTX_ABORT_LOG=<file>         a back trace into <file> when the process aborts or terminates on an uncaught exception
  * (libjtx_mi_testhooks.so -- test infrastructure, never the product -- also reads JTX_FAIL_REBUILD_BEFORE_COMMIT, JTX_TEST_REFUSE_PEER_ACCESS,
- *  JTX_TEST_PROGRESSIVE_ONE_STREAM, JTX_TEST_PROGRESSIVE_NO_PATH_KERNEL and JTX_TEST_RESOLVER_PATIENCE_MS.) */
+ *  JTX_TEST_PROGRESSIVE_ONE_STREAM, JTX_TEST_PROGRESSIVE_NO_PATH_KERNEL, JTX_TEST_PROGRESSIVE_DELAY_PATH_MS and JTX_TEST_RESOLVER_PATIENCE_MS.) */
 
 #ifdef __cplusplus
 }

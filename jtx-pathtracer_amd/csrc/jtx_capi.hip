@@ -9,6 +9,7 @@
 #include "jtx_progressive.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <csignal>
@@ -229,7 +230,8 @@ struct jtx_mi_scene {
     DevBuf<unsigned> prog_ctl;       // [0] chunk counter, [32] closed-at, [64] the resolver leader's word, [128 ..] one word per persistent wave (RenderParams::prog_slots)
     hipStream_t resolve_stream = nullptr, copy_stream = nullptr;   // the resolver's stream; the stream previews travel on
     hipEvent_t prog_ready = nullptr, prog_paths_done = nullptr, prog_resolved = nullptr;
-    unsigned *prog_host = nullptr;   // host-mapped: [0, 64) started, [64, 128) progress: one word per resolver workgroup
+    unsigned *prog_host = nullptr;   // host-mapped: [0, 128) started, [128, 256) progress: one word per resolver workgroup; [256] the host's word for the path kernel
+    unsigned prog_live_epoch = 0;
     unsigned *prog_host_dev = nullptr;
     unsigned prog_epoch = 0;
     DevScene dev{};
@@ -1092,11 +1094,13 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 }
                 for (hipEvent_t *e : {&s.prog_ready, &s.prog_paths_done, &s.prog_resolved}) if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
                 if (!s.prog_host) {
-                    HIPCHK(hipHostMalloc((void **) &s.prog_host, 2 * kResolverMax * sizeof(unsigned), hipHostMallocMapped));
-                    std::memset(s.prog_host, 0, 2 * kResolverMax * sizeof(unsigned));
+                    HIPCHK(hipHostMalloc((void **) &s.prog_host, (2 * kResolverMax + 16) * sizeof(unsigned), hipHostMallocMapped));
+                    std::memset(s.prog_host, 0, (2 * kResolverMax + 16) * sizeof(unsigned));
                     void *d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, s.prog_host, 0)); s.prog_host_dev = (unsigned *) d;
                 }
                 prog->epoch = (++s.prog_epoch & 0x7fffu) + 1u;
+                s.prog_live_epoch = prog->epoch;                           // (jtx_prog_finished vouches for this launch's path kernel while it has not ended)
+                __atomic_store_n(s.prog_host + 2 * kResolverMax, prog->epoch, __ATOMIC_RELEASE);
                 const int nr = prog->resolver_wgs;
                 // The PATH KERNEL FIRST, then the resolver on its own stream (not before the film and the control words stand).  The path grid
                 // leaves the resolver's wave slots free, so the resolver starts beside it at once -- when the two streams run side by side.
@@ -1111,6 +1115,10 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                 hipStream_t rstream = s.resolve_stream;
 #ifdef JTX_TEST_HOOKS       /* libjtx_mi_testhooks.so only */
                 if (getenv("JTX_TEST_PROGRESSIVE_ONE_STREAM")) rstream = stream;         // both kernels on ONE stream: the serialised case, on a box whose streams do run side by side
+                if (const char *e = getenv("JTX_TEST_PROGRESSIVE_DELAY_PATH_MS")) {      // the path kernel comes late (as behind another process' long launch): a host function holds its stream
+                    static std::atomic<int> delayMs{0}; delayMs = atoi(e);
+                    HIPCHK(hipLaunchHostFunc(stream, [](void *) { std::this_thread::sleep_for(std::chrono::milliseconds(delayMs.load())); }, nullptr));
+                }
                 if (getenv("JTX_TEST_PROGRESSIVE_NO_PATH_KERNEL")) launchPaths = false;  // the path kernel never comes: the resolver's bounded wait ...
                 if (const char *e = getenv("JTX_TEST_RESOLVER_PATIENCE_MS")) patienceMs = (unsigned) atoi(e);      // ... shortened from a minute
 #endif
@@ -1118,7 +1126,7 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                     if (const hipError_t le = jtx_launch_render_paths(q, owned, s.num_cus, stream, 1, true, leave))
                         throw std::runtime_error(std::string("k_render_paths (progressive): ") + hipGetErrorString(le));
                 if (rstream != stream) HIPCHK(hipStreamWaitEvent(rstream, s.prog_ready, 0));
-                HIPCHK(jtx_launch_resolve_progressive(q, owned, nwaves, nr, s.prog_host_dev, s.prog_host_dev + kResolverMax, prog->epoch, rstream, patienceMs));
+                HIPCHK(jtx_launch_resolve_progressive(q, owned, nwaves, nr, s.prog_host_dev, s.prog_host_dev + kResolverMax, s.prog_host_dev + 2 * kResolverMax, prog->epoch, rstream, patienceMs));
                 HIPCHK(hipEventRecord(s.prog_resolved, rstream));
                 HIPCHK(hipEventRecord(ev.second, stream)); evClosed = true;
                 HIPCHK(hipEventRecord(s.prog_paths_done, stream));
@@ -1233,7 +1241,10 @@ int jtx_prog_completed(jtx_mi_scene *s, const JtxProgRun &run, bool *gave_up) {
 bool jtx_prog_finished(jtx_mi_scene *s) {
     if (!s->prog_resolved || !s->prog_paths_done) return true;
     DeviceGuard dg(s->device);
-    const bool f = hipEventQuery(s->prog_resolved) == hipSuccess && hipEventQuery(s->prog_paths_done) == hipSuccess;
+    const bool paths = hipEventQuery(s->prog_paths_done) == hipSuccess;
+    // the host's word for a path kernel that has not ended (it may still be waiting its turn): the resolver does not give up on it
+    if (!paths && s->prog_host) __atomic_store_n(s->prog_host + 2 * kResolverMax, s->prog_live_epoch, __ATOMIC_RELEASE);
+    const bool f = paths && hipEventQuery(s->prog_resolved) == hipSuccess;
     (void) hipGetLastError();
     return f;
 }

@@ -741,8 +741,9 @@ JD void resolveStore(const RenderParams &p, size_t pix, f3 acc, int sB) {
     }
 }
 
-__global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderParams p, int num_path_waves, unsigned *started_host, unsigned *progress_host, unsigned epoch, unsigned patience_ms) {
-    __shared__ unsigned shWord, shOldest[RESOLVE_BLOCK / 64];
+__global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderParams p, int num_path_waves, unsigned *started_host, unsigned *progress_host, unsigned *keepalive_host, unsigned epoch,
+                                                                          unsigned patience_ms) {
+    __shared__ unsigned shWord, shGive, shOldest[RESOLVE_BLOCK / 64];
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     if (tid == 0) __hip_atomic_store(started_host + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int nchunks = p.num_subblocks * p.num_groups;
@@ -753,7 +754,7 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
 #ifdef JTX_DBG_PROG
         bool dbgSnap = false;
 #endif
-        unsigned long long tMoved = __builtin_amdgcn_s_memrealtime();
+        unsigned long long tMoved = 0ull;                             // (thread 0's: when something last moved)
         if (tid == 0) __hip_atomic_store(progress_host + wg, (epoch << 16) | (unsigned) p.num_groups, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (no pixels of its own: never the minimum)
         while (true) {
             if (tid == 0) {
@@ -808,12 +809,26 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
             if (complete >= p.num_groups) complete = p.num_groups;
             else complete = complete / p.prog_groups_per_pass * p.prog_groups_per_pass;    // whole passes only (a cancellation may end the launch inside one)
             bool last = allGone && dealtFinal;
-            // a bounded wait: should nothing move for a minute -- no chunk fetched, no wave's word changed (a path launch that failed
-            // behind this one's enqueue, a path kernel that hangs) -- the resolver ends, with the passes it has, and says so
+            // a bounded wait: should nothing move for a minute -- no chunk fetched, no wave's word changed -- AND the host no longer vouch for
+            // the path kernel, the resolver ends, with the passes it has, and says so.  The host vouches (a word in host-mapped memory, rewritten
+            // by its polling loop) as long as the path kernel has not ended: a path kernel that waits its turn behind another process' or
+            // another scene's long launch is no reason to give up.  ONE thread reads the clock (the waves of a workgroup read it at different
+            // moments: each deciding for itself could split the workgroup at its barrier).
             const unsigned sig = shWord ^ (oldest * 0x9e3779b9u);
-            const unsigned long long tNow = __builtin_amdgcn_s_memrealtime();
-            if (sig != sigBefore) { sigBefore = sig; tMoved = tNow; }
-            const bool gaveUp = !last && tNow - tMoved > (unsigned long long) patience_ms * 100000ull;      // s_memrealtime ticks: 100 MHz
+            if (sig != sigBefore) { sigBefore = sig; tMoved = 0ull; }        // (0: take the time at the next look)
+            if (tid == 0) {
+                const unsigned long long tNow = __builtin_amdgcn_s_memrealtime();
+                if (tMoved == 0ull) tMoved = tNow;
+                bool give = !last && tNow - tMoved > (unsigned long long) patience_ms * 100000ull;      // s_memrealtime ticks: 100 MHz
+                if (give && __hip_atomic_load(keepalive_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) {
+                    __hip_atomic_store(keepalive_host, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (used up: the host writes it again while it still holds)
+                    tMoved = tNow; give = false;
+                }
+                shGive = give ? 1u : 0u;
+            }
+            __syncthreads();
+            const bool gaveUp = shGive != 0u;
+            __syncthreads();                                            // (shGive is rewritten in the next round)
             if (gaveUp) last = true;
             const unsigned word = (unsigned) complete | (last ? RESOLVE_LAST : 0u) | (gaveUp ? RESOLVE_GAVE_UP : 0u);
             if (word != published) {
@@ -891,10 +906,10 @@ __global__ void __launch_bounds__(RESOLVE_BLOCK) k_resolve_progressive(RenderPar
 } // namespace jtx
 
 hipError_t jtx_launch_resolve_progressive(const RenderParams &p, int num_owned_tiles, int num_path_waves, int num_workgroups, unsigned *started_host,
-                                          unsigned *progress_host, unsigned epoch, hipStream_t stream, unsigned patience_ms) {
+                                          unsigned *progress_host, unsigned *keepalive_host, unsigned epoch, hipStream_t stream, unsigned patience_ms) {
     if (num_owned_tiles <= 0 || num_workgroups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_resolve_progressive, dim3((unsigned) num_workgroups), dim3(RESOLVE_BLOCK), 0, stream, p, num_path_waves, started_host, progress_host, epoch,
-                       patience_ms ? patience_ms : RESOLVE_PATIENCE_MS);
+    hipLaunchKernelGGL(k_resolve_progressive, dim3((unsigned) num_workgroups), dim3(RESOLVE_BLOCK), 0, stream, p, num_path_waves, started_host, progress_host,
+                       keepalive_host, epoch, patience_ms ? patience_ms : RESOLVE_PATIENCE_MS);
     return hipGetLastError();
 }
 

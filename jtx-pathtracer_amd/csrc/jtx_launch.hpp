@@ -138,9 +138,11 @@ hipError_t jtx_launch_render_paths(const jtx::RenderParams &p, int num_owned_til
 int jtx_resolve_progressive_waves(int num_workgroups);    // wave slots the resolver takes
 // the resolver of a progressive launch (beside k_render_paths<.., PROG>, on a stream of its own): num_path_waves words in p.prog_slots; every workgroup
 // writes its word of started_host when it runs and of progress_host (epoch << 16 | groups in the film of its pixels) as it goes
-// patience_ms: how long the resolver waits without a chunk fetched or a wave's word moving before it gives up (0: a minute)
+// patience_ms: how long the resolver waits without a chunk fetched or a wave's word moving before it gives up (0: a minute) -- unless the host
+// vouches for the path kernel: *keepalive_host == epoch (host-mapped; the resolver clears it, the host's polling loop rewrites it while the path
+// kernel has not ended)
 hipError_t jtx_launch_resolve_progressive(const jtx::RenderParams &p, int num_owned_tiles, int num_path_waves, int num_workgroups, unsigned *started_host,
-                                          unsigned *progress_host, unsigned epoch, hipStream_t stream, unsigned patience_ms = 0);
+                                          unsigned *progress_host, unsigned *keepalive_host, unsigned epoch, hipStream_t stream, unsigned patience_ms = 0);
 int jtx_render_paths_waves(const jtx::RenderParams &p, int num_cus, int share, int leave_waves);   // waves jtx_launch_render_paths starts for p
 int jtx_render_paths_grid(const jtx::DevScene &sc, int num_cus, int *block_size);   // workgroups the persistent grid holds (host only)
 hipError_t jtx_launch_render_alt(const jtx::RenderParams &p, int num_owned_tiles, bool count, int li, hipStream_t stream);

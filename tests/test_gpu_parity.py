@@ -2259,6 +2259,17 @@ except RuntimeError as e:
     assert "gave up" in str(e), str(e)
 assert seen == [] and 0.25 < dt < 10.0, (seen, dt)               # no pass was ever reported; the wait was the patience, not a minute
 del os.environ["JTX_TEST_PROGRESSIVE_NO_PATH_KERNEL"]
+# ... but a path kernel that is merely LATE -- its stream held for 0.5 s, as behind another process' long launch, five times the resolver's patience here --
+# is waited for: the host vouches for it as long as it has not ended
+os.environ["JTX_TEST_RESOLVER_PATIENCE_MS"] = "100"
+os.environ["JTX_TEST_PROGRESSIVE_DELAY_PATH_MS"] = "500"
+late = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); late.samplesPerPass_ = 2
+seen = []
+t0 = time.perf_counter()
+late.render(sc, progress=lambda c, t: seen.append(c))
+assert time.perf_counter() - t0 > 0.45 and seen == list(range(2, 17, 2)), (time.perf_counter() - t0, seen)
+assert np.array_equal(late.acc_.view(np.uint32), ref.acc_.view(np.uint32)) and np.array_equal(late.img_, ref.img_)
+del os.environ["JTX_TEST_PROGRESSIVE_DELAY_PATH_MS"]
 again = gpu.StaticCamera(320, 200, data.camera, 4, 4, 4); again.samplesPerPass_ = 2
 seen = []
 again.render(sc, progress=lambda c, t: seen.append(c))
@@ -2273,7 +2284,8 @@ def test_progressive_resolver_gives_up_when_the_path_kernel_never_comes(gpu, tmp
     """The resolver of a progressive launch waits for a kernel it does not control; the wait is bounded (a minute without a chunk
     fetched or a wave's word moving), it then ends with the passes it has and says so, and jtx_mi_render returns an error.  Exercised
     with the hooks library: the path launch is skipped and the patience shortened to 0.3 s -- the error comes, no pass is reported,
-    nothing hangs, and the scene renders the right film afterwards."""
+    nothing hangs, and the scene renders the right film afterwards.  A path kernel that is merely late (its stream held for five times the
+    patience) is waited for: the host's polling loop vouches for it in host-mapped memory until it has ended."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
