@@ -2298,6 +2298,38 @@ def test_progressive_resolver_gives_up_when_the_path_kernel_never_comes(gpu, tmp
     assert r.returncode == 0 and "no-path-kernel: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def test_two_scenes_render_progressively_at_the_same_time(gpu):
+    """Different scenes are independent (jtx_mi.h): two host threads, each with a scene and a camera of its own, render progressive frames
+    -- a callback after every stratum -- at the same time on one device.  Each launch wants the whole chip (persistent waves) and brings a
+    resolver: whichever path kernel comes second waits its turn, its resolver beside it does not give up on it, and every film is the
+    film of the scene rendered alone."""
+    import threading
+    jobs = []
+    for make, (w, h), (xs, ys) in ((gpu.scenes.cornell, (640, 360), (4, 4)), (lambda: gpu.scenes.atrium(target_tris=20000), (480, 272), (3, 3))):
+        data = make()
+        sc = gpu.Scene(data); sc.buildBVH()
+        ref = gpu.StaticCamera(w, h, data.camera, xs, ys, 5); ref.render(sc)
+        jobs.append((data, sc, ref, w, h, xs, ys))
+    errors = []
+    def work(job):
+        data, sc, ref, w, h, xs, ys = job
+        try:
+            for _ in range(6):
+                cam = gpu.StaticCamera(w, h, data.camera, xs, ys, 5); cam.samplesPerPass_ = 1
+                seen = []
+                cam.render(sc, progress=lambda c, t: seen.append(c))
+                assert seen == list(range(1, xs * ys + 1)), seen
+                assert np.array_equal(cam.acc_.view(np.uint32), ref.acc_.view(np.uint32)) and np.array_equal(cam.img_, ref.img_)
+                cam._unpin()
+        except BaseException as e:          # noqa: BLE001 (reported by the main thread)
+            errors.append(repr(e))
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    for j in jobs: j[1].destroy()
+
+
 def test_frame_slot_memory_is_accounted_and_can_be_released(gpu, cornell_pair):
     """VERDICT r5 missing 5: the frame slots' working memory (the per-path radiance records of the persistent path kernel) is reported
     (scene_info.frame_slot_bytes, not part of device_bytes), capped per launch by opts.max_record_mb, and given back by
