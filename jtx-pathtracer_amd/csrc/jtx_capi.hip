@@ -1893,7 +1893,7 @@ int jtx_mi_render(jtx_mi_scene *s, const jtx_mi_camera_desc *cam, const jtx_mi_r
                         }
                     }
                     if (finished) break;
-                    if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield();
+                    if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(idle > 2048 ? 200 : 20)); else std::this_thread::yield();   // (a long pass: the poll backs off)
                 }
                 HIPCHK(hipStreamSynchronize(s->stream));
                 done = jtx_prog_completed(s, run, &resolverGaveUp);

@@ -344,7 +344,7 @@ int jtx_mi_multi_render(jtx_mi_multi *m, const jtx_mi_camera_desc *cam, const jt
                         }
                     }
                     if (finished) break;
-                    if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(20)); else std::this_thread::yield();
+                    if (++idle > 64) std::this_thread::sleep_for(std::chrono::microseconds(idle > 2048 ? 200 : 20)); else std::this_thread::yield();   // (a long pass: the poll backs off)
                 }
                 for (int r = 0; r < n; ++r) { SetDev sd(m->shards[r].device); MHIPCHK(hipStreamSynchronize(m->shards[r].stream)); }
                 if (gaveUp) throw std::runtime_error("progressive launch: a shard's resolver waited a minute for its path kernel and gave up");
