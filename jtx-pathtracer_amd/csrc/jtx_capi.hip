@@ -1099,6 +1099,8 @@ void launchRender(jtx_mi_scene &s, const jtx_mi_camera_desc &cam, const jtx_mi_r
                     void *d = nullptr; HIPCHK(hipHostGetDevicePointer(&d, s.prog_host, 0)); s.prog_host_dev = (unsigned *) d;
                 }
                 prog->epoch = (++s.prog_epoch & 0x7fffu) + 1u;
+                // (the resolver's words of the launch before: none may read as this launch's when the 15-bit epoch comes round -- the launch before has ended)
+                for (int w = 0; w < 2 * kResolverMax; ++w) __atomic_store_n(s.prog_host + w, 0u, __ATOMIC_RELAXED);
                 s.prog_live_epoch = prog->epoch;                           // (jtx_prog_finished vouches for this launch's path kernel while it has not ended)
                 __atomic_store_n(s.prog_host + 2 * kResolverMax, prog->epoch, __ATOMIC_RELEASE);
                 const int nr = prog->resolver_wgs;
